@@ -1,0 +1,248 @@
+/* sigtk_gpu.h -- C ABI of libsigtk_gpu.so: sigtk's per-read raw-signal hot path
+ * (pa / event / stat / jnn / prefix) as batched HIP kernels for AMD MI355X (gfx950).
+ *
+ * The reference (hasindu2008/sigtk, C99, single-threaded) has no FFI layer: its seam is
+ * the per-record function-pointer slot `void (*func)(slow5_rec_t*, opt_t)` in
+ * src/cmain.c:95-120 and, below it, the compute entry points declared in
+ * src/sigtk.h:124-134 and src/jnn.h:104-109.  This header is what a sigtk maintainer
+ * would bind instead of those entry points (see INTEGRATION.md for the stub):
+ *
+ *   reference (file:line)                         replaced by
+ *   --------------------------------------------  -------------------------------------
+ *   signal_in_picoamps   src/misc.c:15            sgk_pa            / sgk_signal_in_picoamps
+ *   getevents            src/events.c:553         sgk_event         / sgk_getevents
+ *   meanf..mediani16     src/stat.h:17-73         sgk_stat
+ *   jnn_raw/jnn_print    src/jnn.c:282,309        sgk_jnn
+ *   find_adaptor/jnnv2   src/jnn.c:99,181         sgk_prefix
+ *   find_polya/jnn_pa    src/jnn.c:295,352        sgk_prefix
+ *   prefix_func compute  src/cfunc.c:169-216      sgk_prefix
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only.  No exceptions, no exit(): every function returns
+ *     SGK_OK (0) or a negative sgk error code; sgk_strerror() names it.
+ *   - "Device API" functions take DEVICE pointers and a hipStream_t passed as void*
+ *     (NULL = default stream) and only enqueue work; nothing is synchronised.
+ *   - "Host API" functions (suffix _host and the per-read shims) take HOST pointers,
+ *     stage through the GPU and synchronise before returning.  Results they allocate are
+ *     released with the matching *_free function.
+ *   - The library never falls back to a CPU implementation: without a usable GPU every
+ *     compute entry point returns SGK_ERR_NODEVICE / SGK_ERR_HIP.
+ *
+ * Batch layout (structure of arrays, one batch = many reads):
+ *   samples  int16 raw samples of all reads in one buffer; 16-byte aligned; n_samples is the
+ *            readable length of the buffer in samples and must be a multiple of 8;
+ *   offsets  n_reads sample indices, lengths n_reads sample counts: read r is
+ *            samples[offsets[r] .. offsets[r]+lengths[r]).  Reads must be stored in
+ *            increasing, non-overlapping order; gaps between reads are allowed (and ignored),
+ *            which lets a packer start every read on an aligned boundary.  Any offsets are
+ *            accepted; reads starting on a multiple of 8 samples (16 bytes) take the
+ *            vectorised load path (the host packer aligns to 64 samples = 128 bytes);
+ *   digitisation/offset/range  the three per-read doubles of slow5_rec_t
+ *            (slow5lib/include/slow5/slow5_defs.h:84-92), narrowed to float on the device
+ *            exactly as src/misc.c:17-19 does.
+ */
+#ifndef SIGTK_GPU_H
+#define SIGTK_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGK_VERSION_STRING "0.1.0"
+
+/* ---- error codes --------------------------------------------------------------- */
+#define SGK_OK 0
+#define SGK_ERR_ARG (-1)        /* NULL / inconsistent argument                         */
+#define SGK_ERR_HIP (-2)        /* a HIP runtime call failed (sgk_last_hip_error())      */
+#define SGK_ERR_NODEVICE (-3)   /* no usable GPU                                        */
+#define SGK_ERR_WORKSPACE (-4)  /* workspace too small (see *_workspace_bytes)          */
+#define SGK_ERR_CAPACITY (-5)   /* an output arena slot range was too small             */
+#define SGK_ERR_ALIGN (-6)      /* samples buffer not 16-byte aligned                   */
+#define SGK_ERR_NOMEM (-7)      /* host allocation failed                               */
+
+const char *sgk_strerror(int code);
+const char *sgk_version(void);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *sgk_last_hip_error(void);
+/* number of visible GPUs (0 if none / HIP unusable); never fails */
+int sgk_device_count(void);
+/* bind the calling thread to a GPU ordinal */
+int sgk_set_device(int ordinal);
+
+/* pore ids, as OPT_PORE_* in src/sigtk.h:50-52 */
+#define SGK_PORE_R9 0
+#define SGK_PORE_R10 1
+#define SGK_PORE_RNA004 2
+
+/* ---- batch view (device pointers) ---------------------------------------------- */
+typedef struct sgk_batch {
+    const int16_t *samples;
+    const uint64_t *offsets;   /* n_reads: first sample of each read */
+    const uint32_t *lengths;   /* n_reads: samples in each read (len_raw_signal) */
+    const double *digitisation;
+    const double *offset;
+    const double *range;
+    uint32_t n_reads;
+    uint32_t max_read_len; /* max over reads of lengths[r]; host-known */
+    uint64_t n_samples;    /* readable length of `samples` (multiple of 8; all reads lie inside) */
+} sgk_batch_t;
+
+/* ---- pa: int16 -> picoamps (src/misc.c:15-32) ----------------------------------- */
+/* pa_out[offsets[r]+i] for every sample i of every read r (same layout as `samples`;
+ * gap samples are not written). */
+int sgk_pa(const sgk_batch_t *batch, float *pa_out, void *stream);
+
+/* ---- event: Scrappie-derived event detection (src/events.c:553) ------------------ */
+/* Events of read r are written to slots ev_slots[r] .. ev_slots[r]+n_events[r]-1 of the
+ * four SoA arrays (start = first raw sample, length in samples, mean/stdv in pA):
+ * event_t of src/sigtk.h:55-62 as structure-of-arrays with integer start/length.
+ * ev_slots (device, n_reads+1, increasing) is an INPUT describing the arena: read r may
+ * use at most ev_slots[r+1]-ev_slots[r] slots.  sgk_event_slots_for() gives a capacity
+ * that can never overflow (peaks are at least 3 samples apart).  If a read would
+ * overflow, its surplus events are dropped, n_events[r] still holds the true count and
+ * the status word reports it (sgk_event_status -> SGK_ERR_CAPACITY).
+ * Where the reference aborts or is undefined the library defines: a read with no peak
+ * (incl. reads shorter than 2*window) yields one event [0,n); empty reads yield none. */
+static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 2; }
+
+size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
+
+int sgk_event(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
+              uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *workspace,
+              size_t workspace_bytes, void *stream);
+
+/* Same path fed with pA floats instead of raw int16 (drop-in for getevents(), whose input
+ * is the pA array): pa is packed like `samples` (float per sample, 16-byte aligned). */
+int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
+                 uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *workspace,
+                 size_t workspace_bytes, void *stream);
+
+typedef struct sgk_event_status {
+    uint32_t n_fallback_reads;   /* reads re-done by the sequential-prefix exact path     */
+    uint32_t n_rerun_passes;     /* speculative chunk boundaries that needed a re-run     */
+    uint32_t n_capacity_overflow;/* reads whose events did not fit their slot range       */
+    uint32_t reserved;
+    uint64_t n_events_total;
+} sgk_event_status_t;
+/* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.
+ * Returns SGK_ERR_CAPACITY if any read overflowed its slots. */
+int sgk_event_status(const void *workspace, sgk_event_status_t *out, void *stream);
+
+/* ---- stat: per-read mean/std/median of raw and pA (src/stat.h, src/cfunc.c:126-159) */
+typedef struct sgk_stat_rec {
+    float raw_mean, pa_mean, raw_std, pa_std;
+    int32_t raw_median;
+    float pa_median;
+    uint32_t n;
+    uint32_t reserved;
+} sgk_stat_rec_t; /* 32 bytes per read */
+
+size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
+int sgk_stat(const sgk_batch_t *batch, sgk_stat_rec_t *out, void *workspace, size_t workspace_bytes,
+             void *stream);
+/* fused stat + pa (BASELINE config 4): one launch sequence producing both outputs */
+int sgk_stat_pa(const sgk_batch_t *batch, sgk_stat_rec_t *out, float *pa_out, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* ---- jnn: state-machine segmenter on raw signal (src/jnn.c:190-350) --------------- */
+/* Segments of read r go to slots seg_slots[r].. (same arena convention as events);
+ * seg_x/seg_y are jnn_pair_t (src/jnn.h:13-16) as SoA with 32-bit members. */
+static inline uint64_t sgk_jnn_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 32 + 2; }
+size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
+int sgk_jnn(const sgk_batch_t *batch, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
+            uint32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- prefix: adaptor / polyA finder (src/cfunc.c:169-216, src/jnn.c:99-188,352-374) */
+typedef struct sgk_prefix_rec {
+    int32_t adapt_x, adapt_y;  /* find_adaptor(): -1/-1 read too short, 0/0 none found  */
+    int32_t polya_x, polya_y;  /* find_polya(), RELATIVE to adapt_y; -1/-1 if none      */
+    float adapt_mean, adapt_std, adapt_median;
+    float polya_mean, polya_std, polya_median;
+    uint32_t n;
+    uint32_t reserved;
+} sgk_prefix_rec_t; /* 48 bytes per read */
+
+size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
+int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
+               size_t workspace_bytes, void *stream);
+
+/* ---- synthetic reads (BASELINE configs 2-5) ---------------------------- */
+/* Deterministic counter-based generator, identical on host and device (integer only).
+ * kind 0: DNA-like (mean dwell 9 samples); kind 1: RNA-like (mean dwell 36, adaptor +
+ * polyA prefix structure).  Read r of the batch is global read index first_read + r. */
+int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *digitisation,
+                    double *offset, double *range, uint32_t n_reads, uint32_t max_read_len,
+                    uint64_t first_read, uint64_t seed, int kind, void *stream); /* device pointers */
+void sgk_synth_reads_host(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths,
+                          double *digitisation, double *offset, double *range, uint32_t n_reads,
+                          uint64_t first_read, uint64_t seed, int kind);
+
+/* ---- per-launch timing (HIP events on the caller's stream) ------------------------ */
+/* When enabled, every device-API call records hipEvents around each kernel it launches;
+ * sgk_profile_read() synchronises and returns the accumulated milliseconds per kernel
+ * name since the last reset.  Used by bench.py for the roofline figure. */
+void sgk_profile_enable(int on);
+void sgk_profile_reset(void);
+/* names/ms/calls: caller arrays of length cap; returns the number of distinct kernels */
+int sgk_profile_read(const char **names, double *ms, uint32_t *calls, int cap);
+
+/* ================================ Host API ======================================== */
+
+typedef struct sgk_host_batch {
+    const int16_t *samples;   /* host, packed; no alignment/padding requirement */
+    const uint64_t *offsets;  /* host, n_reads+1 */
+    const double *digitisation, *offset, *range; /* host, n_reads */
+    uint32_t n_reads;
+} sgk_host_batch_t;
+
+typedef struct sgk_events_host {
+    uint32_t n_reads;
+    uint64_t *ev_offsets; /* n_reads+1, compact CSR: events of read r are [ev_offsets[r], ev_offsets[r+1]) */
+    uint32_t *start, *length;
+    float *mean, *stdv;
+    sgk_event_status_t status;
+} sgk_events_host_t;
+int sgk_event_host(const sgk_host_batch_t *batch, int rna, sgk_events_host_t *out);
+void sgk_events_host_free(sgk_events_host_t *ev);
+
+int sgk_pa_host(const sgk_host_batch_t *batch, float *pa_out /* host, n_samples */);
+int sgk_stat_host(const sgk_host_batch_t *batch, sgk_stat_rec_t *out /* host, n_reads */);
+
+typedef struct sgk_segs_host {
+    uint32_t n_reads;
+    uint64_t *seg_offsets; /* n_reads+1, compact CSR */
+    int32_t *x, *y;
+} sgk_segs_host_t;
+int sgk_jnn_host(const sgk_host_batch_t *batch, int rna, sgk_segs_host_t *out);
+void sgk_segs_host_free(sgk_segs_host_t *s);
+
+int sgk_prefix_host(const sgk_host_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out /* host, n_reads */);
+
+/* ---- per-read shims with the reference's own signatures (batch of one) ------------- */
+/* event_t / event_table exactly as src/sigtk.h:55-70 */
+typedef struct {
+    uint64_t start;
+    float length;
+    float mean;
+    float stdv;
+} sgk_event_t;
+typedef struct {
+    size_t n;
+    size_t start;
+    size_t end;
+    sgk_event_t *event; /* malloc'd; caller frees, as with getevents() (src/cfunc.c:82) */
+} sgk_event_table;
+/* float *signal_in_picoamps(slow5_rec_t*) (src/misc.c:15): malloc'd, caller frees */
+float *sgk_signal_in_picoamps(const int16_t *raw, uint64_t len_raw_signal, double digitisation,
+                              double offset, double range);
+/* event_table getevents(size_t nsample, float *rawptr, int8_t rna) (src/events.c:553) */
+sgk_event_table sgk_getevents(size_t nsample, float *rawptr, int8_t rna);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGTK_GPU_H */

@@ -1,0 +1,263 @@
+"""ctypes binding of libsigtk_gpu.so (include/sigtk_gpu.h) and a numpy-level mirror of the
+reference's per-read operators (src/sigtk.h:124-134, src/jnn.h:104-109).
+
+There is NO CPU fallback here: if the HIP library is missing or no GPU is usable the calls
+raise ``SigtkGpuError``.  (The test oracle lives under oracle/ and is never imported from
+this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, NamedTuple, Optional, Sequence
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libsigtk_gpu.so")
+
+SGK_OK = 0
+SGK_ERR_CAPACITY = -5
+
+
+class SigtkGpuError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    """sgk_batch_t (device pointers)."""
+    _fields_ = [("samples", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p),
+                ("digitisation", C.c_void_p), ("offset", C.c_void_p), ("range", C.c_void_p),
+                ("n_reads", C.c_uint32), ("max_read_len", C.c_uint32), ("n_samples", C.c_uint64)]
+
+
+class HostBatch(C.Structure):
+    """sgk_host_batch_t (host pointers, CSR offsets)."""
+    _fields_ = [("samples", C.c_void_p), ("offsets", C.c_void_p), ("digitisation", C.c_void_p),
+                ("offset", C.c_void_p), ("range", C.c_void_p), ("n_reads", C.c_uint32)]
+
+
+class EventStatus(C.Structure):
+    _fields_ = [("n_fallback_reads", C.c_uint32), ("n_rerun_passes", C.c_uint32),
+                ("n_capacity_overflow", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_events_total", C.c_uint64)]
+
+
+class EventsHost(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("ev_offsets", C.POINTER(C.c_uint64)),
+                ("start", C.POINTER(C.c_uint32)), ("length", C.POINTER(C.c_uint32)),
+                ("mean", C.POINTER(C.c_float)), ("stdv", C.POINTER(C.c_float)), ("status", EventStatus)]
+
+
+class SegsHost(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("seg_offsets", C.POINTER(C.c_uint64)),
+                ("x", C.POINTER(C.c_int32)), ("y", C.POINTER(C.c_int32))]
+
+
+STAT_DTYPE = np.dtype([("raw_mean", "<f4"), ("pa_mean", "<f4"), ("raw_std", "<f4"), ("pa_std", "<f4"),
+                       ("raw_median", "<i4"), ("pa_median", "<f4"), ("n", "<u4"), ("reserved", "<u4")])
+PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i4"), ("polya_y", "<i4"),
+                         ("adapt_mean", "<f4"), ("adapt_std", "<f4"), ("adapt_median", "<f4"),
+                         ("polya_mean", "<f4"), ("polya_std", "<f4"), ("polya_median", "<f4"),
+                         ("n", "<u4"), ("reserved", "<u4")])
+
+#: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status",
+    "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_synth_reads", "sgk_synth_reads_host",
+    "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
+    "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
+    "sgk_segs_host_free", "sgk_prefix_host", "sgk_signal_in_picoamps", "sgk_getevents",
+]
+
+
+class Events(NamedTuple):
+    start: np.ndarray   # uint32
+    length: np.ndarray  # uint32
+    mean: np.ndarray    # float32
+    stdv: np.ndarray    # float32
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load libsigtk_gpu.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SigtkGpuError("%s not found: build it with `python -m sigtk_amd.build` "
+                            "(__graft_entry__.build())" % path)
+    L = C.CDLL(path)
+    L.sgk_strerror.restype = C.c_char_p
+    L.sgk_version.restype = C.c_char_p
+    L.sgk_last_hip_error.restype = C.c_char_p
+    for f in ("sgk_event_workspace_bytes", "sgk_stat_workspace_bytes", "sgk_jnn_workspace_bytes",
+              "sgk_prefix_workspace_bytes"):
+        fn = getattr(L, f)
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32]
+    L.sgk_event.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+    L.sgk_event_pa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int] + \
+                              [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+    L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
+    L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
+    L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sgk_stat_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sgk_jnn.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+    L.sgk_prefix.argtypes = [C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sgk_synth_reads.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                                     C.c_void_p]
+    L.sgk_synth_reads_host.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
+    L.sgk_synth_reads_host.restype = None
+    L.sgk_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]
+    L.sgk_event_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.POINTER(EventsHost)]
+    L.sgk_events_host_free.argtypes = [C.POINTER(EventsHost)]
+    L.sgk_events_host_free.restype = None
+    L.sgk_pa_host.argtypes = [C.POINTER(HostBatch), C.c_void_p]
+    L.sgk_stat_host.argtypes = [C.POINTER(HostBatch), C.c_void_p]
+    L.sgk_jnn_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.POINTER(SegsHost)]
+    L.sgk_segs_host_free.argtypes = [C.POINTER(SegsHost)]
+    L.sgk_segs_host_free.restype = None
+    L.sgk_prefix_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.c_int, C.c_void_p]
+    L.sgk_signal_in_picoamps.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double]
+    L.sgk_signal_in_picoamps.restype = C.POINTER(C.c_float)
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != SGK_OK:
+        L = load_library()
+        msg = L.sgk_strerror(rc).decode()
+        hip = L.sgk_last_hip_error().decode()
+        raise SigtkGpuError("%s failed: %s%s" % (what or "sgk call", msg, (" [" + hip + "]") if hip else ""))
+
+
+def device_count() -> int:
+    return int(load_library().sgk_device_count())
+
+
+# ---------------------------------------------------------------------- host batches (numpy)
+
+class _HB:
+    """Keeps the numpy arrays behind a sgk_host_batch_t alive."""
+
+    def __init__(self, reads: Sequence[np.ndarray], dig, off, rng):
+        self.n = len(reads)
+        lens = np.array([len(r) for r in reads], dtype=np.uint64)
+        self.offsets = np.zeros(self.n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=self.offsets[1:])
+        self.samples = (np.concatenate([np.asarray(r, dtype=np.int16) for r in reads])
+                        if self.n and int(self.offsets[-1]) else np.zeros(1, dtype=np.int16))
+        self.samples = np.ascontiguousarray(self.samples, dtype=np.int16)
+        self.dig = np.ascontiguousarray(np.broadcast_to(np.asarray(dig, dtype=np.float64), (self.n,)))
+        self.off = np.ascontiguousarray(np.broadcast_to(np.asarray(off, dtype=np.float64), (self.n,)))
+        self.rng = np.ascontiguousarray(np.broadcast_to(np.asarray(rng, dtype=np.float64), (self.n,)))
+        self.c = HostBatch(self.samples.ctypes.data, self.offsets.ctypes.data, self.dig.ctypes.data,
+                           self.off.ctypes.data, self.rng.ctypes.data, self.n)
+
+
+def _np_from(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+# ---------------------------------------------------------------------- operator mirror (numpy in/out)
+
+def pa(reads: Sequence[np.ndarray], dig, off, rng) -> List[np.ndarray]:
+    """signal_in_picoamps (src/misc.c:15) for a batch of reads."""
+    L = load_library()
+    hb = _HB(reads, dig, off, rng)
+    out = np.empty(max(int(hb.offsets[-1]), 1), dtype=np.float32)
+    check(L.sgk_pa_host(C.byref(hb.c), out.ctypes.data), "sgk_pa_host")
+    return [out[int(hb.offsets[r]):int(hb.offsets[r + 1])].copy() for r in range(hb.n)]
+
+
+def event(reads: Sequence[np.ndarray], dig, off, rng, rna: int):
+    """event_func's compute part (src/cfunc.c:72-78) for a batch.  -> (list of Events, EventStatus)"""
+    L = load_library()
+    hb = _HB(reads, dig, off, rng)
+    ev = EventsHost()
+    check(L.sgk_event_host(C.byref(hb.c), int(rna), C.byref(ev)), "sgk_event_host")
+    try:
+        offs = _np_from(ev.ev_offsets, hb.n + 1, np.uint64)
+        tot = int(offs[-1]) if hb.n else 0
+        st = _np_from(ev.start, tot, np.uint32)
+        ln = _np_from(ev.length, tot, np.uint32)
+        mn = _np_from(ev.mean, tot, np.float32)
+        sd = _np_from(ev.stdv, tot, np.float32)
+        status = EventStatus.from_buffer_copy(bytes(ev.status))
+    finally:
+        L.sgk_events_host_free(C.byref(ev))
+    out = []
+    for r in range(hb.n):
+        a, b = int(offs[r]), int(offs[r + 1])
+        out.append(Events(st[a:b], ln[a:b], mn[a:b], sd[a:b]))
+    return out, status
+
+
+def stat(reads: Sequence[np.ndarray], dig, off, rng) -> np.ndarray:
+    """stat_func's compute part (src/cfunc.c:132-139) -> structured array (STAT_DTYPE)."""
+    L = load_library()
+    hb = _HB(reads, dig, off, rng)
+    out = np.zeros(max(hb.n, 1), dtype=STAT_DTYPE)
+    check(L.sgk_stat_host(C.byref(hb.c), out.ctypes.data), "sgk_stat_host")
+    return out[:hb.n]
+
+
+def jnn(reads: Sequence[np.ndarray], dig, off, rng, rna: int):
+    """jnn_raw with jnn_print's preset (src/jnn.c:282,313-319) -> list of (x, y) int32 arrays."""
+    L = load_library()
+    hb = _HB(reads, dig, off, rng)
+    sg = SegsHost()
+    check(L.sgk_jnn_host(C.byref(hb.c), int(rna), C.byref(sg)), "sgk_jnn_host")
+    try:
+        offs = _np_from(sg.seg_offsets, hb.n + 1, np.uint64)
+        tot = int(offs[-1]) if hb.n else 0
+        x = _np_from(sg.x, tot, np.int32)
+        y = _np_from(sg.y, tot, np.int32)
+    finally:
+        L.sgk_segs_host_free(C.byref(sg))
+    return [(x[int(offs[r]):int(offs[r + 1])], y[int(offs[r]):int(offs[r + 1])]) for r in range(hb.n)]
+
+
+def prefix(reads: Sequence[np.ndarray], dig, off, rng, rna: int, pore: int) -> np.ndarray:
+    """prefix_func's compute part (src/cfunc.c:169-216) -> structured array (PREFIX_DTYPE)."""
+    L = load_library()
+    hb = _HB(reads, dig, off, rng)
+    out = np.zeros(max(hb.n, 1), dtype=PREFIX_DTYPE)
+    check(L.sgk_prefix_host(C.byref(hb.c), int(rna), int(pore), out.ctypes.data), "sgk_prefix_host")
+    return out[:hb.n]
+
+
+def synth_reads_host(n_reads: int, read_len, seed: int, kind: int, first_read: int = 0):
+    """Deterministic synthetic reads (host generator; identical to the device kernel).
+    -> (list of int16 arrays, dig, off, rng)"""
+    L = load_library()
+    lens = np.ascontiguousarray(np.broadcast_to(np.asarray(read_len, dtype=np.uint32), (n_reads,)))
+    offs = np.zeros(n_reads, dtype=np.uint64)
+    if n_reads > 1:
+        np.cumsum(lens[:-1].astype(np.uint64), out=offs[1:])
+    total = int(lens.astype(np.uint64).sum())
+    samples = np.zeros(max(total, 1), dtype=np.int16)
+    dig = np.zeros(max(n_reads, 1)); off = np.zeros(max(n_reads, 1)); rng = np.zeros(max(n_reads, 1))
+    L.sgk_synth_reads_host(samples.ctypes.data, offs.ctypes.data, lens.ctypes.data, dig.ctypes.data,
+                           off.ctypes.data, rng.ctypes.data, n_reads, first_read, seed, kind)
+    reads = [samples[int(offs[r]):int(offs[r]) + int(lens[r])].copy() for r in range(n_reads)]
+    return reads, dig[:n_reads], off[:n_reads], rng[:n_reads]
+
+
+def profile_read():
+    """-> {kernel name: (total ms, calls)} accumulated since the last profile_reset()."""
+    L = load_library()
+    cap = 32
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    calls = (C.c_uint32 * cap)()
+    k = L.sgk_profile_read(names, ms, calls, cap)
+    return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}

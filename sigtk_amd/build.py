@@ -1,0 +1,76 @@
+"""Build libsigtk_gpu.so (HIP kernels + C ABI) and the sigtk-amd host CLI, in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU present.  Numerics-critical flags:
+  -ffp-contract=off   the reference is plain C99 on SSE2 (one rounding per operator); HIP's
+                      default 'fast' contraction would fuse mul+add into FMA and change bits
+  (f32 divide/sqrt stay correctly rounded: -fhip-fp32-correctly-rounded-divide-sqrt is the
+   hipcc default and is passed explicitly)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "libsigtk_gpu.so")
+CLI = os.path.join(PKG, "sigtk-amd")
+
+HIP_SOURCES = ["api.hip", "api_stat.hip", "event_kernels.hip", "stat_kernels.hip", "misc_kernels.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function"]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "sigtk_gpu.h"))
+    if not force and _newer(LIB, deps):
+        return LIB
+    cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB, *srcs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    if not os.path.isdir(HOST):
+        return ""
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".c"))
+    if not srcs:
+        return ""
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "sigtk_gpu.h"))
+    if not force and _newer(CLI, deps) and _newer(CLI, [LIB]):
+        return CLI
+    cmd = ["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI, *srcs,
+           "-L", PKG, "-lsigtk_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lm"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)
+    build_cli(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,425 @@
+// api.hip -- C ABI of libsigtk_gpu.so (include/sigtk_gpu.h): error plumbing, per-kernel timing,
+// workspace carving, the pa / event / synth entry points and their host-pointer layer.
+// (stat / jnn / prefix entry points live in api_stat.hip.)
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "event_args.h"
+#include "host_util.h"
+#include "sgk_common.h"
+#include "synth.h"
+
+namespace sgk {
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_hip_err[512] = "";
+
+void set_hip_error(hipError_t e, const char *what, const char *file, int line) {
+    snprintf(g_hip_err, sizeof g_hip_err, "%s: %s (%s:%d)", hipGetErrorName(e), what, file, line);
+}
+
+// ---------------------------------------------------------------- profiling
+struct ProfRec {
+    const char *name;
+    hipEvent_t t0, t1;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), slot(-1) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.name = n;
+    if (hipEventCreate(&r.t0) != hipSuccess) return;
+    if (hipEventCreate(&r.t1) != hipSuccess) {
+        (void)hipEventDestroy(r.t0);
+        return;
+    }
+    (void)hipEventRecord(r.t0, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].t1, stream);
+}
+
+// ---------------------------------------------------------------- workspace layout (event)
+EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, size_t available) {
+    EvWorkspace w;
+    const uint64_t nr = n_reads ? n_reads : 1;
+    size_t o = 0;
+    w.off_hdr = o;     o += sizeof(EvHeader);
+    w.off_flags = o;   o += round_up(nr, 64);
+    w.off_list = o;    o += round_up(nr * 4, 64);
+    w.off_bitmap = o;  o += round_up((n_samples / 64 + nr + 2) * 8, 64);
+    w.off_scratch = o;
+    w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
+    const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
+    uint64_t nb = nr < 64 ? nr : 64;
+    if (available) {
+        const size_t room = available > o ? available - o : 0;
+        uint64_t fit = room / per_block;
+        if (fit > 256) fit = 256;
+        if (fit > nr) fit = nr;
+        nb = fit;
+    }
+    w.n_fb_blocks = (uint32_t)nb;
+    w.total = o + (size_t)nb * per_block;
+    return w;
+}
+
+int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
+int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
+                 double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed, int kind,
+                 hipStream_t st);
+
+int check_batch(const sgk_batch_t *b) {
+    if (!b) return SGK_ERR_ARG;
+    if (b->n_reads == 0) return SGK_OK;
+    if (!b->samples || !b->offsets || !b->lengths || !b->digitisation || !b->offset || !b->range) return SGK_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(b->samples) & 15u) return SGK_ERR_ALIGN;
+    if (b->n_samples & 7u) return SGK_ERR_ARG;
+    return SGK_OK;
+}
+
+static int run_event(const void *samples, bool float_input, const uint64_t *offsets, const uint32_t *lengths,
+                     const double *dig, const double *off, const double *rng, uint32_t n_reads,
+                     uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
+                     uint32_t *ev_start, uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events,
+                     void *ws, size_t ws_bytes, void *stream) {
+    if (n_reads == 0) return SGK_OK;
+    if (!samples || !offsets || !lengths || !ev_slots || !ev_start || !ev_length || !ev_mean || !ev_stdv ||
+        !n_events || !ws)
+        return SGK_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(samples) & 15u) return SGK_ERR_ALIGN;
+    if (reinterpret_cast<uintptr_t>(ws) & 63u) return SGK_ERR_ALIGN;
+    const EvWorkspace w = event_workspace_layout(n_reads, n_samples, max_read_len, ws_bytes);
+    if (w.n_fb_blocks == 0 || w.total > ws_bytes) return SGK_ERR_WORKSPACE;
+    char *base = static_cast<char *>(ws);
+    EvArgs a;
+    a.samples = samples;
+    a.offsets = offsets;
+    a.lengths = lengths;
+    a.dig = dig;
+    a.off = off;
+    a.rng = rng;
+    a.n_reads = n_reads;
+    a.n_alloc = n_samples;
+    a.ev_slots = ev_slots;
+    a.ev_start = ev_start;
+    a.ev_length = ev_length;
+    a.ev_mean = ev_mean;
+    a.ev_stdv = ev_stdv;
+    a.n_events = n_events;
+    a.hdr = reinterpret_cast<EvHeader *>(base + w.off_hdr);
+    a.flags = reinterpret_cast<uint8_t *>(base + w.off_flags);
+    a.flag_list = reinterpret_cast<uint32_t *>(base + w.off_list);
+    a.bitmap = reinterpret_cast<unsigned long long *>(base + w.off_bitmap);
+    a.scratch = reinterpret_cast<double *>(base + w.off_scratch);
+    a.scratch_stride = w.scratch_stride;
+    return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace sgk
+
+using namespace sgk;
+
+// ====================================================================== C ABI
+
+extern "C" {
+
+const char *sgk_strerror(int code) {
+    switch (code) {
+        case SGK_OK: return "ok";
+        case SGK_ERR_ARG: return "invalid argument";
+        case SGK_ERR_HIP: return "HIP runtime error";
+        case SGK_ERR_NODEVICE: return "no usable GPU";
+        case SGK_ERR_WORKSPACE: return "workspace too small";
+        case SGK_ERR_CAPACITY: return "output arena slot range too small";
+        case SGK_ERR_ALIGN: return "buffer not sufficiently aligned";
+        case SGK_ERR_NOMEM: return "host allocation failed";
+        default: return "unknown sgk error";
+    }
+}
+
+const char *sgk_version(void) { return SGK_VERSION_STRING; }
+const char *sgk_last_hip_error(void) { return g_hip_err; }
+
+int sgk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sgk_set_device(int ordinal) {
+    if (sgk_device_count() <= 0) return SGK_ERR_NODEVICE;
+    SGK_HIP_TRY(hipSetDevice(ordinal));
+    return SGK_OK;
+}
+
+void sgk_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+void sgk_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) {
+        (void)hipEventSynchronize(r.t1);
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
+    }
+    g_prof.clear();
+}
+
+int sgk_profile_read(const char **names, double *ms, uint32_t *calls, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int k = 0;
+    for (auto &r : g_prof) {
+        if (hipEventSynchronize(r.t1) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.t0, r.t1) != hipSuccess) continue;
+        int j = 0;
+        for (; j < k; ++j)
+            if (strcmp(names[j], r.name) == 0) break;
+        if (j == k) {
+            if (k >= cap) continue;
+            names[k] = r.name;
+            ms[k] = 0.0;
+            calls[k] = 0;
+            ++k;
+        }
+        ms[j] += (double)t;
+        calls[j] += 1;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------- pa
+int sgk_pa(const sgk_batch_t *batch, float *pa_out, void *stream) {
+    const int rc = check_batch(batch);
+    if (rc != SGK_OK) return rc;
+    if (batch->n_reads == 0) return SGK_OK;
+    if (!pa_out) return SGK_ERR_ARG;
+    return launch_pa(batch, pa_out, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------- event
+size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
+    return event_workspace_layout(n_reads, n_samples, max_read_len, 0).total;
+}
+
+int sgk_event(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, uint32_t *ev_start, uint32_t *ev_length,
+              float *ev_mean, float *ev_stdv, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
+    const int rc = check_batch(b);
+    if (rc != SGK_OK) return rc;
+    return run_event(b->samples, false, b->offsets, b->lengths, b->digitisation, b->offset, b->range, b->n_reads,
+                     b->max_read_len, b->n_samples, rna, ev_slots, ev_start, ev_length, ev_mean, ev_stdv, n_events,
+                     ws, ws_bytes, stream);
+}
+
+int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
+                 uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *ws, size_t ws_bytes,
+                 void *stream) {
+    return run_event(pa, true, offsets, lengths, nullptr, nullptr, nullptr, n_reads, max_read_len, n_samples, rna,
+                     ev_slots, ev_start, ev_length, ev_mean, ev_stdv, n_events, ws, ws_bytes, stream);
+}
+
+int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
+    if (!ws || !out) return SGK_ERR_ARG;
+    EvHeader h;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SGK_HIP_TRY(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, st));
+    SGK_HIP_TRY(hipStreamSynchronize(st));
+    out->n_fallback_reads = h.n_flagged;
+    out->n_rerun_passes = h.n_rerun;
+    out->n_capacity_overflow = h.n_overflow;
+    out->reserved = 0;
+    out->n_events_total = h.n_events_total;
+    return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
+}
+
+// ---------------------------------------------------------------- synthetic reads
+int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
+                    double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed,
+                    int kind, void *stream) {
+    if (n_reads == 0) return SGK_OK;
+    if (!samples || !offsets || !lengths || !dig || !off || !rng) return SGK_ERR_ARG;
+    return launch_synth(samples, offsets, lengths, dig, off, rng, n_reads, max_read_len, first_read, seed, kind,
+                        static_cast<hipStream_t>(stream));
+}
+
+void sgk_synth_reads_host(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig,
+                          double *off, double *rng, uint32_t n_reads, uint64_t first_read, uint64_t seed, int kind) {
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const int64_t n = (int64_t)lengths[r];
+        const sgk_synth_read_t R = sgk_synth_read_init(seed, first_read + r, n, kind);
+        dig[r] = SGK_SYNTH_DIGITISATION;
+        off[r] = (double)R.offset;
+        rng[r] = SGK_SYNTH_RANGE;
+        for (int64_t i = 0; i < n; ++i) samples[offsets[r] + i] = sgk_synth_sample(R, i);
+    }
+}
+
+// ====================================================================== Host API
+
+int sgk_pa_host(const sgk_host_batch_t *hb, float *pa_out) {
+    DeviceBatch db;
+    int rc = db.upload(hb);
+    if (rc != SGK_OK) return rc;
+    if (hb->n_reads == 0) return SGK_OK;
+    if (!pa_out) return SGK_ERR_ARG;
+    DevBuf d_out;
+    if ((rc = d_out.alloc((size_t)db.n_samples * sizeof(float))) != SGK_OK) return rc;
+    if ((rc = sgk_pa(&db.view, d_out.as<float>(), nullptr)) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipDeviceSynchronize());
+    for (uint32_t r = 0; r < hb->n_reads; ++r) {
+        if (!db.lengths[r]) continue;
+        SGK_HIP_TRY(hipMemcpy(pa_out + hb->offsets[r], d_out.as<float>() + db.offsets[r],
+                              (size_t)db.lengths[r] * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return SGK_OK;
+}
+
+// shared tail of sgk_event_host / sgk_getevents: run on an uploaded batch view (raw or pA input)
+static int event_collect(const void *d_samples, bool float_input, const DeviceBatch &db, const sgk_batch_t *view,
+                         int rna, sgk_events_host_t *out) {
+    const uint32_t nr = (uint32_t)db.lengths.size();
+    memset(out, 0, sizeof *out);
+    out->n_reads = nr;
+    out->ev_offsets = (uint64_t *)calloc((size_t)nr + 1, sizeof(uint64_t));
+    if (!out->ev_offsets) return SGK_ERR_NOMEM;
+    if (nr == 0) return SGK_OK;
+    const std::vector<uint64_t> slots = make_slots(db.lengths, [](uint32_t n) { return sgk_event_slots_for(n); });
+    const uint64_t nslots = slots[nr];
+    DevBuf d_slots, d_start, d_len, d_mean, d_sd, d_nev, d_ws;
+    int rc;
+    if ((rc = d_slots.alloc((nr + 1) * sizeof(uint64_t))) != SGK_OK) return rc;
+    if ((rc = d_start.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_len.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_mean.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_sd.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_nev.alloc((size_t)nr * 4)) != SGK_OK) return rc;
+    const size_t wsb = sgk_event_workspace_bytes(nr, db.n_samples, db.max_len);
+    if ((rc = d_ws.alloc(wsb)) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (float_input)
+        rc = sgk_event_pa(static_cast<const float *>(d_samples), view->offsets, view->lengths, nr, db.max_len,
+                          db.n_samples, rna, d_slots.as<uint64_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>(),
+                          d_mean.as<float>(), d_sd.as<float>(), d_nev.as<uint32_t>(), d_ws.p, wsb, nullptr);
+    else
+        rc = sgk_event(view, rna, d_slots.as<uint64_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>(),
+                       d_mean.as<float>(), d_sd.as<float>(), d_nev.as<uint32_t>(), d_ws.p, wsb, nullptr);
+    if (rc != SGK_OK) return rc;
+    rc = sgk_event_status(d_ws.p, &out->status, nullptr);
+    if (rc != SGK_OK) return rc;
+    std::vector<uint32_t> nev(nr);
+    SGK_HIP_TRY(hipMemcpy(nev.data(), d_nev.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < nr; ++r) {
+        out->ev_offsets[r] = tot;
+        tot += nev[r];
+    }
+    out->ev_offsets[nr] = tot;
+    out->start = (uint32_t *)malloc((tot ? tot : 1) * 4);
+    out->length = (uint32_t *)malloc((tot ? tot : 1) * 4);
+    out->mean = (float *)malloc((tot ? tot : 1) * 4);
+    out->stdv = (float *)malloc((tot ? tot : 1) * 4);
+    if (!out->start || !out->length || !out->mean || !out->stdv) return SGK_ERR_NOMEM;
+    for (uint32_t r = 0; r < nr; ++r) {
+        const size_t k = nev[r];
+        if (!k) continue;
+        const uint64_t o = out->ev_offsets[r], s = slots[r];
+        SGK_HIP_TRY(hipMemcpy(out->start + o, d_start.as<uint32_t>() + s, k * 4, hipMemcpyDeviceToHost));
+        SGK_HIP_TRY(hipMemcpy(out->length + o, d_len.as<uint32_t>() + s, k * 4, hipMemcpyDeviceToHost));
+        SGK_HIP_TRY(hipMemcpy(out->mean + o, d_mean.as<float>() + s, k * 4, hipMemcpyDeviceToHost));
+        SGK_HIP_TRY(hipMemcpy(out->stdv + o, d_sd.as<float>() + s, k * 4, hipMemcpyDeviceToHost));
+    }
+    return SGK_OK;
+}
+
+int sgk_event_host(const sgk_host_batch_t *hb, int rna, sgk_events_host_t *out) {
+    if (!out) return SGK_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    DeviceBatch db;
+    int rc = db.upload(hb);
+    if (rc != SGK_OK) return rc;
+    rc = event_collect(db.view.samples, false, db, &db.view, rna, out);
+    if (rc != SGK_OK) sgk_events_host_free(out);
+    return rc;
+}
+
+void sgk_events_host_free(sgk_events_host_t *ev) {
+    if (!ev) return;
+    free(ev->ev_offsets);
+    free(ev->start);
+    free(ev->length);
+    free(ev->mean);
+    free(ev->stdv);
+    memset(ev, 0, sizeof *ev);
+}
+
+// ---------------------------------------------------------------- per-read shims
+float *sgk_signal_in_picoamps(const int16_t *raw, uint64_t n, double digitisation, double offset, double range) {
+    float *out = (float *)malloc(sizeof(float) * (n ? n : 1));
+    if (!out) return nullptr;
+    const uint64_t offs[2] = {0, n};
+    sgk_host_batch_t hb = {raw, offs, &digitisation, &offset, &range, 1};
+    if (sgk_pa_host(&hb, out) != SGK_OK) {
+        free(out);
+        return nullptr;
+    }
+    return out;
+}
+
+sgk_event_table sgk_getevents(size_t nsample, float *rawptr, int8_t rna) {
+    sgk_event_table et;
+    memset(&et, 0, sizeof et);
+    if (!rawptr || nsample == 0 || nsample > 0x7fffffffull || sgk_device_count() <= 0) return et;
+    DeviceBatch db;  // only offsets/lengths bookkeeping is used here
+    db.offsets.assign(1, 0);
+    db.lengths.assign(1, (uint32_t)nsample);
+    db.max_len = (uint32_t)nsample;
+    db.n_samples = round_up(nsample, 64);
+    DevBuf d_pa, d_o, d_l;
+    if (d_pa.alloc((size_t)db.n_samples * sizeof(float)) != SGK_OK) return et;
+    if (d_o.alloc(8) != SGK_OK || d_l.alloc(4) != SGK_OK) return et;
+    if (hipMemset(d_pa.p, 0, (size_t)db.n_samples * sizeof(float)) != hipSuccess) return et;
+    if (hipMemcpy(d_pa.p, rawptr, nsample * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return et;
+    if (hipMemcpy(d_o.p, db.offsets.data(), 8, hipMemcpyHostToDevice) != hipSuccess) return et;
+    if (hipMemcpy(d_l.p, db.lengths.data(), 4, hipMemcpyHostToDevice) != hipSuccess) return et;
+    sgk_batch_t view;
+    memset(&view, 0, sizeof view);
+    view.offsets = d_o.as<uint64_t>();
+    view.lengths = d_l.as<uint32_t>();
+    sgk_events_host_t ev;
+    if (event_collect(d_pa.p, true, db, &view, rna, &ev) != SGK_OK) {
+        sgk_events_host_free(&ev);
+        return et;
+    }
+    const size_t k = (size_t)ev.ev_offsets[1];
+    et.event = (sgk_event_t *)calloc(k ? k : 1, sizeof(sgk_event_t));
+    if (et.event) {
+        et.n = k;
+        et.start = 0;
+        et.end = k;
+        for (size_t i = 0; i < k; ++i) {
+            et.event[i].start = ev.start[i];
+            et.event[i].length = (float)ev.length[i];
+            et.event[i].mean = ev.mean[i];
+            et.event[i].stdv = ev.stdv[i];
+        }
+    }
+    sgk_events_host_free(&ev);
+    return et;
+}
+
+}  // extern "C"

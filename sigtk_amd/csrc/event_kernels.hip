@@ -1,0 +1,747 @@
+// event_kernels.hip -- the `event` hot path (reference: src/events.c:293-573) for gfx950.
+//
+// One wavefront (64 lanes) per read.  Three kernels:
+//
+//   k_event_detect   window sums -> two t-statistics -> short/long peak detector.
+//                    Lane c owns chunk c of the read (K samples, K a multiple of 64);
+//                    samples are staged global -> LDS in 64-sample row tiles (128-byte row
+//                    segments, 16 bytes per lane), each lane slides its four window sums in
+//                    registers (double; exact), evaluates the reference's mixed float/double
+//                    t-statistic expression tree (events.c:338-361) and steps both detector
+//                    automata (events.c:383-440).  The automaton is serial in the reference;
+//                    here every chunk starts SPECULATIVELY from the fresh state LEAD samples
+//                    before its chunk, and the speculation is verified: chunk c is accepted
+//                    iff its state at its chunk start equals chunk c-1's state at that
+//                    position; mismatching chunks are re-run from the true state until a
+//                    fixed point (exact in the general case; re-runs are counted in the
+//                    status block).  Output: one bit per sample (peak positions) in a
+//                    workspace bitmap.
+//
+//   k_event_build    bitmap + samples -> event table (events.c:457-504).  Lane-local double
+//                    prefix sums, wave scan across lanes, boundary records compacted in LDS,
+//                    then one event per lane per round with coalesced SoA stores of
+//                    (start, length, mean, stdv).
+//
+//   k_event_fallback persistent kernel over the reads that fail the exactness guard: lane 0
+//                    reproduces compute_sum_sumsq's sequential double prefix scan
+//                    (events.c:293-303) into workspace scratch, then the same detector and
+//                    builder run with window/event sums taken as differences of those arrays,
+//                    exactly as the reference does.
+//
+// Exactness guard: the reference accumulates double prefix sums sequentially and uses their
+// differences; the fast path forms window sums and event sums directly.  Both give the
+// real-number sums (hence identical bits) whenever no prefix sum can round: every sample is a
+// multiple of 2^g (g = lowest bit of the smallest non-zero |x|) and all partial sums are below
+// 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29  for x and for the
+// float squares; reads failing the check take the fallback kernel.
+#include "sgk_common.h"
+#include "event_args.h"
+
+namespace sgk {
+
+constexpr int LEAD = 64;   // speculative warm-up (samples); multiple of 64
+constexpr int TILE = 64;   // samples per row tile
+constexpr int BACK = 32;   // row margin before the pass start (>= W2 + 1)
+
+__device__ inline uint32_t chunk_len(int64_t n) {
+    const int64_t k = (n + 4095) / 4096;
+    return (uint32_t)(k < 1 ? 64 : 64 * k);
+}
+
+// ---------------------------------------------------------------- LDS row streamer
+// 64 rows (one per lane), each row a window of 2 tiles x 64 samples of T; the row stride is
+// padded by one dword so that lane-per-row reads are bank-conflict free.
+template <typename T>
+struct RowStream {
+    static constexpr int ROW_BYTES = 2 * TILE * (int)sizeof(T) + 4;
+    static constexpr int LDS_BYTES = 64 * ROW_BYTES;
+    static constexpr int PER_VEC = 16 / (int)sizeof(T);  // samples per 16-byte vector
+    static constexpr int VECS = TILE / PER_VEC;          // vectors per row tile
+    static constexpr int ROWS_PER_IT = 64 / VECS;
+
+    char *lds;       // this wave's region
+    const T *base;   // read base (global)
+    int64_t lo, hi;  // loads are legal for read-relative sample index in [lo, hi)
+    int64_t rb;      // this lane's row: read-relative index of row sample 0
+    bool vec_ok;     // read base 16-byte aligned
+
+    // cooperative: every lane of the wave calls it.  rowmask = rows that need data.
+    __device__ void load_tile(int tile, unsigned long long rowmask) {
+        const int l = lane_id();
+        const int v = l % VECS;
+        __syncthreads();  // readers of the slot being replaced are done
+        for (int it = 0; it < VECS; ++it) {
+            const int row = it * ROWS_PER_IT + l / VECS;
+            const int64_t rbr = (int64_t)__shfl((long long)rb, row, 64);
+            if ((rowmask >> row) & 1ull) {
+                const int64_t p0 = rbr + (int64_t)tile * TILE + (int64_t)v * PER_VEC;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (vec_ok && p0 >= lo && p0 + PER_VEC <= hi) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(base + p0);
+                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+                } else {
+                    T tmp[PER_VEC];
+#pragma unroll
+                    for (int k = 0; k < PER_VEC; ++k) {
+                        const int64_t p = p0 + k;
+                        tmp[k] = (p >= lo && p < hi) ? base[p] : (T)0;
+                    }
+                    __builtin_memcpy(w, tmp, 16);
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(
+                    lds + row * ROW_BYTES + (tile & 1) * TILE * (int)sizeof(T) + v * 16);
+                dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+            }
+        }
+        __syncthreads();
+    }
+    // sample at row index q of this lane's row (q must lie in one of the two resident tiles)
+    __device__ T get(int q) const {
+        const int off = lane_id() * ROW_BYTES + (((q >> 6) & 1) * TILE + (q & 63)) * (int)sizeof(T);
+        return *reinterpret_cast<const T *>(lds + off);
+    }
+};
+
+// ---------------------------------------------------------------- t-statistic
+// src/events.c:338-361, one rounding per C operator (FLT_EVAL_METHOD 0, no contraction).
+template <int W>
+__device__ inline float tstat_from_sums(double A, double A2, double B, double B2) {
+    const float wf = (float)W;
+    const float sum2 = (float)B;
+    const float sumsq2 = (float)B2;
+    const float mean1 = (float)(A / (double)wf);
+    const float mean2 = sum2 / wf;
+    const float m1sq = mean1 * mean1;
+    const float m2sq = mean2 * mean2;
+    const float q2 = sumsq2 / wf;
+    double acc = A2 / (double)wf;
+    acc = acc - (double)m1sq;
+    acc = acc + (double)q2;
+    acc = acc - (double)m2sq;
+    float cv = (float)acc;
+    cv = fmaxf(cv, FLT_MIN);
+    const float delta = mean2 - mean1;
+    const float cvw = cv / wf;
+    return (float)(fabs((double)delta) / sqrt((double)cvw));
+}
+
+// ---------------------------------------------------------------- detector state
+struct DetState {
+    int sp;      // short peak_pos (-1 none)
+    float sv;    // short peak_value
+    int svalid;
+    int lp;      // long peak_pos
+    float lv;
+    int lvalid;
+    int lmask;   // long masked_to, normalised to -1 when it no longer masks
+};
+__device__ inline DetState det_fresh(int masked_to) {
+    DetState d;
+    d.sp = -1; d.sv = FLT_MAX; d.svalid = 0;
+    d.lp = -1; d.lv = FLT_MAX; d.lvalid = 0;
+    d.lmask = masked_to;
+    return d;
+}
+__device__ inline DetState det_norm(DetState d, int i) {
+    if (d.lmask < i) d.lmask = -1;
+    return d;
+}
+__device__ inline bool det_equal(const DetState &a, const DetState &b) {
+    return a.sp == b.sp && __float_as_int(a.sv) == __float_as_int(b.sv) && a.svalid == b.svalid &&
+           a.lp == b.lp && __float_as_int(a.lv) == __float_as_int(b.lv) && a.lvalid == b.lvalid &&
+           a.lmask == b.lmask;
+}
+__device__ inline DetState det_shfl_up(const DetState &a) {
+    DetState r;
+    r.sp = __shfl_up(a.sp, 1, 64);
+    r.sv = __shfl_up(a.sv, 1, 64);
+    r.svalid = __shfl_up(a.svalid, 1, 64);
+    r.lp = __shfl_up(a.lp, 1, 64);
+    r.lv = __shfl_up(a.lv, 1, 64);
+    r.lvalid = __shfl_up(a.lvalid, 1, 64);
+    r.lmask = __shfl_up(a.lmask, 1, 64);
+    return r;
+}
+
+template <int W1>
+struct DetParam;
+template <>
+struct DetParam<3> {  // event_detection_defaults, src/events.c:43-47
+    static constexpr float thr1 = 1.4f, thr2 = 9.0f, ph = 0.2f;
+};
+template <>
+struct DetParam<7> {  // event_detection_rna, src/events.c:50-54
+    static constexpr float thr1 = 2.5f, thr2 = 9.0f, ph = 1.0f;
+};
+
+// One index of short_long_peak_detector (src/events.c:383-440): short first, then long.
+// emit_s / emit_l receive the emitted peak position of each detector, or -1.
+template <int W1>
+__device__ inline void det_step(DetState &d, int i, float v1, float v2, int &emit_s, int &emit_l) {
+    constexpr int W2 = 2 * W1;
+    constexpr float ph = DetParam<W1>::ph;
+    emit_s = -1;
+    emit_l = -1;
+    // ---- short detector: its masked_to stays 0, so only index 0 is skipped (events.c:387)
+    if (i > 0) {
+        if (d.sp < 0) {
+            if (v1 < d.sv) {
+                d.sv = v1;
+            } else if (v1 - d.sv > ph) {
+                d.sv = v1;
+                d.sp = i;
+            }
+        } else {
+            if (v1 > d.sv) {
+                d.sv = v1;
+                d.sp = i;
+            }
+            if (d.sv > DetParam<W1>::thr1) {  // dominate the long detector (events.c:414-422)
+                d.lmask = d.sp + W1;
+                d.lp = -1;
+                d.lv = FLT_MAX;
+                d.lvalid = 0;
+            }
+            if (d.sv - v1 > ph && d.sv > DetParam<W1>::thr1) d.svalid = 1;
+            if (d.svalid && (i - d.sp) > W1 / 2) {
+                emit_s = d.sp;
+                d.sp = -1;
+                d.sv = v1;
+                d.svalid = 0;
+            }
+        }
+    }
+    // ---- long detector
+    if (!(d.lmask >= i)) {
+        if (d.lp < 0) {
+            if (v2 < d.lv) {
+                d.lv = v2;
+            } else if (v2 - d.lv > ph) {
+                d.lv = v2;
+                d.lp = i;
+            }
+        } else {
+            if (v2 > d.lv) {
+                d.lv = v2;
+                d.lp = i;
+            }
+            if (d.lv - v2 > ph && d.lv > DetParam<W1>::thr2) d.lvalid = 1;
+            if (d.lvalid && (i - d.lp) > W2 / 2) {
+                emit_l = d.lp;
+                d.lp = -1;
+                d.lv = v2;
+                d.lvalid = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-read context
+template <typename T>
+struct ReadCtx {
+    const T *base;            // read's first sample
+    int64_t n;                // samples in the read
+    int64_t lo, hi;           // legal read-relative load range
+    Scale sc;
+    bool vec_ok;
+    unsigned long long *bm;   // bitmap words of this read
+    const double *P, *P2;     // fallback prefix arrays (n+1 entries) or null
+};
+
+template <typename T>
+__device__ inline ReadCtx<T> make_ctx(const EvArgs &a, uint32_t r) {
+    ReadCtx<T> rc;
+    const uint64_t o0 = a.offsets[r];
+    rc.base = reinterpret_cast<const T *>(a.samples) + o0;
+    rc.n = (int64_t)a.lengths[r];
+    rc.lo = -(int64_t)o0;
+    rc.hi = (int64_t)(a.n_alloc - o0);
+    if (a.dig) rc.sc = make_scale(a.dig[r], a.off[r], a.rng[r]);
+    else { rc.sc.offf = 0.0f; rc.sc.unit = 1.0f; }
+    rc.vec_ok = ((reinterpret_cast<uintptr_t>(rc.base) & 15u) == 0);
+    rc.bm = a.bitmap + (o0 >> 6) + r;
+    rc.P = nullptr;
+    rc.P2 = nullptr;
+    return rc;
+}
+
+// One pass of the detector over the wave's chunks.
+//   lead   : samples each lane starts before its chunk start (LEAD: speculative pass, 0: re-run)
+//   active : whether this lane runs in this pass
+//   st     : state at the pass start (lead == 0 only; the speculative pass starts fresh)
+//   at_s   : out, normalised state when the lane reaches its chunk start s (speculative pass)
+//   at_e   : out, normalised state when the lane reaches its chunk end e (written only when reached)
+//   mn/mx  : min non-zero |x| / max |x| over the lane's own chunk (guard), speculative pass only
+template <int W1, typename T, bool PREFIX>
+__device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char *lds, int lead, bool active,
+                                                      int64_t s, int64_t e, uint32_t K, DetState st,
+                                                      DetState &at_s, DetState &at_e, float &mn, float &mx) {
+    constexpr int W2 = 2 * W1;
+    const int64_t n = rc.n;
+    const int64_t i_begin = s - lead;
+    RowStream<T> rs;
+    rs.lds = lds;
+    rs.base = rc.base;
+    rs.lo = rc.lo;
+    rs.hi = rc.hi;
+    rs.rb = i_begin - BACK;
+    rs.vec_ok = rc.vec_ok;
+    const unsigned long long rowmask = __ballot(active);
+    if (rowmask == 0ull) return;
+
+    double A1 = 0, A1q = 0, B1 = 0, B1q = 0, A2 = 0, A2q = 0, B2 = 0, B2q = 0;
+    if (!PREFIX) {
+        rs.load_tile(0, rowmask);
+        rs.load_tile(1, rowmask);
+        if (active) {
+            // direct summation of the four windows around i_begin (row index BACK)
+#pragma unroll
+            for (int k = 1; k <= W2; ++k) {
+                const float x = to_pa(rs.get(BACK - k), rc.sc);
+                const float xq = x * x;
+                A2 = A2 + (double)x; A2q = A2q + (double)xq;
+                if (k <= W1) { A1 = A1 + (double)x; A1q = A1q + (double)xq; }
+            }
+#pragma unroll
+            for (int k = 0; k < W2; ++k) {
+                const float x = to_pa(rs.get(BACK + k), rc.sc);
+                const float xq = x * x;
+                B2 = B2 + (double)x; B2q = B2q + (double)xq;
+                if (k < W1) { B1 = B1 + (double)x; B1q = B1q + (double)xq; }
+            }
+        }
+    }
+
+    DetState d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : st;
+    // bitmap register window: wcur = word of the current index, wprev = the word before it
+    unsigned long long wcur = 0ull, wprev = 0ull;
+    const int64_t wlo = s >> 6, whi = (e + 63) >> 6;
+    bool done = !active;
+    const int main_steps = lead + (int)K;
+    const bool t1_ok = n >= 2 * W1, t2_ok = n >= 2 * W2;
+
+    int j = 0;
+    for (;; ++j) {
+        if (j >= main_steps && !__any(!done)) break;
+        const int64_t i = i_begin + j;
+        const int q = j + BACK;
+        if (!PREFIX) {
+            if (((q + W2) & 63) == 0 && j > 0) rs.load_tile((q + W2) >> 6, rowmask);
+        }
+        if ((j & 63) == 0 && j > 0 && active) {
+            // entering bitmap word (i>>6): retire the word two back
+            const int64_t wr = (i >> 6) - 2;
+            if (wr >= wlo && wr < whi) rc.bm[wr] = wprev;
+            wprev = wcur;
+            wcur = 0ull;
+        }
+        if (active && i >= 0) {
+            if (i == s && lead > 0) at_s = det_norm(d, (int)i);
+            if (i == e) at_e = det_norm(d, (int)i);
+            if (i >= n) done = true;
+            if (i >= e) {
+                const bool pend = (d.sp >= 0 && d.sp < e) || (d.lp >= 0 && d.lp < e);
+                if (!pend) done = true;
+            }
+            if (!done) {
+                float v1 = 0.0f, v2 = 0.0f;
+                if (PREFIX) {
+                    if (t1_ok && i >= W1 && i <= n - W1) {
+                        const double p0 = rc.P[i], q0 = rc.P2[i];
+                        v1 = tstat_from_sums<W1>(p0 - rc.P[i - W1], q0 - rc.P2[i - W1], rc.P[i + W1] - p0,
+                                                 rc.P2[i + W1] - q0);
+                    }
+                    if (t2_ok && i >= W2 && i <= n - W2) {
+                        const double p0 = rc.P[i], q0 = rc.P2[i];
+                        v2 = tstat_from_sums<W2>(p0 - rc.P[i - W2], q0 - rc.P2[i - W2], rc.P[i + W2] - p0,
+                                                 rc.P2[i + W2] - q0);
+                    }
+                } else {
+                    if (t1_ok && i >= W1 && i <= n - W1) v1 = tstat_from_sums<W1>(A1, A1q, B1, B1q);
+                    if (t2_ok && i >= W2 && i <= n - W2) v2 = tstat_from_sums<W2>(A2, A2q, B2, B2q);
+                }
+                int es, el;
+                det_step<W1>(d, (int)i, v1, v2, es, el);
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int p = z ? el : es;
+                    if (p >= s && p < e) {
+                        const int64_t wi = (int64_t)p >> 6, wb = i >> 6;
+                        const unsigned long long bit = 1ull << (p & 63);
+                        if (wi == wb) wcur |= bit;
+                        else if (wi == wb - 1) wprev |= bit;
+                        else rc.bm[wi] |= bit;  // older word: already retired, owned by this lane only
+                    }
+                }
+            }
+        }
+        if (!PREFIX) {
+            if (active) {
+                // slide the four windows from index i to i+1 (exact in double)
+                const float xm2 = to_pa(rs.get(q - W2), rc.sc);
+                const float xm1 = to_pa(rs.get(q - W1), rc.sc);
+                const float x0 = to_pa(rs.get(q), rc.sc);
+                const float xp1 = to_pa(rs.get(q + W1), rc.sc);
+                const float xp2 = to_pa(rs.get(q + W2), rc.sc);
+                const double d0 = (double)x0, d0q = (double)(x0 * x0);
+                A1 = (A1 + d0) - (double)xm1;  A1q = (A1q + d0q) - (double)(xm1 * xm1);
+                A2 = (A2 + d0) - (double)xm2;  A2q = (A2q + d0q) - (double)(xm2 * xm2);
+                B1 = (B1 + (double)xp1) - d0;  B1q = (B1q + (double)(xp1 * xp1)) - d0q;
+                B2 = (B2 + (double)xp2) - d0;  B2q = (B2q + (double)(xp2 * xp2)) - d0q;
+                if (lead > 0 && i >= s && i < e) {
+                    const float ax = fabsf(x0);
+                    mx = fmaxf(mx, ax);
+                    if (ax != 0.0f) mn = fminf(mn, ax);
+                }
+            }
+        }
+    }
+    if (active) {
+        // the last processed index is i_begin + j - 1; the register window holds its word and
+        // the one before it
+        const int64_t wb = (i_begin + (int64_t)j - 1) >> 6;
+        if (wb - 1 >= wlo && wb - 1 < whi) rc.bm[wb - 1] = wprev;
+        if (wb >= wlo && wb < whi) rc.bm[wb] = wcur;
+    }
+}
+
+__device__ inline bool guard_ok(float mn, float mx, int64_t n) {
+    if (!(mx > 0.0f)) return true;  // all samples zero
+    const int eb = ilogb((double)n * (double)mx), em = ilogb((double)mn);
+    if (eb - em > 29) return false;
+    const float mnq = mn * mn, mxq = mx * mx;
+    if (mnq < FLT_MIN) return false;
+    const int ebq = ilogb((double)n * (double)mxq), emq = ilogb((double)mnq);
+    return ebq - emq <= 29;
+}
+
+// Detector over one read by one wave.  Returns true when the exactness guard fails
+// (fast path only).
+template <int W1, typename T, bool PREFIX>
+__device__ bool detect_read(const ReadCtx<T> &rc, char *lds, EvHeader *hdr) {
+    const int64_t n = rc.n;
+    if (n <= 0) return false;
+    const uint32_t K = chunk_len(n);
+    const int c = lane_id();
+    const int64_t s = (int64_t)c * K;
+    const int64_t e = (s + K < n) ? s + K : n;
+    const bool active = s < n;
+    const DetState fresh = det_fresh(0);
+    DetState at_s = fresh, at_e = fresh;
+    float mn = FLT_MAX, mx = 0.0f;
+    detect_pass<W1, T, PREFIX>(rc, lds, LEAD, active, s, e, K, fresh, at_s, at_e, mn, mx);
+    DetState init = at_s;
+    for (int iter = 0; iter < 64; ++iter) {
+        const DetState pe = det_shfl_up(at_e);
+        const bool bad = active && c > 0 && !det_equal(pe, init);
+        const unsigned long long badmask = __ballot(bad);
+        if (badmask == 0ull) break;
+        if (bad) init = pe;
+        float mn2 = FLT_MAX, mx2 = 0.0f;
+        DetState unused = fresh;
+        detect_pass<W1, T, PREFIX>(rc, lds, 0, bad, s, e, K, pe, unused, at_e, mn2, mx2);
+        if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
+    }
+    if (PREFIX) return false;
+    mn = wave_min_f(mn);
+    mx = wave_max_f(mx);
+    return !guard_ok(mn, mx, n);
+}
+
+// ---------------------------------------------------------------- event builder
+
+// src/events.c:457-473 (create_event)
+__device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap, uint64_t k, uint32_t ps,
+                                   uint32_t pe, double dsum, double dsumsq, bool &overflow) {
+    if (k >= cap) { overflow = true; return; }
+    const float len = (float)(pe - ps);
+    const float m = (float)dsum / len;
+    const float dsq = (float)dsumsq;
+    const float var = dsq / len - m * m;
+    const float sd = sqrtf(fmaxf(var, 0.0f));
+    a.ev_start[slot0 + k] = ps;
+    a.ev_length[slot0 + k] = pe - ps;
+    a.ev_mean[slot0 + k] = m;
+    a.ev_stdv[slot0 + k] = sd;
+}
+
+constexpr int BT = 32;            // samples per lane per builder tile
+constexpr int BREC = 64 * 11;     // max boundaries per tile (peaks are >= 3 apart)
+struct BuildLds {
+    double S[BREC];
+    double S2[BREC];
+    double pt[64];
+    double pt2[64];
+    uint32_t p[BREC];
+};
+
+template <typename T>
+__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L) {
+    const int64_t n = rc.n;
+    const int l = lane_id();
+    const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
+    if (n <= 0) {
+        if (l == 0) a.n_events[r] = 0;
+        return;
+    }
+    const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
+    bool overflow = false;
+    uint32_t rank = 0, prevp = 0;
+    double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary
+    double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
+    constexpr int NV = BT * (int)sizeof(T) / 16;
+    for (int64_t tb = 0; tb < n; tb += 64 * BT) {
+        const int64_t pos0 = tb + (int64_t)l * BT;
+        uint32_t bits = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
+        const int64_t rem = n - pos0;
+        const int nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
+        if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
+        T buf[BT];
+        if (rc.vec_ok && pos0 + BT <= rc.hi && pos0 < n) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(rc.base + pos0);
+            uint4 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = src[k];
+            __builtin_memcpy(buf, v, sizeof(buf));
+        } else {
+#pragma unroll
+            for (int k = 0; k < BT; ++k) buf[k] = (k < nvalid) ? rc.base[pos0 + k] : (T)0;
+        }
+        const int cnt = __popc(bits);
+        const int incl = wave_incl_scan_i(cnt);
+        const int excl = incl - cnt;
+        const int total = __shfl(incl, 63, 64);
+        // walk: lane-relative prefix sums, boundary records
+        double S = 0.0, S2 = 0.0;
+        int idx = excl;
+#pragma unroll
+        for (int k = 0; k < BT; ++k) {
+            float x = to_pa(buf[k], rc.sc);
+            if (k >= nvalid) x = 0.0f;
+            const float xq = x * x;
+            if ((bits >> k) & 1u) {
+                if (idx < BREC) {
+                    L->p[idx] = (uint32_t)(pos0 + k);
+                    L->S[idx] = S;
+                    L->S2[idx] = S2;
+                }
+                ++idx;
+            }
+            S = S + (double)x;
+            S2 = S2 + (double)xq;
+        }
+        const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
+        L->pt[l] = inS - S;
+        L->pt2[l] = inS2 - S2;
+        const double tileS = shfl_d(inS, 63), tileS2 = shfl_d(inS2, 63);
+        __syncthreads();
+        const int tot = total < BREC ? total : BREC;
+        if (total > BREC) overflow = true;
+        for (int k = l; k < tot; k += 64) {
+            const uint32_t p = L->p[k];
+            const int ln = (int)((p - (uint32_t)tb) / BT);
+            const double G = G0 + (L->pt[ln] + L->S[k]);
+            const double G2 = G20 + (L->pt2[ln] + L->S2[k]);
+            uint32_t pp;
+            double Gp, G2p;
+            if (k == 0) {
+                pp = prevp; Gp = Gprev; G2p = G2prev;
+            } else {
+                pp = L->p[k - 1];
+                const int lp = (int)((pp - (uint32_t)tb) / BT);
+                Gp = G0 + (L->pt[lp] + L->S[k - 1]);
+                G2p = G20 + (L->pt2[lp] + L->S2[k - 1]);
+            }
+            store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)k, pp, p, G - Gp, G2 - G2p, overflow);
+        }
+        if (tot > 0) {
+            const uint32_t p = L->p[tot - 1];
+            const int ln = (int)((p - (uint32_t)tb) / BT);
+            prevp = p;
+            Gprev = G0 + (L->pt[ln] + L->S[tot - 1]);
+            G2prev = G20 + (L->pt2[ln] + L->S2[tot - 1]);
+            rank += (uint32_t)tot;
+        }
+        G0 = G0 + tileS;
+        G20 = G20 + tileS2;
+        __syncthreads();
+    }
+    if (l == 0) {
+        store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, G0 - Gprev, G20 - G2prev, overflow);
+        a.n_events[r] = rank + 1;
+        atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
+    }
+    if (__any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
+}
+
+// fallback builder: event sums are differences of the sequential prefix arrays, as in the reference
+template <typename T>
+__device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r) {
+    const int64_t n = rc.n;
+    const int l = lane_id();
+    const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
+    if (n <= 0) {
+        if (l == 0) a.n_events[r] = 0;
+        return;
+    }
+    const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
+    bool overflow = false;
+    uint32_t rank = 0, prevp = 0;
+    const int64_t nwords = (n + 31) >> 5;
+    for (int64_t w0 = 0; w0 < nwords; w0 += 64) {
+        const int64_t w = w0 + l;
+        const int64_t pos0 = w * 32;
+        uint32_t bits = (w < nwords) ? bm32[w] : 0u;
+        if (w < nwords && n - pos0 < 32) bits &= (1u << (int)(n - pos0)) - 1u;
+        const int cnt = __popc(bits);
+        const int incl = wave_incl_scan_i(cnt);
+        const int excl = incl - cnt;
+        const int total = __shfl(incl, 63, 64);
+        const unsigned long long m = __ballot(cnt > 0);
+        const uint32_t lastp = cnt > 0 ? (uint32_t)(pos0 + 31 - __clz((int)bits)) : 0u;
+        const unsigned long long lower = m & ((1ull << l) - 1ull);
+        const int src = lower ? 63 - __clzll((long long)lower) : 0;
+        uint32_t pl = __shfl(lastp, src, 64);
+        if (!lower) pl = prevp;
+        int k = 0;
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const uint32_t p = (uint32_t)(pos0 + b);
+            store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)(excl + k), pl, p, rc.P[p] - rc.P[pl],
+                        rc.P2[p] - rc.P2[pl], overflow);
+            pl = p;
+            ++k;
+        }
+        if (m) {
+            prevp = __shfl(lastp, 63 - __clzll((long long)m), 64);
+            rank += (uint32_t)total;
+        }
+    }
+    if (l == 0) {
+        store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, rc.P[n] - rc.P[prevp],
+                    rc.P2[n] - rc.P2[prevp], overflow);
+        a.n_events[r] = rank + 1;
+        atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
+    }
+    if (__any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
+}
+
+// sequential double prefix sums, src/events.c:293-303: strictly in order, by one lane.
+// The wave converts a tile to pA (and float squares) in parallel into LDS; lane 0 then runs
+// the two dependent double accumulations and writes sum[i+1], sumsq[i+1].
+constexpr int SP_TILE = 2048;
+struct PrefixLds {
+    float x[SP_TILE];
+    float xq[SP_TILE];
+};
+template <typename T>
+__device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLds *L) {
+    const int l = lane_id();
+    const int64_t n = rc.n;
+    double s = 0.0, sq = 0.0;
+    if (l == 0) { P[0] = 0.0; P2[0] = 0.0; }
+    for (int64_t tb = 0; tb < n; tb += SP_TILE) {
+        const int m = (n - tb) < SP_TILE ? (int)(n - tb) : SP_TILE;
+        __syncthreads();
+        for (int k = l; k < m; k += 64) {
+            const float x = to_pa(rc.base[tb + k], rc.sc);
+            L->x[k] = x;
+            L->xq[k] = x * x;
+        }
+        __syncthreads();
+        if (l == 0) {
+            for (int k = 0; k < m; ++k) {
+                s = s + (double)L->x[k];
+                sq = sq + (double)L->xq[k];
+                P[tb + k + 1] = s;
+                P2[tb + k + 1] = sq;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- kernels
+
+template <int W1, typename T>
+__global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[RowStream<T>::LDS_BYTES];
+    const uint32_t r = blockIdx.x;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
+    const bool flagged = detect_read<W1, T, false>(rc, lds, a.hdr);
+    if (lane_id() == 0) {
+        a.flags[r] = flagged ? 1 : 0;
+        if (flagged) {
+            const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
+            a.flag_list[k] = r;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_event_build(EvArgs a) {
+    __shared__ BuildLds L;
+    const uint32_t r = blockIdx.x;
+    if (a.flags[r]) return;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
+    build_read<T>(a, rc, r, &L);
+}
+
+template <int W1, typename T>
+__global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
+    __shared__ PrefixLds L;
+    double *P = a.scratch + (uint64_t)blockIdx.x * a.scratch_stride;
+    double *P2 = P + a.scratch_stride / 2;
+    const uint32_t nf = a.hdr->n_flagged;
+    for (;;) {
+        uint32_t w = 0;
+        if (lane_id() == 0) w = atomicAdd(&a.hdr->fb_next, 1u);
+        w = __shfl(w, 0, 64);
+        if (w >= nf) break;
+        const uint32_t r = a.flag_list[w];
+        ReadCtx<T> rc = make_ctx<T>(a, r);
+        seq_prefix<T>(rc, P, P2, &L);
+        rc.P = P;
+        rc.P2 = P2;
+        detect_read<W1, T, true>(rc, nullptr, a.hdr);
+        __threadfence();
+        __syncthreads();
+        build_read_prefix<T>(a, rc, r);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- launcher
+
+template <typename T>
+static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
+    if (a.n_reads == 0) return SGK_OK;
+    SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
+    {
+        ProfScope ps("k_event_detect", st);
+        if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_event_detect<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
+    }
+    SGK_HIP_TRY(hipGetLastError());
+    {
+        ProfScope ps("k_event_build", st);
+        hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, a);
+    }
+    SGK_HIP_TRY(hipGetLastError());
+    {
+        ProfScope ps("k_event_fallback", st);
+        if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_event_fallback<3, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);
+    }
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_event(const EvArgs &a, int rna, bool float_input, uint32_t n_fb_blocks, hipStream_t st) {
+    return float_input ? launch_event_t<float>(a, rna, n_fb_blocks, st)
+                       : launch_event_t<int16_t>(a, rna, n_fb_blocks, st);
+}
+
+}  // namespace sgk
