@@ -1,0 +1,137 @@
+"""Device-resident batches on top of the C ABI.  torch is used only as the allocator / stream
+provider (plumbing): every compute call goes through libsigtk_gpu.so with raw device pointers
+and the current torch HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import api
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())
+
+
+@dataclass
+class DeviceReads:
+    """A batch of reads resident in HBM (sgk_batch_t view + owning tensors)."""
+    samples: torch.Tensor   # int16 [n_samples]
+    offsets: torch.Tensor   # int64 (uint64 bits) [n_reads]
+    lengths: torch.Tensor   # int32 (uint32 bits) [n_reads]
+    dig: torch.Tensor       # float64 [n_reads]
+    off: torch.Tensor
+    rng: torch.Tensor
+    n_reads: int
+    max_read_len: int
+    n_samples: int
+    offsets_host: np.ndarray
+    lengths_host: np.ndarray
+
+    def view(self) -> api.Batch:
+        return api.Batch(_ptr(self.samples), _ptr(self.offsets), _ptr(self.lengths), _ptr(self.dig),
+                         _ptr(self.off), _ptr(self.rng), self.n_reads, self.max_read_len, self.n_samples)
+
+    @property
+    def total_samples(self) -> int:
+        return int(self.lengths_host.astype(np.int64).sum())
+
+
+def alloc_reads(lengths: np.ndarray, device: torch.device, align: int = 64) -> DeviceReads:
+    """Lay out reads of the given lengths with every read starting on an `align`-sample boundary."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = lengths.size
+    padded = (lengths + align - 1) // align * align
+    offsets = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        np.cumsum(padded[:-1], out=offsets[1:])
+    n_samples = int(padded.sum()) if n else 0
+    n_samples = max((n_samples + 63) // 64 * 64, 64)
+    return DeviceReads(
+        samples=torch.zeros(n_samples, dtype=torch.int16, device=device),
+        offsets=torch.from_numpy(offsets).to(device),
+        lengths=torch.from_numpy(lengths.astype(np.int32)).to(device),
+        dig=torch.zeros(max(n, 1), dtype=torch.float64, device=device),
+        off=torch.zeros(max(n, 1), dtype=torch.float64, device=device),
+        rng=torch.zeros(max(n, 1), dtype=torch.float64, device=device),
+        n_reads=n, max_read_len=int(lengths.max()) if n else 0, n_samples=n_samples,
+        offsets_host=offsets.astype(np.uint64), lengths_host=lengths.astype(np.uint32))
+
+
+def synth_reads(n_reads: int, read_len: int, seed: int, kind: int, device: torch.device,
+                first_read: int = 0) -> DeviceReads:
+    """Synthetic reads generated on the device (same generator as api.synth_reads_host)."""
+    L = api.load_library()
+    b = alloc_reads(np.full(n_reads, read_len, dtype=np.int64), device)
+    api.check(L.sgk_synth_reads(_ptr(b.samples), _ptr(b.offsets), _ptr(b.lengths), _ptr(b.dig), _ptr(b.off),
+                                _ptr(b.rng), b.n_reads, b.max_read_len, first_read, seed, kind, _stream_ptr()),
+              "sgk_synth_reads")
+    return b
+
+
+def upload_reads(reads, dig, off, rng, device: torch.device) -> DeviceReads:
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    b = alloc_reads(lens, device)
+    host = np.zeros(b.n_samples, dtype=np.int16)
+    for r, raw in enumerate(reads):
+        o = int(b.offsets_host[r])
+        host[o:o + len(raw)] = raw
+    b.samples.copy_(torch.from_numpy(host))
+    b.dig[:b.n_reads] = torch.from_numpy(np.asarray(dig, dtype=np.float64))
+    b.off[:b.n_reads] = torch.from_numpy(np.asarray(off, dtype=np.float64))
+    b.rng[:b.n_reads] = torch.from_numpy(np.asarray(rng, dtype=np.float64))
+    return b
+
+
+class EventArena:
+    """Output arena + workspace of sgk_event for one batch shape (allocated once, reused)."""
+
+    def __init__(self, b: DeviceReads):
+        L = api.load_library()
+        dev = b.samples.device
+        slots = np.zeros(b.n_reads + 1, dtype=np.int64)
+        np.cumsum(b.lengths_host.astype(np.int64) // 3 + 2, out=slots[1:])
+        self.slots_host = slots
+        self.n_slots = int(slots[-1])
+        self.slots = torch.from_numpy(slots).to(dev)
+        self.start = torch.empty(max(self.n_slots, 1), dtype=torch.int32, device=dev)
+        self.length = torch.empty(max(self.n_slots, 1), dtype=torch.int32, device=dev)
+        self.mean = torch.empty(max(self.n_slots, 1), dtype=torch.float32, device=dev)
+        self.stdv = torch.empty(max(self.n_slots, 1), dtype=torch.float32, device=dev)
+        self.n_events = torch.zeros(max(b.n_reads, 1), dtype=torch.int32, device=dev)
+        self.ws_bytes = int(L.sgk_event_workspace_bytes(b.n_reads, b.n_samples, b.max_read_len))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        assert self.ws.data_ptr() % 64 == 0
+
+    def status(self) -> api.EventStatus:
+        L = api.load_library()
+        st = api.EventStatus()
+        rc = L.sgk_event_status(_ptr(self.ws), C.byref(st), _stream_ptr())
+        if rc != api.SGK_OK and rc != api.SGK_ERR_CAPACITY:
+            api.check(rc, "sgk_event_status")
+        return st
+
+    def read_events(self, r: int) -> api.Events:
+        k = int(self.n_events[r].item())
+        s = int(self.slots_host[r])
+        return api.Events(self.start[s:s + k].cpu().numpy().view(np.uint32),
+                          self.length[s:s + k].cpu().numpy().view(np.uint32),
+                          self.mean[s:s + k].cpu().numpy(), self.stdv[s:s + k].cpu().numpy())
+
+
+def event(b: DeviceReads, arena: EventArena, rna: int) -> None:
+    """Enqueue one pass of the event path over the batch on the current stream (async)."""
+    L = api.load_library()
+    view = b.view()
+    api.check(L.sgk_event(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.start), _ptr(arena.length),
+                          _ptr(arena.mean), _ptr(arena.stdv), _ptr(arena.n_events), _ptr(arena.ws),
+                          arena.ws_bytes, _stream_ptr()), "sgk_event")
