@@ -1,15 +1,161 @@
-// TEMPORARY stubs (replaced by the real stat / jnn / prefix entry points)
+// api_stat.hip -- C ABI entry points of stat / stat_pa / jnn / prefix (device and host layers).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "host_util.h"
 #include "sgk_common.h"
-extern "C" {
-size_t sgk_stat_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
-int sgk_stat(const sgk_batch_t *, sgk_stat_rec_t *, void *, size_t, void *) { return SGK_ERR_ARG; }
-int sgk_stat_pa(const sgk_batch_t *, sgk_stat_rec_t *, float *, void *, size_t, void *) { return SGK_ERR_ARG; }
-size_t sgk_jnn_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
-int sgk_jnn(const sgk_batch_t *, int, const uint64_t *, int32_t *, int32_t *, uint32_t *, void *, size_t, void *) { return SGK_ERR_ARG; }
-size_t sgk_prefix_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
-int sgk_prefix(const sgk_batch_t *, int, int, sgk_prefix_rec_t *, void *, size_t, void *) { return SGK_ERR_ARG; }
-int sgk_stat_host(const sgk_host_batch_t *, sgk_stat_rec_t *) { return SGK_ERR_ARG; }
-int sgk_jnn_host(const sgk_host_batch_t *, int, sgk_segs_host_t *) { return SGK_ERR_ARG; }
-void sgk_segs_host_free(sgk_segs_host_t *) {}
-int sgk_prefix_host(const sgk_host_batch_t *, int, int, sgk_prefix_rec_t *) { return SGK_ERR_ARG; }
+#include "stat_args.h"
+
+using namespace sgk;
+
+static StatArgs make_args(const sgk_batch_t *b) {
+    StatArgs a;
+    memset(&a, 0, sizeof a);
+    a.b = *b;
+    return a;
 }
+
+extern "C" {
+
+size_t sgk_stat_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
+size_t sgk_jnn_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
+size_t sgk_prefix_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
+
+int sgk_stat(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream) {
+    (void)ws; (void)ws_bytes;
+    const int rc = check_batch(b);
+    if (rc != SGK_OK) return rc;
+    if (b->n_reads == 0) return SGK_OK;
+    if (!out) return SGK_ERR_ARG;
+    StatArgs a = make_args(b);
+    a.stat = out;
+    return launch_stat(a, static_cast<hipStream_t>(stream));
+}
+
+int sgk_stat_pa(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = sgk_stat(b, out, ws, ws_bytes, stream);
+    if (rc != SGK_OK) return rc;
+    if (b->n_reads == 0) return SGK_OK;
+    if (!pa_out) return SGK_ERR_ARG;
+    return launch_pa(b, pa_out, static_cast<hipStream_t>(stream));
+}
+
+int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
+            uint32_t *n_segs, void *ws, size_t ws_bytes, void *stream) {
+    const int rc = check_batch(b);
+    if (rc != SGK_OK) return rc;
+    if (b->n_reads == 0) return SGK_OK;
+    if (!seg_slots || !seg_x || !seg_y || !n_segs || !ws) return SGK_ERR_ARG;
+    if (ws_bytes < 64) return SGK_ERR_WORKSPACE;
+    StatArgs a = make_args(b);
+    a.seg_slots = seg_slots;
+    a.seg_x = seg_x;
+    a.seg_y = seg_y;
+    a.n_segs = n_segs;
+    a.err_count = static_cast<uint32_t *>(ws);
+    return launch_jnn(a, rna, static_cast<hipStream_t>(stream));
+}
+
+int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
+               void *stream) {
+    (void)ws; (void)ws_bytes;
+    const int rc = check_batch(b);
+    if (rc != SGK_OK) return rc;
+    if (b->n_reads == 0) return SGK_OK;
+    if (!out) return SGK_ERR_ARG;
+    StatArgs a = make_args(b);
+    a.prefix = out;
+    return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------- host layer
+
+int sgk_stat_host(const sgk_host_batch_t *hb, sgk_stat_rec_t *out) {
+    DeviceBatch db;
+    int rc = db.upload(hb);
+    if (rc != SGK_OK) return rc;
+    const size_t nr = hb->n_reads;
+    if (nr == 0) return SGK_OK;
+    if (!out) return SGK_ERR_ARG;
+    DevBuf d_out;
+    if ((rc = d_out.alloc(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
+    if ((rc = sgk_stat(&db.view, d_out.as<sgk_stat_rec_t>(), nullptr, 0, nullptr)) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipDeviceSynchronize());
+    SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_stat_rec_t), hipMemcpyDeviceToHost));
+    return SGK_OK;
+}
+
+int sgk_prefix_host(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefix_rec_t *out) {
+    DeviceBatch db;
+    int rc = db.upload(hb);
+    if (rc != SGK_OK) return rc;
+    const size_t nr = hb->n_reads;
+    if (nr == 0) return SGK_OK;
+    if (!out) return SGK_ERR_ARG;
+    DevBuf d_out;
+    if ((rc = d_out.alloc(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
+    if ((rc = sgk_prefix(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), nullptr, 0, nullptr)) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipDeviceSynchronize());
+    SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_prefix_rec_t), hipMemcpyDeviceToHost));
+    return SGK_OK;
+}
+
+int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
+    if (!out) return SGK_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    DeviceBatch db;
+    int rc = db.upload(hb);
+    if (rc != SGK_OK) return rc;
+    const uint32_t nr = hb->n_reads;
+    out->n_reads = nr;
+    out->seg_offsets = (uint64_t *)calloc((size_t)nr + 1, sizeof(uint64_t));
+    if (!out->seg_offsets) return SGK_ERR_NOMEM;
+    if (nr == 0) return SGK_OK;
+    const std::vector<uint64_t> slots = make_slots(db.lengths, [](uint32_t n) { return sgk_jnn_slots_for(n); });
+    const uint64_t nslots = slots[nr];
+    DevBuf d_slots, d_x, d_y, d_n, d_ws;
+    if ((rc = d_slots.alloc((nr + 1) * sizeof(uint64_t))) != SGK_OK) return rc;
+    if ((rc = d_x.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_y.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_n.alloc((size_t)nr * 4)) != SGK_OK) return rc;
+    if ((rc = d_ws.alloc(64)) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    rc = sgk_jnn(&db.view, rna, d_slots.as<uint64_t>(), d_x.as<int32_t>(), d_y.as<int32_t>(), d_n.as<uint32_t>(),
+                 d_ws.p, 64, nullptr);
+    if (rc != SGK_OK) return rc;
+    SGK_HIP_TRY(hipDeviceSynchronize());
+    uint32_t nerr = 0;
+    SGK_HIP_TRY(hipMemcpy(&nerr, d_ws.p, 4, hipMemcpyDeviceToHost));
+    if (nerr) return SGK_ERR_CAPACITY;
+    std::vector<uint32_t> ns(nr);
+    SGK_HIP_TRY(hipMemcpy(ns.data(), d_n.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < nr; ++r) {
+        out->seg_offsets[r] = tot;
+        tot += ns[r];
+    }
+    out->seg_offsets[nr] = tot;
+    out->x = (int32_t *)malloc((tot ? tot : 1) * 4);
+    out->y = (int32_t *)malloc((tot ? tot : 1) * 4);
+    if (!out->x || !out->y) return SGK_ERR_NOMEM;
+    for (uint32_t r = 0; r < nr; ++r) {
+        if (!ns[r]) continue;
+        SGK_HIP_TRY(hipMemcpy(out->x + out->seg_offsets[r], d_x.as<int32_t>() + slots[r], (size_t)ns[r] * 4,
+                              hipMemcpyDeviceToHost));
+        SGK_HIP_TRY(hipMemcpy(out->y + out->seg_offsets[r], d_y.as<int32_t>() + slots[r], (size_t)ns[r] * 4,
+                              hipMemcpyDeviceToHost));
+    }
+    return SGK_OK;
+}
+
+void sgk_segs_host_free(sgk_segs_host_t *s) {
+    if (!s) return;
+    free(s->seg_offsets);
+    free(s->x);
+    free(s->y);
+    memset(s, 0, sizeof *s);
+}
+
+}  // extern "C"

@@ -34,73 +34,19 @@
 // multiple of 2^g (g = lowest bit of the smallest non-zero |x|) and all partial sums are below
 // 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29  for x and for the
 // float squares; reads failing the check take the fallback kernel.
-#include "sgk_common.h"
 #include "event_args.h"
+#include "row_stream.h"
+#include "sgk_common.h"
 
 namespace sgk {
 
 constexpr int LEAD = 64;   // speculative warm-up (samples); multiple of 64
-constexpr int TILE = 64;   // samples per row tile
 constexpr int BACK = 32;   // row margin before the pass start (>= W2 + 1)
 
 __device__ inline uint32_t chunk_len(int64_t n) {
     const int64_t k = (n + 4095) / 4096;
     return (uint32_t)(k < 1 ? 64 : 64 * k);
 }
-
-// ---------------------------------------------------------------- LDS row streamer
-// 64 rows (one per lane), each row a window of 2 tiles x 64 samples of T; the row stride is
-// padded by one dword so that lane-per-row reads are bank-conflict free.
-template <typename T>
-struct RowStream {
-    static constexpr int ROW_BYTES = 2 * TILE * (int)sizeof(T) + 4;
-    static constexpr int LDS_BYTES = 64 * ROW_BYTES;
-    static constexpr int PER_VEC = 16 / (int)sizeof(T);  // samples per 16-byte vector
-    static constexpr int VECS = TILE / PER_VEC;          // vectors per row tile
-    static constexpr int ROWS_PER_IT = 64 / VECS;
-
-    char *lds;       // this wave's region
-    const T *base;   // read base (global)
-    int64_t lo, hi;  // loads are legal for read-relative sample index in [lo, hi)
-    int64_t rb;      // this lane's row: read-relative index of row sample 0
-    bool vec_ok;     // read base 16-byte aligned
-
-    // cooperative: every lane of the wave calls it.  rowmask = rows that need data.
-    __device__ void load_tile(int tile, unsigned long long rowmask) {
-        const int l = lane_id();
-        const int v = l % VECS;
-        __syncthreads();  // readers of the slot being replaced are done
-        for (int it = 0; it < VECS; ++it) {
-            const int row = it * ROWS_PER_IT + l / VECS;
-            const int64_t rbr = (int64_t)__shfl((long long)rb, row, 64);
-            if ((rowmask >> row) & 1ull) {
-                const int64_t p0 = rbr + (int64_t)tile * TILE + (int64_t)v * PER_VEC;
-                uint32_t w[4] = {0u, 0u, 0u, 0u};
-                if (vec_ok && p0 >= lo && p0 + PER_VEC <= hi) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(base + p0);
-                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-                } else {
-                    T tmp[PER_VEC];
-#pragma unroll
-                    for (int k = 0; k < PER_VEC; ++k) {
-                        const int64_t p = p0 + k;
-                        tmp[k] = (p >= lo && p < hi) ? base[p] : (T)0;
-                    }
-                    __builtin_memcpy(w, tmp, 16);
-                }
-                uint32_t *dst = reinterpret_cast<uint32_t *>(
-                    lds + row * ROW_BYTES + (tile & 1) * TILE * (int)sizeof(T) + v * 16);
-                dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
-            }
-        }
-        __syncthreads();
-    }
-    // sample at row index q of this lane's row (q must lie in one of the two resident tiles)
-    __device__ T get(int q) const {
-        const int off = lane_id() * ROW_BYTES + (((q >> 6) & 1) * TILE + (q & 63)) * (int)sizeof(T);
-        return *reinterpret_cast<const T *>(lds + off);
-    }
-};
 
 // ---------------------------------------------------------------- t-statistic
 // src/events.c:338-361, one rounding per C operator (FLT_EVAL_METHOD 0, no contraction).
@@ -279,13 +225,13 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
     constexpr int W2 = 2 * W1;
     const int64_t n = rc.n;
     const int64_t i_begin = s - lead;
-    RowStream<T> rs;
+    RowStream<T, 2> rs;
     rs.lds = lds;
     rs.base = rc.base;
     rs.lo = rc.lo;
     rs.hi = rc.hi;
     rs.rb = i_begin - BACK;
-    rs.vec_ok = rc.vec_ok;
+    rs.base_al = rc.vec_ok;
     const unsigned long long rowmask = __ballot(active);
     if (rowmask == 0ull) return;
 
@@ -667,7 +613,7 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[RowStream<T>::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[RowStream<T, 2>::LDS_BYTES];
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
     const bool flagged = detect_read<W1, T, false>(rc, lds, a.hdr);

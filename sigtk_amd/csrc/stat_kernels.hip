@@ -1,0 +1,477 @@
+// stat_kernels.hip -- per-read statistics, the JNN segmenter and the adaptor/polyA finder.
+//
+// Reference semantics that shape these kernels:
+//   * meanf/meani16/stdvf/stdvi16 (src/stat.h:17-54) accumulate into ONE float, strictly in
+//     sample order; at 100k samples the result differs from the exact value by up to ~6e-5
+//     relative, so the order must be reproduced: one read per LANE, serial float chain.
+//     The lanes of a wave stream 64 different reads through the LDS row stager (row_stream.h),
+//     so global loads are still whole 128-byte line segments.
+//   * medians are order statistics (rank n/2, src/stat.h:56-73 + ksort.h:233-259): any exact
+//     selection works -> one 256-thread workgroup per read, two-level radix select on the
+//     int16 keys with LDS histograms; pA median = pA(raw order statistic) because the
+//     int16 -> pA map is monotone (non-increasing when range/digitisation < 0).
+//   * jnn_core (src/jnn.c:190-278) and jnnv2 (src/jnn.c:99-179) are serial automata with
+//     thresholds derived from those sequential float moments: one read per lane as well.
+#include "row_stream.h"
+#include "sgk_common.h"
+#include "stat_args.h"
+
+namespace sgk {
+
+using Stream1 = RowStream<int16_t, 1>;
+
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// region of read r a kernel works on (absolute sample index + length)
+struct Region {
+    int64_t start;
+    int64_t len;
+};
+__device__ inline Region get_region(int mode, const sgk_batch_t &b, const sgk_prefix_rec_t *prec, uint32_t r) {
+    Region g;
+    g.start = (int64_t)b.offsets[r];
+    g.len = (int64_t)b.lengths[r];
+    if (mode == REG_ADAPT) {
+        const sgk_prefix_rec_t p = prec[r];
+        if (p.adapt_y > 0) { g.start += p.adapt_x; g.len = (int64_t)p.adapt_y - p.adapt_x; }
+        else g.len = 0;
+    } else if (mode == REG_POLYA) {
+        const sgk_prefix_rec_t p = prec[r];
+        if (p.adapt_y > 0 && p.polya_y > 0) { g.start += (int64_t)p.polya_x + p.adapt_y; g.len = (int64_t)p.polya_y - p.polya_x; }
+        else g.len = 0;
+    } else if (mode == REG_TAIL) {  // pA[adapt_y .. n), find_polya's input (cfunc.c:186-191)
+        const sgk_prefix_rec_t p = prec[r];
+        if (p.adapt_y > 0) { g.start += p.adapt_y; g.len -= p.adapt_y; }
+        else g.len = 0;
+    }
+    if (g.len < 0) g.len = 0;
+    return g;
+}
+
+__device__ inline float clampf_raw(int16_t v) {  // rm_outlier, src/jnn.c:61-77
+    return v > 1200 ? 1200.0f : (v < 0 ? 0.0f : (float)v);
+}
+__device__ inline float clampf_pa(float v) {     // rm_outlierf, src/jnn.c:79-95
+    return v > 1200.0f ? 1200.0f : (v < 0.0f ? 0.0f : v);
+}
+
+// Lane-per-row sequential sweep: calls f(j, raw) for j = 0..len-1 in order.  All lanes of the wave
+// must call it (cooperative tile loads); lanes with len == 0 just help loading.
+template <typename F>
+__device__ inline void sweep_rows(Stream1 &rs, int skip, int64_t len, unsigned long long rowmask, F f) {
+    const int maxq = wave_max_i((int)(len > 0 ? skip + len : 0));
+    const int ntiles = (maxq + TILE - 1) / TILE;
+    for (int t = 0; t < ntiles; ++t) {
+        rs.load_tile(t, rowmask);
+        const int q0 = t * TILE;
+        if (q0 + TILE > skip && q0 < skip + len) {
+#pragma unroll 4
+            for (int k = 0; k < TILE; ++k) {
+                const int64_t j = (int64_t)(q0 + k) - skip;
+                if (j >= 0 && j < len) f(j, rs.get(q0 + k));
+            }
+        }
+    }
+}
+
+__device__ inline Stream1 make_stream(char *lds, const sgk_batch_t &b, int64_t start, int &skip) {
+    Stream1 rs;
+    rs.lds = lds;
+    rs.base = b.samples;
+    rs.lo = 0;
+    rs.hi = (int64_t)b.n_samples;
+    rs.rb = start & ~(int64_t)7;
+    skip = (int)(start - rs.rb);
+    rs.base_al = true;  // checked by the launcher
+    return rs;
+}
+
+// ---------------------------------------------------------------- moments (src/stat.h:17-54)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_moments(StatArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
+    const uint32_t r = blockIdx.x * 64 + lane_id();
+    const bool valid = r < a.b.n_reads;
+    Region g = {0, 0};
+    Scale sc = {0.0f, 1.0f};
+    if (valid) {
+        g = get_region(MODE, a.b, a.prefix, r);
+        sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+    }
+    int skip;
+    Stream1 rs = make_stream(lds, a.b, g.start, skip);
+    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    const float nf = (float)(int)g.len;
+    float sraw = 0.0f, spa = 0.0f;
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+        sraw = sraw + (float)v;
+        spa = spa + to_pa(v, sc);
+    });
+    const float mraw = sraw / nf, mpa = spa / nf;
+    float qraw = 0.0f, qpa = 0.0f;
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+        const float d = (float)v - mraw;
+        qraw = qraw + d * d;
+        const float e = to_pa(v, sc) - mpa;
+        qpa = qpa + e * e;
+    });
+    if (!valid) return;
+    const float sdraw = sqrtf(qraw / nf), sdpa = sqrtf(qpa / nf);
+    if (MODE == REG_WHOLE) {
+        sgk_stat_rec_t *o = a.stat + r;
+        o->raw_mean = mraw; o->pa_mean = mpa; o->raw_std = sdraw; o->pa_std = sdpa;
+        o->n = (uint32_t)g.len;
+        o->reserved = 0;
+    } else if (MODE == REG_ADAPT) {
+        a.prefix[r].adapt_mean = mpa;
+        a.prefix[r].adapt_std = sdpa;
+    } else {
+        a.prefix[r].polya_mean = mpa;
+        a.prefix[r].polya_std = sdpa;
+    }
+}
+
+// ---------------------------------------------------------------- median (src/stat.h:56-73)
+// rank-k order statistic of the int16 keys of a region, by a 256-thread workgroup
+__device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t *hist /*4096*/, uint32_t *part /*256+2*/) {
+    const int t = threadIdx.x;
+    for (int i = t; i < 4096; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = t; i < n; i += 256) atomicAdd(&hist[((uint32_t)((int)x[i] + 32768)) >> 4], 1u);
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += hist[t * 16 + k];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
+    }
+    __syncthreads();
+    const uint32_t before = part[t];
+    if ((uint64_t)rank >= before && (uint64_t)rank < (uint64_t)before + s) {
+        uint32_t acc = before;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t h = hist[t * 16 + k];
+            if ((uint64_t)rank < (uint64_t)acc + h) { part[256] = (uint32_t)(t * 16 + k); part[257] = (uint32_t)(rank - acc); break; }
+            acc += h;
+        }
+    }
+    __syncthreads();
+    const uint32_t bin = part[256], rank2 = part[257];
+    __syncthreads();
+    if (t < 16) hist[t] = 0;
+    __syncthreads();
+    for (int64_t i = t; i < n; i += 256) {
+        const uint32_t key = (uint32_t)((int)x[i] + 32768);
+        if ((key >> 4) == bin) atomicAdd(&hist[key & 15u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0, val = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (rank2 < acc + hist[k]) { val = (uint32_t)k; break; }
+            acc += hist[k];
+        }
+        part[256] = val;
+    }
+    __syncthreads();
+    const int res = (int)((bin << 4) | part[256]) - 32768;
+    __syncthreads();
+    return res;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_median(StatArgs a) {
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t part[258];
+    const uint32_t r = blockIdx.x;
+    const Region g = get_region(MODE, a.b, a.prefix, r);
+    if (g.len <= 0) {
+        if (threadIdx.x == 0 && MODE == REG_WHOLE) { a.stat[r].raw_median = 0; a.stat[r].pa_median = 0.0f; }
+        return;
+    }
+    const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+    const int16_t *x = a.b.samples + g.start;
+    const int64_t k = g.len / 2;
+    const int med = block_select(x, g.len, k, hist, part);
+    int med_for_pa = med;
+    if (sc.unit < 0.0f && g.len - 1 - k != k) med_for_pa = block_select(x, g.len, g.len - 1 - k, hist, part);
+    if (threadIdx.x == 0) {
+        const float pm = to_pa((int16_t)med_for_pa, sc);
+        if (MODE == REG_WHOLE) { a.stat[r].raw_median = med; a.stat[r].pa_median = pm; }
+        else if (MODE == REG_ADAPT) a.prefix[r].adapt_median = pm;
+        else a.prefix[r].polya_median = pm;
+    }
+}
+
+// ---------------------------------------------------------------- jnn_core automaton (src/jnn.c:190-278)
+struct JnnAuto {
+    float top, bot, first_min;
+    int window, error, seg_dist;
+    int open, err, run_err, c, w, start, nseg, last_x, last_y;
+    __device__ void init(float top_, float bot_, int corrector, int seg_dist_, int window_, float stall_len, int error_) {
+        top = top_; bot = bot_; window = window_; error = error_; seg_dist = seg_dist_;
+        first_min = (float)window_ * stall_len;
+        open = 0; err = 0; run_err = 0; c = 0; w = corrector; start = 0; nseg = 0; last_x = 0; last_y = 0;
+    }
+    // emit(k, x, y) is called when segment k can no longer change
+    template <typename E>
+    __device__ void step(int i, float v, E emit) {
+        if (v < top && v > bot) {
+            if (!open) { start = i; open = 1; }
+            ++c; ++w;
+            run_err = 0;
+            if (c >= window && c >= w && (c % w) == 0) --err;
+        } else if (open && err < error) {
+            ++c; ++err; ++run_err;
+            if (c >= window && c >= w && (c % w) == 0) --err;
+        } else if (open && (c >= window || (nseg == 0 && (float)c >= first_min))) {
+            const int end = i - run_err;
+            open = 0;
+            if (nseg > 0 && start - last_y < seg_dist) {
+                last_y = end;
+            } else {
+                if (nseg > 0) emit(nseg - 1, last_x, last_y);
+                last_x = start; last_y = end;
+                ++nseg;
+            }
+            c = 0; err = 0; run_err = 0;
+        } else if (open) {
+            open = 0; c = 0; err = 0; run_err = 0;
+        }
+    }
+    template <typename E>
+    __device__ void finish(E emit) {
+        if (nseg > 0) emit(nseg - 1, last_x, last_y);
+    }
+};
+
+// jnn_raw with jnn_print's presets (src/jnn.c:282-293, :313-319; presets src/jnn.h:29-49)
+__global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
+    __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
+    const uint32_t r = blockIdx.x * 64 + lane_id();
+    const bool valid = r < a.b.n_reads;
+    Region g = {0, 0};
+    if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
+    int skip;
+    Stream1 rs = make_stream(lds, a.b, g.start, skip);
+    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    const float nf = (float)(int)g.len;
+    float s = 0.0f;
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) { s = s + clampf_raw(v); });
+    const float mn = s / nf;
+    float q = 0.0f;
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+        const float d = clampf_raw(v) - mn;
+        q = q + d * d;
+    });
+    const float sd = sqrtf(q / nf);
+    const float band = sd * 0.75f;
+    JnnAuto A;
+    if (rna) A.init(mn + band, mn - band, 50, 50, 1000, 1.0f, 5);
+    else A.init(mn + band, mn - band, 50, 50, 150, 0.25f, 5);
+    const uint64_t slot0 = valid ? a.seg_slots[r] : 0, cap = valid ? a.seg_slots[r + 1] - slot0 : 0;
+    bool overflow = false;
+    auto emit = [&](int k, int x, int y) {
+        if ((uint64_t)k < cap) { a.seg_x[slot0 + k] = x; a.seg_y[slot0 + k] = y; }
+        else overflow = true;
+    };
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
+    A.finish(emit);
+    if (valid) a.n_segs[r] = (uint32_t)A.nseg;
+    if (overflow) atomicAdd(a.err_count, 1u);
+}
+
+// find_polya (src/jnn.c:352-374): first segment of jnn_pa on pA[adapt_y..n) with fixed thresholds
+// top = (m_a+30)+20, bot = (m_a+30)-20 (src/cfunc.c:191); polyA preset src/jnn.h:52-72.
+__global__ __launch_bounds__(64) void k_polya(StatArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
+    const uint32_t r = blockIdx.x * 64 + lane_id();
+    const bool valid = r < a.b.n_reads;
+    Region g = {0, 0};
+    Scale sc = {0.0f, 1.0f};
+    float m_a = 0.0f;
+    if (valid) {
+        g = get_region(REG_TAIL, a.b, a.prefix, r);
+        sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+        m_a = a.prefix[r].adapt_mean;
+    }
+    int skip;
+    Stream1 rs = make_stream(lds, a.b, g.start, skip);
+    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    const float mid = m_a + 30.0f;
+    JnnAuto A;
+    A.init(mid + 20.0f, mid - 20.0f, 50, 200, 250, 1.0f, 30);
+    int px = -1, py = -1;
+    auto emit = [&](int k, int x, int y) {
+        if (k == 0) { px = x; py = y; }
+    };
+    // (a lane whose first segment is final could stop; the sweep is wave-cooperative, so it just idles)
+    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t j, int16_t v) {
+        if (py < 0 || A.nseg < 2) A.step((int)j, clampf_pa(to_pa(v, sc)), emit);
+    });
+    if (A.nseg == 1 || (A.nseg >= 2 && py < 0)) A.finish(emit);
+    if (valid) {
+        a.prefix[r].polya_x = px;
+        a.prefix[r].polya_y = py;
+    }
+}
+
+// ---------------------------------------------------------------- find_adaptor / jnnv2 (src/jnn.c:99-188)
+// rolling window mean (jnn.c:20-56) of the clamped raw signal, its sequential float mean/std,
+// then the below-threshold run finder with merging; first run with lo <= length <= hi.
+struct RunFinder {
+    float bot;
+    int seg_dist, lo, hi;
+    int in_run, start, end, nseg, last_x, last_y, ans_x, ans_y, found;
+    __device__ void init(float bot_, int seg_dist_, int lo_, int hi_) {
+        bot = bot_; seg_dist = seg_dist_; lo = lo_; hi = hi_;
+        in_run = 0; start = 0; end = 0; nseg = 0; last_x = 0; last_y = 0; ans_x = 0; ans_y = 0; found = 0;
+    }
+    __device__ void settle() {  // the last segment can no longer change
+        const int len = last_y - last_x;
+        if (!found && !(len > hi) && !(len < lo)) { found = 1; ans_x = last_x; ans_y = last_y; }
+    }
+    __device__ void step(int j, float v) {
+        if (v < bot && !in_run) { start = j; in_run = 1; }
+        else if (v < bot) { end = j; }
+        else if (v > bot && in_run) {
+            if (nseg > 0 && start - last_y < seg_dist) last_y = end;
+            else {
+                if (nseg > 0) settle();
+                last_x = start; last_y = end; ++nseg;
+            }
+            start = 0; end = 0; in_run = 0;
+        }
+    }
+    __device__ void finish() { if (nseg > 0) settle(); }
+};
+
+constexpr int ADW = 2000;  // jnnv2 window (both presets, src/jnn.h:84-98)
+
+// one rolling-window sweep: calls f(i, t_i) for i = 0..m-1 (m = n - ADW) in order
+template <typename F>
+__device__ inline void sweep_rolling(Stream1 &lead, Stream1 &trail, int skip, int64_t n, unsigned long long rowmask, F f) {
+    const int maxq = wave_max_i((int)(n > ADW ? skip + n : 0));
+    float tot = 0.0f;
+    for (int q0 = 0; q0 < maxq; q0 += 16) {
+        if ((q0 & 63) == 0) lead.load_tile(q0 >> 6, rowmask);
+        if (q0 >= ADW && ((q0 - ADW) & 63) == 0) trail.load_tile((q0 - ADW) >> 6, rowmask);
+        if (n > ADW) {
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const int q = q0 + k;
+                const int64_t il = (int64_t)q - skip;  // lead index
+                if (il < 0 || il >= n) continue;
+                const float cl = clampf_raw(lead.get(q));
+                if (il < ADW) {
+                    tot = tot + cl;
+                    if (il == ADW - 1) f((int64_t)0, tot / (float)ADW);
+                } else {
+                    const float ct = clampf_raw(trail.get(q - ADW));
+                    tot = tot - ct;
+                    tot = tot + cl;
+                    f(il - ADW + 1, tot / (float)ADW);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * Stream1::LDS_BYTES];
+    const uint32_t r = blockIdx.x * 64 + lane_id();
+    const bool valid = r < a.b.n_reads;
+    Region g = {0, 0};
+    if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
+    const int64_t n = g.len;
+    int skip;
+    Stream1 lead = make_stream(lds, a.b, g.start, skip);
+    Stream1 trail = lead;
+    trail.lds = lds + Stream1::LDS_BYTES;
+    const bool run = valid && n > ADW;
+    const unsigned long long rowmask = __ballot(run);
+    const int64_t m = n - ADW;
+    const float mf = (float)(int)m;
+    float s = 0.0f;
+    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) { if (i < m) s = s + t; });
+    const float mn = s / mf;
+    float q = 0.0f;
+    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) {
+        if (i < m) { const float d = t - mn; q = q + d * d; }
+    });
+    const float sd = sqrtf(q / mf);
+    const float std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
+    RunFinder F;
+    F.init(mn - sd * std_scale, 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
+    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) { if (i < m) F.step((int)i, t); });
+    F.finish();
+    if (!valid) return;
+    sgk_prefix_rec_t *o = a.prefix + r;
+    o->n = (uint32_t)n;
+    o->reserved = 0;
+    o->polya_x = -1; o->polya_y = -1;
+    o->adapt_mean = 0.0f; o->adapt_std = 0.0f; o->adapt_median = 0.0f;
+    o->polya_mean = 0.0f; o->polya_std = 0.0f; o->polya_median = 0.0f;
+    if (!run) { o->adapt_x = -1; o->adapt_y = -1; }
+    else if (F.found) { o->adapt_x = F.ans_x + ADW / 2 - 1; o->adapt_y = F.ans_y + ADW / 2 - 1; }
+    else { o->adapt_x = 0; o->adapt_y = 0; }
+}
+
+// ---------------------------------------------------------------- launchers
+#define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
+    do {                                                                           \
+        ProfScope ps_(name, st);                                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__);     \
+    } while (0)
+
+int launch_stat(const StatArgs &a, hipStream_t st) {
+    const uint32_t nr = a.b.n_reads;
+    if (nr == 0) return SGK_OK;
+    SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
+    SGK_HIP_TRY(hipGetLastError());
+    SGK_LAUNCH("k_median", (k_median<REG_WHOLE>), nr, 256, a);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_jnn(const StatArgs &a, int rna, hipStream_t st) {
+    const uint32_t nr = a.b.n_reads;
+    if (nr == 0) return SGK_OK;
+    SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
+    SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, rna);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
+    const uint32_t nr = a.b.n_reads;
+    if (nr == 0) return SGK_OK;
+    const uint32_t gw = (nr + 63) / 64;
+    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, pore);
+    SGK_HIP_TRY(hipGetLastError());
+    SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
+    SGK_HIP_TRY(hipGetLastError());
+    SGK_LAUNCH("k_median_adapt", (k_median<REG_ADAPT>), nr, 256, a);
+    SGK_HIP_TRY(hipGetLastError());
+    if (rna) {
+        SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
+        SGK_HIP_TRY(hipGetLastError());
+        SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
+        SGK_HIP_TRY(hipGetLastError());
+        SGK_LAUNCH("k_median_polya", (k_median<REG_POLYA>), nr, 256, a);
+        SGK_HIP_TRY(hipGetLastError());
+    }
+    return SGK_OK;
+}
+
+}  // namespace sgk

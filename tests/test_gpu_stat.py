@@ -1,0 +1,111 @@
+"""GPU parity: stat / jnn / prefix HIP paths against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5  # tolerance stated by BASELINE.json's north_star for float means/stds
+
+
+def _scal(recs):
+    return (np.array([r.digitisation for r in recs]), np.array([r.offset for r in recs]),
+            np.array([r.range for r in recs]))
+
+
+def _close(a, b, what):
+    a = np.float32(a); b = np.float32(b)
+    if np.isnan(a) and np.isnan(b):
+        return
+    assert abs(float(a) - float(b)) <= REL * max(abs(float(b)), 1e-30), "%s: gpu %r oracle %r" % (what, a, b)
+
+
+def _check_stat(oracle, reads, dig, off, rng, got, exact=True):
+    for r, raw in enumerate(reads):
+        e = oracle.stat(raw, dig[r], off[r], rng[r])
+        g = got[r]
+        assert int(g["n"]) == raw.size
+        assert int(g["raw_median"]) == e[4], "read %d raw_median" % r
+        for name, ev in (("raw_mean", e[0]), ("pa_mean", e[1]), ("raw_std", e[2]), ("pa_std", e[3]),
+                         ("pa_median", e[5])):
+            _close(g[name], ev, "read %d %s" % (r, name))
+            if exact:  # same sequential float order as the reference: expect identical bits
+                assert np.float32(g[name]).view(np.uint32) == np.float32(ev).view(np.uint32), \
+                    "read %d %s not bit-exact: %r vs %r" % (r, name, g[name], ev)
+
+
+def test_stat_sp1_dna(gpu, oracle, sp1):
+    reads = [r.raw for r in sp1.reads]
+    dig, off, rng = _scal(sp1.reads)
+    _check_stat(oracle, reads, dig, off, rng, gpu.stat(reads, dig, off, rng))
+
+
+def test_stat_synthetic_100k(gpu, oracle):
+    reads, dig, off, rng = gpu.synth_reads_host(5, 100000, seed=3, kind=0)
+    _check_stat(oracle, reads, dig, off, rng, gpu.stat(reads, dig, off, rng))
+
+
+def test_stat_ragged_and_negative_range(gpu, oracle):
+    lens = [1, 2, 3, 7, 8, 9, 63, 64, 65, 100, 1000, 4097, 70001]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=5, kind=0)
+    rs = np.random.RandomState(1)
+    reads[4] = rs.randint(-32768, 32767, size=8).astype(np.int16)
+    reads[10] = rs.randint(-2000, 2000, size=1000).astype(np.int16)
+    rng = rng.copy(); rng[5] = -rng[5]; rng[11] = -rng[11]
+    _check_stat(oracle, reads, dig, off, rng, gpu.stat(reads, dig, off, rng))
+
+
+def _check_jnn(oracle, reads, rna, got):
+    for r, raw in enumerate(reads):
+        ex, ey = oracle.jnn_raw(raw, rna)
+        gx, gy = got[r]
+        np.testing.assert_array_equal(gx.astype(np.int64), ex, err_msg="read %d seg x" % r)
+        np.testing.assert_array_equal(gy.astype(np.int64), ey, err_msg="read %d seg y" % r)
+
+
+def test_jnn_sp1_dna(gpu, oracle, sp1):
+    reads = [r.raw for r in sp1.reads]
+    dig, off, rng = _scal(sp1.reads)
+    for rna in (0, 1):
+        _check_jnn(oracle, reads, rna, gpu.jnn(reads, dig, off, rng, rna))
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_jnn_synthetic(gpu, oracle, kind):
+    lens = [0, 1, 149, 150, 151, 1000, 5000, 30000, 100000, 100000]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=9, kind=kind)
+    for rna in (0, 1):
+        _check_jnn(oracle, reads, rna, gpu.jnn(reads, dig, off, rng, rna))
+
+
+def _check_prefix(oracle, reads, dig, off, rng, rna, pore, got):
+    for r, raw in enumerate(reads):
+        e = oracle.prefix(raw, dig[r], off[r], rng[r], rna, pore)
+        g = got[r]
+        assert (int(g["adapt_x"]), int(g["adapt_y"])) == (e.adapt_x, e.adapt_y), "read %d adaptor" % r
+        assert (int(g["polya_x"]), int(g["polya_y"])) == (e.polya_x, e.polya_y), "read %d polyA" % r
+        if e.adapt_y > 0:
+            for name in ("adapt_mean", "adapt_std", "adapt_median"):
+                _close(g[name], getattr(e, name), "read %d %s" % (r, name))
+                assert np.float32(g[name]).view(np.uint32) == np.float32(getattr(e, name)).view(np.uint32)
+        if e.polya_y > 0:
+            for name in ("polya_mean", "polya_std", "polya_median"):
+                _close(g[name], getattr(e, name), "read %d %s" % (r, name))
+                assert np.float32(g[name]).view(np.uint32) == np.float32(getattr(e, name)).view(np.uint32)
+
+
+def test_prefix_sp1_dna(gpu, oracle, sp1):
+    reads = [r.raw for r in sp1.reads]
+    dig, off, rng = _scal(sp1.reads)
+    _check_prefix(oracle, reads, dig, off, rng, 0, 0, gpu.prefix(reads, dig, off, rng, 0, 0))
+    # RNA handling of the same reads exercises find_polya on real signal
+    _check_prefix(oracle, reads, dig, off, rng, 1, 0, gpu.prefix(reads, dig, off, rng, 1, 0))
+
+
+@pytest.mark.parametrize("pore", [0, 2])
+def test_prefix_synthetic_rna(gpu, oracle, pore):
+    lens = [100, 2000, 2001, 2500, 20000, 50000, 100000, 100000, 100000, 100000]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=21, kind=1)
+    got = gpu.prefix(reads, dig, off, rng, 1, pore)
+    _check_prefix(oracle, reads, dig, off, rng, 1, pore, got)
+    assert (int(got[0]["adapt_x"]), int(got[0]["adapt_y"])) == (-1, -1)   # too short (jnn.c:173-177)
+    assert any(int(g["adapt_y"]) > 0 and int(g["polya_y"]) > 0 for g in got)  # the structure is found
