@@ -64,7 +64,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     if not force and _newer(CLI, deps) and _newer(CLI, [LIB]):
         return CLI
     cmd = ["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI, *srcs,
-           "-L", PKG, "-lsigtk_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lm"]
+           "-L", PKG, "-lsigtk_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lm", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

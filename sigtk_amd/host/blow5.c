@@ -1,0 +1,252 @@
+/* blow5.c -- see blow5.h */
+#include "blow5.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+static const uint8_t B5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', 1};
+static const char B5_EOF_MARK[5] = {'5', 'W', 'O', 'L', 'B'};
+
+static int grow(uint8_t **p, uint64_t *cap, uint64_t need) {
+    if (*cap >= need) return 0;
+    uint64_t c = *cap ? *cap : 4096;
+    while (c < need) c *= 2;
+    uint8_t *q = (uint8_t *)realloc(*p, c);
+    if (!q) return B5_ERR_MEM;
+    *p = q;
+    *cap = c;
+    return 0;
+}
+
+b5_file_t *b5_open(const char *path) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return NULL;
+    uint8_t head[68];
+    if (fread(head, 1, 68, fp) != 68 || memcmp(head, B5_MAGIC, 6) != 0) {
+        fclose(fp);
+        return NULL;
+    }
+    b5_file_t *f = (b5_file_t *)calloc(1, sizeof *f);
+    if (!f) { fclose(fp); return NULL; }
+    f->fp = fp;
+    f->path = strdup(path);
+    memcpy(f->version, head + 6, 3);
+    f->record_press = head[9];
+    memcpy(&f->num_read_groups, head + 10, 4);
+    /* the signal compression byte exists from file version 0.2.0 on */
+    const int has_sig = f->version[0] > 0 || f->version[1] >= 2;
+    f->signal_press = has_sig ? head[14] : 0;
+    uint32_t hsize;
+    memcpy(&hsize, head + 64, 4);
+    f->hdr_text = (char *)malloc((size_t)hsize + 1);
+    if (!f->hdr_text || fread(f->hdr_text, 1, hsize, fp) != hsize) { b5_close(f); return NULL; }
+    f->hdr_text[hsize] = '\0';
+    f->first_rec = 68 + (uint64_t)hsize;
+    if (f->record_press > 1 || f->signal_press > 1) { b5_close(f); return NULL; }
+    return f;
+}
+
+void b5_close(b5_file_t *f) {
+    if (!f) return;
+    if (f->fp) fclose(f->fp);
+    for (uint64_t i = 0; i < f->n_idx; i++) free(f->idx[i].id);
+    free(f->idx);
+    free(f->hdr_text);
+    free(f->path);
+    free(f);
+}
+
+char *b5_hdr_get(const b5_file_t *f, const char *name, uint32_t rg) {
+    const size_t nl = strlen(name);
+    const char *p = f->hdr_text;
+    while (p && *p) {
+        const char *eol = strchr(p, '\n');
+        const size_t len = eol ? (size_t)(eol - p) : strlen(p);
+        if (len > nl + 1 && p[0] == '@' && strncmp(p + 1, name, nl) == 0 && p[1 + nl] == '\t') {
+            const char *v = p + 2 + nl, *end = p + len;
+            for (uint32_t g = 0; g < rg; g++) {
+                const char *t = memchr(v, '\t', (size_t)(end - v));
+                if (!t) return NULL;
+                v = t + 1;
+            }
+            const char *t = memchr(v, '\t', (size_t)(end - v));
+            const size_t vl = t ? (size_t)(t - v) : (size_t)(end - v);
+            char *out = (char *)malloc(vl + 1);
+            if (!out) return NULL;
+            memcpy(out, v, vl);
+            out[vl] = '\0';
+            return out;
+        }
+        p = eol ? eol + 1 : NULL;
+    }
+    return NULL;
+}
+
+/* streamvbyte (scalar) + zigzag-delta, slow5lib/src/slow5_press.c:1116-1146: u32 count, 2-bit
+ * length codes (four per key byte, LSB first), then the little-endian data bytes */
+static int svb_zd_decode(const uint8_t *blob, uint64_t nbytes, b5_rec_t *rec) {
+    if (nbytes < 4) return B5_ERR_PRESS;
+    uint32_t count;
+    memcpy(&count, blob, 4);
+    const uint64_t nkeys = ((uint64_t)count + 3) / 4;
+    if (4 + nkeys > nbytes) return B5_ERR_PRESS;
+    if (rec->cap_signal < count) {
+        int16_t *q = (int16_t *)realloc(rec->raw_signal, sizeof(int16_t) * ((uint64_t)count + 1));
+        if (!q) return B5_ERR_MEM;
+        rec->raw_signal = q;
+        rec->cap_signal = count;
+    }
+    const uint8_t *keys = blob + 4, *data = keys + nkeys, *end = blob + nbytes;
+    int32_t prev = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const unsigned code = (keys[i >> 2] >> ((i & 3) * 2)) & 3u;
+        if (data + code + 1 > end) return B5_ERR_PRESS;
+        uint32_t v = 0;
+        memcpy(&v, data, code + 1);
+        data += code + 1;
+        const int32_t delta = (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+        prev += delta;
+        rec->raw_signal[i] = (int16_t)prev;
+    }
+    if (data != end) return B5_ERR_PRESS;
+    rec->len_raw_signal = count;
+    return 0;
+}
+
+static int parse_record(const b5_file_t *f, const uint8_t *p, uint64_t n, b5_rec_t *rec, int id_only) {
+    if (n < 2) return B5_ERR_FORMAT;
+    uint16_t idl;
+    memcpy(&idl, p, 2);
+    if (2 + (uint64_t)idl + 44 > n) return B5_ERR_FORMAT;
+    char *id = (char *)realloc(rec->read_id, (size_t)idl + 1);
+    if (!id) return B5_ERR_MEM;
+    memcpy(id, p + 2, idl);
+    id[idl] = '\0';
+    rec->read_id = id;
+    if (id_only) return 0;
+    const uint8_t *q = p + 2 + idl;
+    memcpy(&rec->read_group, q, 4);
+    memcpy(&rec->digitisation, q + 4, 8);
+    memcpy(&rec->offset, q + 12, 8);
+    memcpy(&rec->range, q + 20, 8);
+    memcpy(&rec->sampling_rate, q + 28, 8);
+    uint64_t ln;
+    memcpy(&ln, q + 36, 8);
+    q += 44;
+    const uint64_t left = n - (uint64_t)(q - p);
+    if (f->signal_press == 1) {
+        if (ln > left) return B5_ERR_FORMAT;
+        return svb_zd_decode(q, ln, rec);
+    }
+    if (ln * 2 > left) return B5_ERR_FORMAT;
+    if (rec->cap_signal < ln) {
+        int16_t *s = (int16_t *)realloc(rec->raw_signal, sizeof(int16_t) * (ln + 1));
+        if (!s) return B5_ERR_MEM;
+        rec->raw_signal = s;
+        rec->cap_signal = ln;
+    }
+    memcpy(rec->raw_signal, q, ln * 2);
+    rec->len_raw_signal = ln;
+    return 0;
+}
+
+/* reads the record at the current file position; id_only skips signal decoding when possible */
+static int read_record(b5_file_t *f, b5_rec_t *rec, int id_only) {
+    uint8_t szb[8];
+    const size_t got = fread(szb, 1, 8, f->fp);
+    if (got >= 5 && memcmp(szb, B5_EOF_MARK, 5) == 0) {
+        /* proper end only if nothing follows the marker */
+        if (got == 5) return B5_EOF;
+        return B5_ERR_FORMAT;
+    }
+    if (got != 8) return B5_ERR_IO;
+    uint64_t size;
+    memcpy(&size, szb, 8);
+    if (size == 0 || size > (1ull << 36)) return B5_ERR_FORMAT;
+    int rc = grow(&rec->buf, &rec->cap_buf, size);
+    if (rc) return rc;
+    if (fread(rec->buf, 1, size, f->fp) != size) return B5_ERR_IO;
+    const uint8_t *p = rec->buf;
+    uint64_t n = size;
+    if (f->record_press == 1) {
+        uLongf cap = rec->cap_zbuf ? rec->cap_zbuf : (size * 4 + 4096);
+        for (;;) {
+            rc = grow(&rec->zbuf, &rec->cap_zbuf, cap);
+            if (rc) return rc;
+            uLongf out = rec->cap_zbuf;
+            const int z = uncompress(rec->zbuf, &out, rec->buf, size);
+            if (z == Z_OK) { n = out; break; }
+            if (z != Z_BUF_ERROR) return B5_ERR_PRESS;
+            cap = rec->cap_zbuf * 2;
+        }
+        p = rec->zbuf;
+    }
+    return parse_record(f, p, n, rec, id_only);
+}
+
+int b5_next(b5_file_t *f, b5_rec_t *rec) { return read_record(f, rec, 0); }
+
+static int idx_cmp(const void *a, const void *b) {
+    return strcmp(((const b5_idx_entry_t *)a)->id, ((const b5_idx_entry_t *)b)->id);
+}
+
+int b5_index(b5_file_t *f) {
+    if (f->idx) return 0;
+    const long keep = ftell(f->fp);
+    if (fseek(f->fp, (long)f->first_rec, SEEK_SET) != 0) return B5_ERR_IO;
+    b5_rec_t tmp;
+    memset(&tmp, 0, sizeof tmp);
+    uint64_t cap = 1024, n = 0;
+    b5_idx_entry_t *idx = (b5_idx_entry_t *)malloc(cap * sizeof *idx);
+    if (!idx) return B5_ERR_MEM;
+    int rc;
+    for (;;) {
+        const uint64_t pos = (uint64_t)ftell(f->fp);
+        rc = read_record(f, &tmp, 1);
+        if (rc == B5_EOF) { rc = 0; break; }
+        if (rc) break;
+        if (n == cap) {
+            cap *= 2;
+            b5_idx_entry_t *q = (b5_idx_entry_t *)realloc(idx, cap * sizeof *idx);
+            if (!q) { rc = B5_ERR_MEM; break; }
+            idx = q;
+        }
+        idx[n].id = strdup(tmp.read_id);
+        idx[n].offset = pos;
+        n++;
+    }
+    b5_rec_free(&tmp);
+    if (rc) {
+        for (uint64_t i = 0; i < n; i++) free(idx[i].id);
+        free(idx);
+        return rc;
+    }
+    qsort(idx, n, sizeof *idx, idx_cmp);
+    f->idx = idx;
+    f->n_idx = n;
+    fseek(f->fp, keep, SEEK_SET);
+    return 0;
+}
+
+int b5_get(b5_file_t *f, const char *read_id, b5_rec_t *rec) {
+    if (!f->idx) {
+        const int rc = b5_index(f);
+        if (rc) return rc;
+    }
+    b5_idx_entry_t key;
+    key.id = (char *)read_id;
+    key.offset = 0;
+    const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
+    if (!e) return B5_ERR_NOTFOUND;
+    if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
+    return read_record(f, rec, 0);
+}
+
+void b5_rec_free(b5_rec_t *rec) {
+    free(rec->read_id);
+    free(rec->raw_signal);
+    free(rec->buf);
+    free(rec->zbuf);
+    memset(rec, 0, sizeof *rec);
+}

@@ -1,0 +1,63 @@
+/* blow5.h -- minimal BLOW5 reader of the sigtk-amd host CLI.
+ *
+ * Written from the on-disk layout; the reference reads the same files
+ * through slow5lib (slow5_open / slow5_get_next / slow5_get, slow5lib/include/slow5/slow5.h:345-454).
+ * Supports record compression none/zlib and signal compression none/svb-zd; zstd files are
+ * rejected (the reference build here has no zstd either).  Auxiliary fields are skipped. */
+#ifndef SGK_BLOW5_H
+#define SGK_BLOW5_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+typedef struct {
+    char *read_id;
+    uint32_t read_group;
+    double digitisation, offset, range, sampling_rate;
+    uint64_t len_raw_signal;
+    int16_t *raw_signal; /* capacity grows; reused across b5_next calls like slow5_rec_t */
+    uint64_t cap_signal;
+    uint8_t *buf;        /* scratch for the (de)compressed record */
+    uint64_t cap_buf;
+    uint8_t *zbuf;
+    uint64_t cap_zbuf;
+} b5_rec_t;
+
+typedef struct {
+    char *id;
+    uint64_t offset; /* file offset of the u64 record size */
+} b5_idx_entry_t;
+
+typedef struct {
+    FILE *fp;
+    char *path;
+    uint8_t version[3];
+    uint8_t record_press; /* 0 none, 1 zlib */
+    uint8_t signal_press; /* 0 none, 1 svb-zd */
+    uint32_t num_read_groups;
+    char *hdr_text;       /* header text block */
+    uint64_t first_rec;   /* file offset of the first record */
+    b5_idx_entry_t *idx;  /* built lazily by b5_index (sorted by id) */
+    uint64_t n_idx;
+} b5_file_t;
+
+#define B5_EOF (-1)
+#define B5_ERR_IO (-2)
+#define B5_ERR_FORMAT (-3)
+#define B5_ERR_PRESS (-4)
+#define B5_ERR_MEM (-5)
+#define B5_ERR_NOTFOUND (-6)
+
+b5_file_t *b5_open(const char *path);
+void b5_close(b5_file_t *f);
+/* value of header attribute `name` for read group `rg`, or NULL (malloc'd; caller frees) */
+char *b5_hdr_get(const b5_file_t *f, const char *name, uint32_t rg);
+/* next record in file order: 0 ok, B5_EOF at the proper end, other negatives on error */
+int b5_next(b5_file_t *f, b5_rec_t *rec);
+/* build the in-memory read-id index (one sequential scan of the record sizes + ids) */
+int b5_index(b5_file_t *f);
+/* random access by read id (needs b5_index) */
+int b5_get(b5_file_t *f, const char *read_id, b5_rec_t *rec);
+void b5_rec_free(b5_rec_t *rec);
+
+#endif

@@ -1,0 +1,93 @@
+"""CPU: the sigtk-amd host CLI -- argument surface, the C BLOW5 reader, and the no-GPU error."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from sigtk_amd import api, blow5, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    path = build.CLI
+    if not os.path.exists(path):
+        build.build_lib()
+        path = build.build_cli()
+    return path
+
+
+def run(cli, *args):
+    return subprocess.run([cli, *args], capture_output=True, text=True)
+
+
+def fnv(raw):
+    h = 1469598103934665603
+    for v in raw.astype(np.uint16).tolist():
+        h ^= v
+        h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_version_and_usage(cli):
+    p = run(cli, "--version")
+    assert p.returncode == 0 and p.stdout == "sigtk 0.2.0\n"          # src/main.c:101-104
+    p = run(cli, "event", "--version")
+    assert p.returncode == 0 and p.stdout == "sigtk 0.2.0\n"          # src/cmain.c:54-56
+    p = run(cli)
+    assert p.returncode == 1 and p.stderr.startswith("Usage: sigtk <command> [options]")
+    p = run(cli, "--help")
+    assert p.returncode == 0 and p.stdout.startswith("Usage: sigtk <command> [options]")
+    p = run(cli, "event")
+    assert p.returncode == 1 and "Usage: sigtk event reads.blow5" in p.stderr
+    p = run(cli, "stat", "-h")
+    assert p.returncode == 0 and "Usage: sigtk stat reads.blow5" in p.stdout
+    p = run(cli, "frobnicate")
+    assert p.returncode == 1 and "Unrecognised command frobnicate" in p.stderr
+    p = run(cli, "event", "/nonexistent.blow5")
+    assert p.returncode == 1 and "cannot open /nonexistent.blow5" in p.stderr
+
+
+def _check_dump(cli, path, reads):
+    p = run(cli, "_dump", path)
+    assert p.returncode == 0, p.stderr
+    rows = [ln.split("\t") for ln in p.stdout.strip().split("\n")[1:]]
+    assert len(rows) == len(reads)
+    for row, r in zip(rows, reads):
+        assert row[0] == r.read_id and int(row[1]) == r.raw.size
+        assert float(row[2]) == r.digitisation and float(row[3]) == r.offset and float(row[4]) == r.range
+        assert int(row[5], 16) == fnv(r.raw)
+
+
+def test_c_reader_matches_python_reader(cli, sp1):
+    _check_dump(cli, os.path.join(GOLDEN, "sp1_dna.blow5"), sp1.reads)
+
+
+@pytest.mark.parametrize("rp,sp", [(0, 0), (1, 1), (1, 0), (0, 1)])
+def test_c_reader_compression_variants(cli, tmp_path, rp, sp):
+    reads, dig, off, rng = api.synth_reads_host(5, [0, 1, 777, 4096, 30000], 5, 0)
+    rs = np.random.RandomState(2)
+    reads[3] = rs.randint(-32768, 32767, size=4096).astype(np.int16)  # 3-byte svb codes
+    recs = [blow5.Read("r%d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
+            for i in range(5)]
+    path = str(tmp_path / "x.blow5")
+    blow5.write_blow5(path, recs, {"experiment_type": "rna", "sequencing_kit": "sqk-rna004"}, rp, sp)
+    _check_dump(cli, path, recs)
+
+
+def test_truncated_file_is_an_error(cli, tmp_path):
+    data = open(os.path.join(GOLDEN, "sp1_dna.blow5"), "rb").read()
+    path = str(tmp_path / "trunc.blow5")
+    open(path, "wb").write(data[:len(data) // 2])
+    assert run(cli, "_dump", path).returncode == 1
+
+
+def test_no_gpu_is_a_loud_error(cli):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = run(cli, "event", "-c", os.path.join(GOLDEN, "sp1_dna.blow5"))
+    assert p.returncode == 1 and "no usable GPU" in p.stderr
+    assert "DNA data detected" in p.stderr and "R9 data detected" in p.stderr

@@ -1,0 +1,99 @@
+"""GPU: the sigtk-amd CLI reproduces the real reference's stdout byte for byte
+(goldens from tests/golden/make_golden.py, which ran the reference built from source)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from sigtk_amd import api, blow5, build
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+SP1 = os.path.join(GOLDEN, "sp1_dna.blow5")
+
+
+@pytest.fixture(scope="module")
+def cli(gpu):
+    assert os.path.exists(build.CLI), "sigtk-amd not built (run __graft_entry__.build())"
+    return build.CLI
+
+
+def out(cli, *args):
+    p = subprocess.run([cli, *args], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout
+
+
+def gold(name):
+    return open(os.path.join(GOLDEN, name), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def synth_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("synth")
+    files = {}
+    for name, spec in MANIFEST["_synth_specs"].items():
+        n, ln, seed, kind, exp, kit = spec
+        reads, dig, off, rng = api.synth_reads_host(n, ln, seed, kind)
+        recs = [blow5.Read("synth-%08d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
+                for i in range(n)]
+        path = str(d / (name + ".blow5"))
+        blow5.write_blow5(path, recs, {"experiment_type": exp, "sequencing_kit": kit})
+        files[name] = path
+    return files
+
+
+@pytest.mark.parametrize("fname,args", [
+    ("sp1_dna.event_c.tsv", ["event", "-c", SP1]),
+    ("sp1_dna.stat.tsv", ["stat", SP1]),
+    ("sp1_dna.jnn.tsv", ["jnn", SP1]),
+    ("sp1_dna.jnn_c.tsv", ["jnn", SP1, "-c"]),          # options may follow positionals (GNU getopt)
+    ("sp1_dna.prefix.tsv", ["prefix", SP1]),
+    ("sp1_dna.prefix_stat.tsv", ["prefix", "--print-stat", SP1]),
+    ("sp1_dna.pa3.tsv", ["pa", SP1, "00011a60-dd92-4aad-be1d-59a33545ab1d",
+                         "0448591b-036c-4cc7-a702-6c542ccc07de", "03880e3d-b79d-4bd8-aab4-15724f1331af"]),
+])
+def test_sp1_outputs(cli, fname, args):
+    assert out(cli, *args) == gold(fname)
+
+
+def test_sp1_event_long_form_hash(cli):
+    assert hashlib.sha256(out(cli, "event", SP1)).hexdigest() == MANIFEST["sp1_dna.event.tsv.sha256"]
+
+
+def test_reference_golden_event_dna_exp(cli):
+    """scripts/test.sh:71 -- event on one read id; event_dna.exp has a stale header line."""
+    got = out(cli, "event", SP1, "05d90f17-f4a6-4349-924c-3ffd3457a99d")
+    assert got.split(b"\n", 1)[1] == gold("event_dna.exp").split(b"\n", 1)[1]
+
+
+def test_reference_golden_prefix_dna_exp(cli):
+    assert out(cli, "prefix", SP1) == gold("prefix_dna.exp")          # scripts/test.sh:55
+
+
+def test_no_header_and_small_batches(cli):
+    full = out(cli, "event", "-c", SP1)
+    assert out(cli, "event", "-c", "-n", SP1) == full.split(b"\n", 1)[1]
+    # force many batches: rows must still come out in file order
+    assert out(cli, "event", "-c", "--batch-samples", "20000", SP1) == full
+    assert out(cli, "stat", "--batch-samples", "5000", SP1) == gold("sp1_dna.stat.tsv")
+
+
+def test_more_gpus_requested_than_present(cli):
+    p = subprocess.run([cli, "stat", "--gpus", "64", SP1], capture_output=True)
+    assert p.returncode == 0 and p.stdout == gold("sp1_dna.stat.tsv")
+
+
+@pytest.mark.parametrize("name", list(MANIFEST["_synth_specs"]))
+def test_synthetic_outputs(cli, synth_files, name):
+    f = synth_files[name]
+    assert out(cli, "event", "-c", f) == gold(name + ".event_c.tsv")
+    assert out(cli, "stat", f) == gold(name + ".stat.tsv")
+    assert out(cli, "jnn", f) == gold(name + ".jnn.tsv")
+    assert out(cli, "prefix", "--print-stat", f) == gold(name + ".prefix_stat.tsv")
+    assert hashlib.sha256(out(cli, "event", f)).hexdigest() == MANIFEST[name + ".event.tsv.sha256"]
