@@ -34,9 +34,12 @@
 // multiple of 2^g (g = lowest bit of the smallest non-zero |x|) and all partial sums are below
 // 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29  for x and for the
 // float squares; reads failing the check take the fallback kernel.
+#include <utility>
+
 #include "event_args.h"
 #include "row_stream.h"
 #include "sgk_common.h"
+#include "tstat_math.h"
 
 namespace sgk {
 
@@ -351,6 +354,383 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
     }
 }
 
+
+// ================================================================ fast detector pass
+// Same semantics as detect_pass<.., false>, restructured for issue rate:
+//  * window sums come from a register ring of W(p) = sum x[p..p+W1) (and of the float squares):
+//      A1 = W(i-W1), B1 = W(i), A2 = W(i-2W1)+W(i-W1), B2 = W(i)+W(i+W1)        (W2 == 2*W1)
+//    one new W per index: W(i+W1+1) = W(i+W1) + x[i+2W1] - x[i+W1]; the loop is unrolled by the
+//    ring length so every ring index is a compile-time constant (registers, no scratch);
+//  * only the leading sample x[i+2W1] is read from LDS per index (one row tile resident);
+//  * t-statistics use the exact constant-division / certified-rsqrt forms of tstat_math.h;
+//  * the automaton is written with selects (the reference's if/else ladder diverges on every lane);
+//  * all indices are 32-bit (a read has < 2^31 samples, src/misc.c:20).
+template <int W1>
+struct RingCfg {
+    static constexpr int R = (W1 == 3) ? 16 : 32;  // >= 3*W1+1, power of two, divides 64
+    static constexpr int XR = (W1 == 3) ? 4 : 8;   // >= W1+1, power of two
+};
+
+template <int W1>
+__device__ __forceinline__ int det_step_sel(DetState &d, int i, float v1, float v2) {
+    constexpr int W2 = 2 * W1;
+    constexpr float ph = DetParam<W1>::ph, thr1 = DetParam<W1>::thr1, thr2 = DetParam<W1>::thr2;
+    int emit = -1;
+    {   // short detector (masked_to == 0: only index 0 is skipped)
+        const bool on = i > 0;
+        const bool inpk = d.sp >= 0;
+        const bool lower = v1 < d.sv;
+        const bool rise = (v1 - d.sv) > ph;
+        const bool higher = v1 > d.sv;
+        const bool upd = on && (inpk ? higher : (lower || rise));
+        const bool pos = on && (inpk ? higher : (!lower && rise));
+        const float sv = upd ? v1 : d.sv;
+        const int sp = pos ? i : d.sp;
+        const bool c2 = on && inpk;
+        const bool strong = sv > thr1;
+        if (c2 && strong) {  // events.c:414-422
+            d.lmask = sp + W1;
+            d.lp = -1;
+            d.lv = FLT_MAX;
+            d.lvalid = 0;
+        }
+        const bool val = (d.svalid != 0) || (c2 && ((sv - v1) > ph) && strong);
+        const bool em = c2 && val && (i - sp) > W1 / 2;
+        emit = em ? sp : emit;
+        d.sp = em ? -1 : sp;
+        d.sv = em ? v1 : sv;
+        d.svalid = (val && !em) ? 1 : 0;
+    }
+    {   // long detector
+        const bool on = !(d.lmask >= i);
+        const bool inpk = d.lp >= 0;
+        const bool lower = v2 < d.lv;
+        const bool rise = (v2 - d.lv) > ph;
+        const bool higher = v2 > d.lv;
+        const bool upd = on && (inpk ? higher : (lower || rise));
+        const bool pos = on && (inpk ? higher : (!lower && rise));
+        const float lv = upd ? v2 : d.lv;
+        const int lp = pos ? i : d.lp;
+        const bool c2 = on && inpk;
+        const bool val = (d.lvalid != 0) || (c2 && ((lv - v2) > ph) && lv > thr2);
+        const bool em = c2 && val && (i - lp) > W2 / 2;
+        emit = em ? lp : emit;
+        d.lp = em ? -1 : lp;
+        d.lv = em ? v2 : lv;
+        d.lvalid = (val && !em) ? 1 : 0;
+    }
+    return emit;
+}
+
+// Exact (reference-expression) t-statistic at index i of a read, window sums formed directly from
+// the samples in global memory.  Out of line: only reached when a fast evaluation's certificate
+// fails (about 2^-13 of the evaluations).
+template <typename T>
+__device__ __attribute__((noinline)) float tstat_exact_at(const T *base, Scale sc, int i, int w) {
+    double A = 0.0, A2 = 0.0, B = 0.0, B2 = 0.0;
+    for (int k = 0; k < w; ++k) {
+        const float xa = to_pa(base[i - w + k], sc);
+        const float xb = to_pa(base[i + k], sc);
+        A = A + (double)xa;
+        A2 = A2 + (double)(xa * xa);
+        B = B + (double)xb;
+        B2 = B2 + (double)(xb * xb);
+    }
+    if (w == 3) return sgk_tstat_ref<3>(A, A2, B, B2);
+    if (w == 6) return sgk_tstat_ref<6>(A, A2, B, B2);
+    if (w == 7) return sgk_tstat_ref<7>(A, A2, B, B2);
+    return sgk_tstat_ref<14>(A, A2, B, B2);
+}
+
+// 16 consecutive samples starting at an even sample offset, as they sit in memory.
+template <typename T>
+struct Lead16;
+template <>
+struct Lead16<int16_t> {
+    uint32_t w[8];
+    template <int U>
+    __device__ __forceinline__ float get(const Scale &sc) const {
+        const int v = (U & 1) ? ((int)w[U / 2] >> 16) : (int)(short)(w[U / 2] & 0xffffu);
+        const float shifted = (float)v + sc.offf;
+        return shifted * sc.unit;
+    }
+};
+template <>
+struct Lead16<float> {
+    float w[16];
+    template <int U>
+    __device__ __forceinline__ float get(const Scale &) const { return w[U]; }
+};
+typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// State of one fast pass.  Every ring access uses a compile-time index (U is a template parameter
+// and the pass starts on a multiple of the ring length), so the arrays live in registers; the R
+// steps of one loop iteration are expanded with fold expressions, four at a time:
+// t-statistics of 4 indices -> (rare, rolled, out of line) exact redo of uncertified ones ->
+// both automata on those 4 indices.
+//
+// Samples are NOT staged through LDS here: each lane loads the 16 leading samples of the next
+// block (x[i+2*W1], 32 bytes) straight from global memory one block ahead.  A wave touches 64
+// different 128-byte lines per load instruction; each line is consumed over 4 consecutive blocks
+// and stays in L2 meanwhile, so HBM traffic remains one pass over the samples and there are no
+// barriers or cooperative loads in the loop.
+template <int W1, typename T>
+struct FastPass {
+    static constexpr int W2 = 2 * W1, R = RingCfg<W1>::R, XR = RingCfg<W1>::XR;
+    static constexpr int NL = R / 16;  // 16-sample lead groups per block
+    double Ws[R], Wq[R];
+    float xs[XR], xq[XR];
+    float t1[4], t2[4];
+    Lead16<T> cur[NL];  // x[ib + W2 .. ib + W2 + R)
+    DetState d;
+    unsigned long long wcur, wprev;
+    unsigned long long *bm;
+    const T *base;
+    int lo, hi;  // legal read-relative load range
+    Scale sc;
+    int n, s, e, ib, wb;
+    unsigned cnt1, cnt2;
+    unsigned bad1, bad2;
+    bool done, al;
+
+    __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
+        if (al && pos >= lo && pos + 16 <= hi) {
+            constexpr int NV = 16 * (int)sizeof(T) / 16;
+            const sgk_u32x4_a4 *src = reinterpret_cast<const sgk_u32x4_a4 *>(base + pos);
+            sgk_u32x4_a4 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = src[k];
+            __builtin_memcpy(dst.w, v, sizeof(dst.w));
+        } else {
+            T tmp[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tmp[k] = (pos + k >= lo && pos + k < hi) ? base[pos + k] : (T)0;
+            __builtin_memcpy(dst.w, tmp, sizeof(dst.w));
+        }
+    }
+
+    // phase 1: window sums and both t-statistics of index ib+U; advance the rings
+    template <int U>
+    __device__ __forceinline__ void tstep() {
+        const int i = ib + U;
+        const float xn = cur[U / 16].template get<U % 16>(sc);  // leading sample x[i + 2*W1]
+        const float xqn = xn * xn;
+        const double a1 = Ws[(U - W1) & (R - 1)], a1q = Wq[(U - W1) & (R - 1)];
+        const double b1 = Ws[U & (R - 1)], b1q = Wq[U & (R - 1)];
+        const double a2 = Ws[(U - W2) & (R - 1)] + a1, a2q = Wq[(U - W2) & (R - 1)] + a1q;
+        const double b2 = b1 + Ws[(U + W1) & (R - 1)], b2q = b1q + Wq[(U + W1) & (R - 1)];
+        bool ok1, ok2;
+        const float v1 = sgk_tstat_try<W1>(a1, a1q, b1, b1q, ok1);
+        const float v2 = sgk_tstat_try<W2>(a2, a2q, b2, b2q, ok2);
+        const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
+        t1[U & 3] = in1 ? v1 : 0.0f;
+        t2[U & 3] = in2 ? v2 : 0.0f;
+        bad1 |= (in1 && !ok1) ? (1u << (U & 3)) : 0u;
+        bad2 |= (in2 && !ok2) ? (1u << (U & 3)) : 0u;
+        Ws[(U + W1 + 1) & (R - 1)] = (Ws[(U + W1) & (R - 1)] + (double)xn) - (double)xs[(U + W1) & (XR - 1)];
+        Wq[(U + W1 + 1) & (R - 1)] = (Wq[(U + W1) & (R - 1)] + (double)xqn) - (double)xq[(U + W1) & (XR - 1)];
+        xs[(U + W2) & (XR - 1)] = xn;
+        xq[(U + W2) & (XR - 1)] = xqn;
+        // keep the evaluations from being interleaved: their live ranges would otherwise add up
+        // to far more than the register budget; latency is hidden across waves instead
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // phase 2: both automata at index ib+U
+    template <int U>
+    __device__ __forceinline__ void dstep() {
+        const int i = ib + U;
+        if (!done && (unsigned)i < (unsigned)n) {
+            const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
+            if (p >= s && p < e) {
+                const int wi = p >> 6;
+                const unsigned long long bit = 1ull << (p & 63);
+                if (wi == wb) wcur |= bit;
+                else if (wi == wb - 1) wprev |= bit;
+                else bm[wi] |= bit;  // older word: already retired, owned by this lane only
+            }
+        }
+    }
+    // four indices U0..U0+3
+    template <int U0>
+    __device__ __forceinline__ void quad() {
+        bad1 = 0u;
+        bad2 = 0u;
+        tstep<U0>();
+        tstep<U0 + 1>();
+        tstep<U0 + 2>();
+        tstep<U0 + 3>();
+        // rare: evaluations whose certificate failed are redone with the reference expression
+        while (__any((bad1 | bad2) != 0u)) {
+            if ((bad1 | bad2) != 0u) {
+                const bool first = bad1 != 0u;
+                const unsigned m = first ? bad1 : bad2;
+                const int u = __ffs((int)m) - 1;
+                const float v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == u) {
+                        if (first) t1[k] = v;
+                        else t2[k] = v;
+                    }
+                }
+                if (first) bad1 &= bad1 - 1u;
+                else bad2 &= bad2 - 1u;
+            }
+        }
+        dstep<U0>();
+        dstep<U0 + 1>();
+        dstep<U0 + 2>();
+        dstep<U0 + 3>();
+    }
+    template <int... Qs>
+    __device__ __forceinline__ void block(std::integer_sequence<int, Qs...>) {
+        (quad<4 * Qs>(), ...);
+    }
+
+    template <int K0>
+    __device__ __forceinline__ void init_w(double &a, double &aq, const float (&w)[4 * W1]) {
+        // W(p+1) from W(p), p = i_begin - 2*W1 + K0; w[k] = x[i_begin - 2*W1 + k]
+        const float xin = w[K0 + W1], xout = w[K0];
+        a = (a + (double)xin) - (double)xout;
+        aq = (aq + (double)(xin * xin)) - (double)(xout * xout);
+        Ws[(-W2 + K0 + 1) & (R - 1)] = a;
+        Wq[(-W2 + K0 + 1) & (R - 1)] = aq;
+    }
+    template <int... Ks>
+    __device__ __forceinline__ void init_ws(double &a, double &aq, const float (&w)[4 * W1],
+                                            std::integer_sequence<int, Ks...>) {
+        (init_w<Ks>(a, aq, w), ...);
+    }
+};
+
+template <int W1, typename T>
+__device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool active, int s, int e, int K,
+                                          const DetState &st0, DetState &at_s, DetState &at_e) {
+    using FP = FastPass<W1, T>;
+    constexpr int W2 = FP::W2, R = FP::R, XR = FP::XR, NL = FP::NL;
+    if (!__any(active)) return;
+    FP f;
+    f.n = (int)rc.n;
+    f.s = s;
+    f.e = e;
+    f.bm = rc.bm;
+    f.sc = rc.sc;
+    f.base = rc.base;
+    f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
+    f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
+    f.al = (reinterpret_cast<uintptr_t>(rc.base) & 3u) == 0;  // vector loads need 4-byte alignment
+    const int n = f.n;
+    const int i_begin = s - lead;  // multiple of 64
+    if (!active) { f.lo = 0; f.hi = 0; }  // idle lanes load nothing
+
+    // ring slots are addressed by (position - i_begin) & (R-1); i_begin is a multiple of R
+#pragma unroll
+    for (int k = 0; k < R; ++k) { f.Ws[k] = 0.0; f.Wq[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.t2[k] = 0.0f; }
+    {
+        // x[i_begin - 2*W1 .. i_begin + 2*W1): W(i_begin-2*W1), then slide to W(i_begin+W1); x ring
+        float w[4 * W1];
+#pragma unroll
+        for (int k = 0; k < 4 * W1; ++k) {
+            const int p = i_begin - W2 + k;
+            w[k] = (p >= f.lo && p < f.hi) ? to_pa(f.base[p], f.sc) : to_pa((T)0, f.sc);
+        }
+        double a = 0.0, aq = 0.0;
+#pragma unroll
+        for (int k = 0; k < W1; ++k) {
+            a = a + (double)w[k];
+            aq = aq + (double)(w[k] * w[k]);
+        }
+        f.Ws[(-W2) & (R - 1)] = a;
+        f.Wq[(-W2) & (R - 1)] = aq;
+        f.init_ws(a, aq, w, std::make_integer_sequence<int, 3 * W1>{});
+#pragma unroll
+        for (int k = 0; k < XR; ++k) { f.xs[k] = 0.0f; f.xq[k] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < W1; ++k) {  // x[i_begin + W1 + k]
+            f.xs[(W1 + k) & (XR - 1)] = w[W2 + W1 + k];
+            f.xq[(W1 + k) & (XR - 1)] = w[W2 + W1 + k] * w[W2 + W1 + k];
+        }
+    }
+    // leading samples of the first block
+#pragma unroll
+    for (int g = 0; g < NL; ++g) f.load_lead(f.cur[g], i_begin + W2 + 16 * g);
+
+    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : st0;
+    f.wcur = 0ull;
+    f.wprev = 0ull;
+    const int wlo = s >> 6, whi = (e + 63) >> 6;
+    f.done = !active;
+    const int main_steps = lead + K;
+    f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
+    f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
+
+    int jb = 0;
+    for (;; jb += R) {
+        if (jb >= main_steps && !__any(!f.done)) break;
+        const int ib = i_begin + jb;
+        const int wb = ib >> 6;  // bitmap word of every index of this block (R divides 64)
+        if ((jb & 63) == 0 && jb > 0 && active) {
+            const int wr = wb - 2;
+            if (wr >= wlo && wr < whi) f.bm[wr] = f.wprev;
+            f.wprev = f.wcur;
+            f.wcur = 0ull;
+        }
+        if (active) {
+            if (lead > 0 && jb == lead) at_s = det_norm(f.d, ib);
+            if (ib == e) at_e = det_norm(f.d, ib);
+            if (ib >= e) {
+                const bool pend = (f.d.sp >= 0 && f.d.sp < e) || (f.d.lp >= 0 && f.d.lp < e);
+                if (!pend || ib >= n) f.done = true;  // the reference's loop ends at n-1: pending peaks are dropped
+            }
+        }
+        f.ib = ib;
+        f.wb = wb;
+        // issue the loads of the NEXT block's leading samples now; consumed one iteration later
+        Lead16<T> nxt[NL];
+#pragma unroll
+        for (int g = 0; g < NL; ++g) f.load_lead(nxt[g], ib + R + W2 + 16 * g);
+        f.block(std::make_integer_sequence<int, R / 4>{});
+#pragma unroll
+        for (int g = 0; g < NL; ++g) f.cur[g] = nxt[g];
+    }
+    if (active) {
+        const int wbl = (i_begin + jb - 1) >> 6;  // word of the last processed index
+        if (wbl - 1 >= wlo && wbl - 1 < whi) f.bm[wbl - 1] = f.wprev;
+        if (wbl >= wlo && wbl < whi) f.bm[wbl] = f.wcur;
+    }
+}
+
+// speculative pass + verification / re-run loop (one inlined copy of pass_fast)
+template <int W1, typename T>
+__device__ void detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
+    const int n = (int)rc.n;
+    if (n <= 0) return;
+    const int K = (int)chunk_len(n);
+    const int c = lane_id();
+    const int s = c * K;
+    const int e = (s + K < n) ? s + K : n;
+    const bool active = (int64_t)c * K < (int64_t)n;
+    const DetState fresh = det_fresh(0);
+    DetState at_s = fresh, at_e = fresh, init = fresh, st0 = fresh;
+    int lead = LEAD;
+    bool run = active;
+    for (int iter = 0; iter < 66; ++iter) {
+        pass_fast<W1, T>(rc, lead, run, s, e, K, st0, at_s, at_e);
+        if (iter == 0) init = at_s;
+        const DetState pe = det_shfl_up(at_e);
+        const bool bad = active && c > 0 && !det_equal(pe, init);
+        const unsigned long long badmask = __ballot(bad);
+        if (badmask == 0ull) break;
+        if (bad) init = pe;
+        st0 = pe;
+        run = bad;
+        lead = 0;
+        if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
+    }
+}
+
 __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
     if (!(mx > 0.0f)) return true;  // all samples zero
     const int eb = ilogb((double)n * (double)mx), em = ilogb((double)mn);
@@ -388,10 +768,7 @@ __device__ bool detect_read(const ReadCtx<T> &rc, char *lds, EvHeader *hdr) {
         detect_pass<W1, T, PREFIX>(rc, lds, 0, bad, s, e, K, pe, unused, at_e, mn2, mx2);
         if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
     }
-    if (PREFIX) return false;
-    mn = wave_min_f(mn);
-    mx = wave_max_f(mx);
-    return !guard_ok(mn, mx, n);
+    return false;
 }
 
 // ---------------------------------------------------------------- event builder
@@ -427,7 +804,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     const int l = lane_id();
     const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
     if (n <= 0) {
-        if (l == 0) a.n_events[r] = 0;
+        if (l == 0) { a.n_events[r] = 0; a.flags[r] = 0; }
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
@@ -435,6 +812,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     uint32_t rank = 0, prevp = 0;
     double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary
     double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
+    float mn = FLT_MAX, mx = 0.0f;     // exactness guard: min non-zero |x| and max |x| over the read
     constexpr int NV = BT * (int)sizeof(T) / 16;
     for (int64_t tb = 0; tb < n; tb += 64 * BT) {
         const int64_t pos0 = tb + (int64_t)l * BT;
@@ -465,6 +843,9 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             float x = to_pa(buf[k], rc.sc);
             if (k >= nvalid) x = 0.0f;
             const float xq = x * x;
+            const float ax = fabsf(x);
+            mx = fmaxf(mx, ax);
+            mn = (ax != 0.0f) ? fminf(mn, ax) : mn;
             if ((bits >> k) & 1u) {
                 if (idx < BREC) {
                     L->p[idx] = (uint32_t)(pos0 + k);
@@ -512,12 +893,22 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         G20 = G20 + tileS2;
         __syncthreads();
     }
+    // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
+    mn = wave_min_f(mn);
+    mx = wave_max_f(mx);
+    const bool flagged = !guard_ok(mn, mx, n);
     if (l == 0) {
-        store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, G0 - Gprev, G20 - G2prev, overflow);
-        a.n_events[r] = rank + 1;
-        atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
+        a.flags[r] = flagged ? 1 : 0;
+        if (flagged) {
+            const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
+            a.flag_list[k] = r;
+        } else {
+            store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, G0 - Gprev, G20 - G2prev, overflow);
+            a.n_events[r] = rank + 1;
+            atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
+        }
     }
-    if (__any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
+    if (!flagged && __any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
 }
 
 // fallback builder: event sums are differences of the sequential prefix arrays, as in the reference
@@ -613,24 +1004,15 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[RowStream<T, 2>::LDS_BYTES];
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const bool flagged = detect_read<W1, T, false>(rc, lds, a.hdr);
-    if (lane_id() == 0) {
-        a.flags[r] = flagged ? 1 : 0;
-        if (flagged) {
-            const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
-            a.flag_list[k] = r;
-        }
-    }
+    detect_read_fast<W1, T>(rc, a.hdr);
 }
 
 template <typename T>
 __global__ __launch_bounds__(64) void k_event_build(EvArgs a) {
     __shared__ BuildLds L;
     const uint32_t r = blockIdx.x;
-    if (a.flags[r]) return;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
     build_read<T>(a, rc, r, &L);
 }

@@ -29,7 +29,7 @@ struct RowStream {
     int64_t rb;       // this lane's row: base-relative index of row sample 0
     bool base_al;     // base pointer 16-byte aligned
 
-    __device__ void load_tile(int tile, unsigned long long rowmask) {
+    __device__ __attribute__((noinline)) void load_tile(int tile, unsigned long long rowmask) {
         const int l = lane_id();
         const int v = l % VECS;
         __syncthreads();  // readers of the slot being replaced are done

@@ -1,0 +1,155 @@
+// tstat_math.h -- bit-exact fast forms of the arithmetic in compute_tstat (src/events.c:338-361).
+// Shared by the device kernels and by the host-side verification tool (oracle/verify_math.c), so the
+// exactness claims below are checked against plain IEEE division / sqrt on the CPU:
+//
+//  div3/6/7/14 in f64 and f32: correctly rounded division by a small constant in three FMA-class ops
+//      q = a*r; rem = fma(-q, d, a); q' = fma(rem, r, q)          (r = RN(1/d))
+//    (Markstein's correction step: rem is exact, q' = RN(a/d)).  f32 inputs below 2^-100 take a true
+//    division (the correction is not exact in the subnormal range).  Verified exhaustively for f32
+//    and on 4e9 random/structured inputs for f64 (oracle/verify_math.c).
+//
+//  tail(delta, cvw) = (float)( fabs((double)delta) / sqrt((double)cvw) ): the reference rounds the
+//    sqrt and the quotient to double and then the quotient to float.  Fast path: y = rsqrt(cvw)
+//    refined by one Newton step in f64 (relative error < 2^-40, certified at run time from the
+//    residual e = 1 - v*y0^2), q = |delta|*y.  The reference's double quotient is within 2^-39 of q,
+//    so unless q lies within 2^15 double-ulps of a float rounding midpoint, (float)q IS the reference
+//    result.  Otherwise (probability ~2^-13), or when the residual test fails or the result is
+//    outside the normal float range, the exact expression is evaluated.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SGK_TM __host__ __device__ inline
+#define SGK_TM_COLD __host__ __device__ __attribute__((noinline))
+#else
+#define SGK_TM static inline
+#define SGK_TM_COLD static __attribute__((noinline))
+#endif
+
+#ifndef SGK_RSQ64
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGK_RSQ64(v) __builtin_amdgcn_rsq(v)
+#else
+#define SGK_RSQ64(v) (1.0 / sqrt(v))
+#endif
+#endif
+
+SGK_TM uint64_t sgk_d2u(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    return u;
+}
+
+template <int W>
+SGK_TM double sgk_div_f64(double a) {
+    constexpr double d = (double)W;
+    constexpr double r = 1.0 / d;
+    const double q = a * r;
+    const double rem = fma(-q, d, a);
+    return fma(rem, r, q);
+}
+
+// a / (float)W for |a| >= 2^-100 (callers route smaller inputs, zero included, to the exact path)
+template <int W>
+SGK_TM float sgk_div_f32(float a) {
+    constexpr float d = (float)W;
+    constexpr float r = 1.0f / d;
+    const float q = a * r;
+    const float rem = fmaf(-q, d, a);
+    return fmaf(rem, r, q);
+}
+#define SGK_F32_TINY 7.8886090522101181e-31f /* 2^-100 */
+
+// Fast form of (float)( fabs((double)delta) / sqrt((double)cvw) ) plus its certificate.
+SGK_TM float sgk_tail_fast(float delta, float cvw, bool &ok) {
+    const double ad = fabs((double)delta);
+    const double v = (double)cvw;
+    const double y0 = SGK_RSQ64(v);
+    const double t = v * y0;
+    const double e = fma(-t, y0, 1.0);
+    const double y1 = fma(y0, 0.5 * e, y0);
+    const double q = ad * y1;
+    const uint32_t lo29 = (uint32_t)sgk_d2u(q) & 0x1FFFFFFFu;
+    const uint32_t dist = lo29 > 0x10000000u ? lo29 - 0x10000000u : 0x10000000u - lo29;
+    const bool cert = (fabs(e) < 9.5367431640625e-07) &   // 2^-20: y1 within 2^-40 of rsqrt(v)
+                      (dist > 0x8000u) &                  // q not near a float rounding midpoint
+                      (q > 7.5231638452626401e-37) &      // 2^-120: float result comfortably normal
+                      (q < 1.7014118346046923e+38);       // 2^127
+    // delta == 0 gives exactly 0 whenever the residual certificate holds (v is finite and positive)
+    ok = cert | ((ad == 0.0) & (fabs(e) < 9.5367431640625e-07));
+    return (float)q;
+}
+// standalone tail with its exact fallback (used by the verification tool)
+SGK_TM float sgk_tstat_tail(float delta, float cvw) {
+    bool ok;
+    const float tq = sgk_tail_fast(delta, cvw, ok);
+    if (ok) return tq;
+    __asm__ volatile("" ::: "memory");
+    return (float)(fabs((double)delta) / sqrt((double)cvw));
+}
+
+template <int W>
+SGK_TM_COLD float sgk_tstat_ref(double A, double A2, double B, double B2);
+
+// compute_tstat's expression tree for one index, given the four exact window sums: fast value and
+// its certificate.  ok == false means "evaluate the reference expression instead".
+template <int W>
+SGK_TM float sgk_tstat_try(double A, double A2, double B, double B2, bool &ok) {
+    const float sum2 = (float)B;
+    const float sumsq2 = (float)B2;
+    const float mean1 = (float)sgk_div_f64<W>(A);
+    const float mean2 = sgk_div_f32<W>(sum2);
+    const float m1sq = mean1 * mean1;
+    const float m2sq = mean2 * mean2;
+    const float q2 = sgk_div_f32<W>(sumsq2);
+    double acc = sgk_div_f64<W>(A2);
+    acc = acc - (double)m1sq;
+    acc = acc + (double)q2;
+    acc = acc - (double)m2sq;
+    float cv = (float)acc;
+    cv = fmaxf(cv, 1.17549435e-38f);  // FLT_MIN
+    const float delta = mean2 - mean1;
+    // the variance floor is by far the most common tiny input: its quotient is a constant
+    constexpr float floor_q = 1.17549435e-38f / (float)W;
+    const bool at_floor = cv == 1.17549435e-38f;
+    const float cvw = at_floor ? floor_q : sgk_div_f32<W>(cv);
+    bool tail_ok;
+    const float tq = sgk_tail_fast(delta, cvw, tail_ok);
+    // an exactly-zero dividend divides exactly (+0 in, +0 out); other tiny inputs take the exact path
+    ok = ((fabsf(sum2) >= SGK_F32_TINY) | (sum2 == 0.0f)) & ((sumsq2 >= SGK_F32_TINY) | (sumsq2 == 0.0f)) &
+         ((cv >= SGK_F32_TINY) | at_floor) & tail_ok;
+    return tq;
+}
+
+template <int W>
+SGK_TM float sgk_tstat_fast(double A, double A2, double B, double B2) {
+    bool ok;
+    const float tq = sgk_tstat_try<W>(A, A2, B, B2, ok);
+    if (ok) return tq;
+    __asm__ volatile("" ::: "memory");
+    return sgk_tstat_ref<W>(A, A2, B, B2);
+}
+
+// the reference expression, operator by operator (used as the exact slow path and as the yardstick)
+template <int W>
+SGK_TM_COLD float sgk_tstat_ref(double A, double A2, double B, double B2) {
+    const float wf = (float)W;
+    const float sum2 = (float)B;
+    const float sumsq2 = (float)B2;
+    const float mean1 = (float)(A / (double)wf);
+    const float mean2 = sum2 / wf;
+    const float m1sq = mean1 * mean1;
+    const float m2sq = mean2 * mean2;
+    const float q2 = sumsq2 / wf;
+    double acc = A2 / (double)wf;
+    acc = acc - (double)m1sq;
+    acc = acc + (double)q2;
+    acc = acc - (double)m2sq;
+    float cv = (float)acc;
+    cv = fmaxf(cv, 1.17549435e-38f);
+    const float delta = mean2 - mean1;
+    const float cvw = cv / wf;
+    return (float)(fabs((double)delta) / sqrt((double)cvw));
+}
