@@ -36,7 +36,10 @@
  *            increasing, non-overlapping order; gaps between reads are allowed (and ignored),
  *            which lets a packer start every read on an aligned boundary.  Any offsets are
  *            accepted; reads starting on a multiple of 8 samples (16 bytes) take the
- *            vectorised load path (the host packer aligns to 64 samples = 128 bytes);
+ *            vectorised load paths (the host packer aligns to 64 samples = 128 bytes).  The
+ *            event fast path additionally wants >= 64 readable samples in front of a read and
+ *            >= 16 behind it (neighbouring reads or padding); reads without that room, or
+ *            starting on an odd sample, are processed by the slower exact fallback kernel;
  *   digitisation/offset/range  the three per-read doubles of slow5_rec_t
  *            (slow5lib/include/slow5/slow5_defs.h:84-92), narrowed to float on the device
  *            exactly as src/misc.c:17-19 does.

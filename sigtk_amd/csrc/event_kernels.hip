@@ -491,22 +491,21 @@ struct FastPass {
     int n, s, e, ib, wb;
     unsigned cnt1, cnt2;
     unsigned bad1, bad2;
-    bool done, al;
+    bool done;
 
+    // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are
+    // redirected to the nearest readable group: whatever finite value a position yields is used
+    // consistently when it enters and when it leaves a window, and no t-statistic whose window
+    // reaches outside [0, n) is ever used (events.c:332-338), so only memory safety matters.
     __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
-        if (al && pos >= lo && pos + 16 <= hi) {
-            constexpr int NV = 16 * (int)sizeof(T) / 16;
-            const sgk_u32x4_a4 *src = reinterpret_cast<const sgk_u32x4_a4 *>(base + pos);
-            sgk_u32x4_a4 v[NV];
+        int p = pos > hi - 16 ? hi - 16 : pos;
+        p = p < lo ? lo : p;
+        constexpr int NV = 16 * (int)sizeof(T) / 16;
+        const sgk_u32x4_a4 *src = reinterpret_cast<const sgk_u32x4_a4 *>(base + p);
+        sgk_u32x4_a4 v[NV];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] = src[k];
-            __builtin_memcpy(dst.w, v, sizeof(dst.w));
-        } else {
-            T tmp[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tmp[k] = (pos + k >= lo && pos + k < hi) ? base[pos + k] : (T)0;
-            __builtin_memcpy(dst.w, tmp, sizeof(dst.w));
-        }
+        for (int k = 0; k < NV; ++k) v[k] = src[k];
+        __builtin_memcpy(dst.w, v, sizeof(dst.w));
     }
 
     // phase 1: window sums and both t-statistics of index ib+U; advance the rings
@@ -521,6 +520,7 @@ struct FastPass {
         const double b2 = b1 + Ws[(U + W1) & (R - 1)], b2q = b1q + Wq[(U + W1) & (R - 1)];
         bool ok1, ok2;
         const float v1 = sgk_tstat_try<W1>(a1, a1q, b1, b1q, ok1);
+        __builtin_amdgcn_sched_barrier(0);
         const float v2 = sgk_tstat_try<W2>(a2, a2q, b2, b2q, ok2);
         const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
         t1[U & 3] = in1 ? v1 : 0.0f;
@@ -618,10 +618,8 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
     f.base = rc.base;
     f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
     f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
-    f.al = (reinterpret_cast<uintptr_t>(rc.base) & 3u) == 0;  // vector loads need 4-byte alignment
     const int n = f.n;
     const int i_begin = s - lead;  // multiple of 64
-    if (!active) { f.lo = 0; f.hi = 0; }  // idle lanes load nothing
 
     // ring slots are addressed by (position - i_begin) & (R-1); i_begin is a multiple of R
 #pragma unroll
@@ -633,8 +631,10 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
         float w[4 * W1];
 #pragma unroll
         for (int k = 0; k < 4 * W1; ++k) {
-            const int p = i_begin - W2 + k;
-            w[k] = (p >= f.lo && p < f.hi) ? to_pa(f.base[p], f.sc) : to_pa((T)0, f.sc);
+            int p = i_begin - W2 + k;
+            p = p > f.hi - 1 ? f.hi - 1 : p;
+            p = p < f.lo ? f.lo : p;
+            w[k] = to_pa(f.base[p], f.sc);
         }
         double a = 0.0, aq = 0.0;
 #pragma unroll
@@ -704,9 +704,13 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
 
 // speculative pass + verification / re-run loop (one inlined copy of pass_fast)
 template <int W1, typename T>
-__device__ void detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
+__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
     const int n = (int)rc.n;
-    if (n <= 0) return;
+    if (n <= 0) return true;
+    // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 64 readable samples
+    // before the read (speculative warm-up of chunk 0) and 16 after it; other reads (e.g. a read at
+    // the very start of a caller's buffer) take the exact fallback
+    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -64 || rc.hi < (int64_t)n + 16) return false;
     const int K = (int)chunk_len(n);
     const int c = lane_id();
     const int s = c * K;
@@ -729,6 +733,7 @@ __device__ void detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
         lead = 0;
         if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
     }
+    return true;
 }
 
 __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
@@ -896,7 +901,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
     mn = wave_min_f(mn);
     mx = wave_max_f(mx);
-    const bool flagged = !guard_ok(mn, mx, n);
+    const bool flagged = !guard_ok(mn, mx, n) || a.flags[r] == 2;
     if (l == 0) {
         a.flags[r] = flagged ? 1 : 0;
         if (flagged) {
@@ -1006,7 +1011,8 @@ template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    detect_read_fast<W1, T>(rc, a.hdr);
+    const bool ok = detect_read_fast<W1, T>(rc, a.hdr);
+    if (lane_id() == 0) a.flags[r] = ok ? 0 : 2;  // 2: declined by the fast pass -> exact fallback
 }
 
 template <typename T>

@@ -44,7 +44,7 @@ struct DeviceBatch {
         if (sgk_device_count() <= 0) return SGK_ERR_NODEVICE;
         offsets.resize(nr);
         lengths.resize(nr);
-        uint64_t o = 0;
+        uint64_t o = 64;  // head room: the event fast path wants 64 readable samples before a read
         for (size_t r = 0; r < nr; ++r) {
             const uint64_t n = hb->offsets[r + 1] - hb->offsets[r];
             if (n > 0x7fffffffull) return SGK_ERR_ARG;  // nsample is int32 in the reference (misc.c:20)
@@ -53,7 +53,7 @@ struct DeviceBatch {
             if (n > max_len) max_len = (uint32_t)n;
             o += round_up(n, 64);
         }
-        n_samples = o ? o : 64;
+        n_samples = o + 64;  // tail room (>= 16 samples after the last read)
         std::vector<int16_t> packed((size_t)n_samples, 0);
         for (size_t r = 0; r < nr; ++r)
             if (lengths[r])

@@ -51,11 +51,11 @@ def alloc_reads(lengths: np.ndarray, device: torch.device, align: int = 64) -> D
     lengths = np.asarray(lengths, dtype=np.int64)
     n = lengths.size
     padded = (lengths + align - 1) // align * align
-    offsets = np.zeros(n, dtype=np.int64)
+    # 64 samples of head room and tail room: the event fast path reads a little outside each read
+    offsets = np.full(n, 64, dtype=np.int64)
     if n > 1:
-        np.cumsum(padded[:-1], out=offsets[1:])
-    n_samples = int(padded.sum()) if n else 0
-    n_samples = max((n_samples + 63) // 64 * 64, 64)
+        offsets[1:] += np.cumsum(padded[:-1])
+    n_samples = (int(padded.sum()) if n else 0) + 128
     return DeviceReads(
         samples=torch.zeros(n_samples, dtype=torch.int16, device=device),
         offsets=torch.from_numpy(offsets).to(device),
