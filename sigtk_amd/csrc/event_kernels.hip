@@ -112,6 +112,13 @@ __device__ inline DetState det_shfl_up(const DetState &a) {
     return r;
 }
 
+// per-lane state snapshots of one read's chunks, kept in LDS
+struct DetSnap {
+    DetState init[64];  // state a chunk's accepted run started from (at its chunk start)
+    DetState at_e[64];  // state at the chunk end
+    DetState st0[64];   // start state handed to a re-run
+};
+
 template <int W1>
 struct DetParam;
 template <>
@@ -605,7 +612,7 @@ struct FastPass {
 
 template <int W1, typename T>
 __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool active, int s, int e, int K,
-                                          const DetState &st0, DetState &at_s, DetState &at_e) {
+                                          DetSnap *snap) {
     using FP = FastPass<W1, T>;
     constexpr int W2 = FP::W2, R = FP::R, XR = FP::XR, NL = FP::NL;
     if (!__any(active)) return;
@@ -657,7 +664,7 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
 #pragma unroll
     for (int g = 0; g < NL; ++g) f.load_lead(f.cur[g], i_begin + W2 + 16 * g);
 
-    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : st0;
+    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : snap->st0[lane_id()];
     f.wcur = 0ull;
     f.wprev = 0ull;
     const int wlo = s >> 6, whi = (e + 63) >> 6;
@@ -678,8 +685,9 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
             f.wcur = 0ull;
         }
         if (active) {
-            if (lead > 0 && jb == lead) at_s = det_norm(f.d, ib);
-            if (ib == e) at_e = det_norm(f.d, ib);
+            // state snapshots live in LDS (they are only needed after the pass): frees ~28 VGPRs
+            if (lead > 0 && jb == lead) snap->init[lane_id()] = det_norm(f.d, ib);
+            if (ib == e) snap->at_e[lane_id()] = det_norm(f.d, ib);
             if (ib >= e) {
                 const bool pend = (f.d.sp >= 0 && f.d.sp < e) || (f.d.lp >= 0 && f.d.lp < e);
                 if (!pend || ib >= n) f.done = true;  // the reference's loop ends at n-1: pending peaks are dropped
@@ -704,7 +712,7 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
 
 // speculative pass + verification / re-run loop (one inlined copy of pass_fast)
 template <int W1, typename T>
-__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
+__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap) {
     const int n = (int)rc.n;
     if (n <= 0) return true;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 64 readable samples
@@ -716,22 +724,28 @@ __device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr) {
     const int s = c * K;
     const int e = (s + K < n) ? s + K : n;
     const bool active = (int64_t)c * K < (int64_t)n;
-    const DetState fresh = det_fresh(0);
-    DetState at_s = fresh, at_e = fresh, init = fresh, st0 = fresh;
+    snap->init[c] = det_fresh(0);
+    snap->at_e[c] = det_fresh(0);
     int lead = LEAD;
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
-        pass_fast<W1, T>(rc, lead, run, s, e, K, st0, at_s, at_e);
-        if (iter == 0) init = at_s;
-        const DetState pe = det_shfl_up(at_e);
-        const bool bad = active && c > 0 && !det_equal(pe, init);
+        pass_fast<W1, T>(rc, lead, run, s, e, K, snap);
+        __syncthreads();
+        // chunk c is right iff it started (at s) from the state chunk c-1 ended with
+        const DetState pe = snap->at_e[c > 0 ? c - 1 : 0];
+        const DetState mine = snap->init[c];
+        const bool bad = active && c > 0 && !det_equal(pe, mine);
         const unsigned long long badmask = __ballot(bad);
         if (badmask == 0ull) break;
-        if (bad) init = pe;
-        st0 = pe;
+        __syncthreads();
+        if (bad) {
+            snap->init[c] = pe;
+            snap->st0[c] = pe;
+        }
         run = bad;
         lead = 0;
         if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
+        __syncthreads();
     }
     return true;
 }
@@ -1009,9 +1023,10 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
+    __shared__ DetSnap snap;
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const bool ok = detect_read_fast<W1, T>(rc, a.hdr);
+    const bool ok = detect_read_fast<W1, T>(rc, a.hdr, &snap);
     if (lane_id() == 0) a.flags[r] = ok ? 0 : 2;  // 2: declined by the fast pass -> exact fallback
 }
 
