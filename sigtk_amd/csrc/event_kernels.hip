@@ -527,7 +527,6 @@ struct FastPass {
         const double b2 = b1 + Ws[(U + W1) & (R - 1)], b2q = b1q + Wq[(U + W1) & (R - 1)];
         bool ok1, ok2;
         const float v1 = sgk_tstat_try<W1>(a1, a1q, b1, b1q, ok1);
-        __builtin_amdgcn_sched_barrier(0);
         const float v2 = sgk_tstat_try<W2>(a2, a2q, b2, b2q, ok2);
         const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
         t1[U & 3] = in1 ? v1 : 0.0f;
