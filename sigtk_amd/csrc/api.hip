@@ -385,15 +385,15 @@ sgk_event_table sgk_getevents(size_t nsample, float *rawptr, int8_t rna) {
     memset(&et, 0, sizeof et);
     if (!rawptr || nsample == 0 || nsample > 0x7fffffffull || sgk_device_count() <= 0) return et;
     DeviceBatch db;  // only offsets/lengths bookkeeping is used here
-    db.offsets.assign(1, 64);  // head/tail room for the event fast path
+    db.offsets.assign(1, 256);  // head/tail room for the event fast path
     db.lengths.assign(1, (uint32_t)nsample);
     db.max_len = (uint32_t)nsample;
-    db.n_samples = round_up(nsample, 64) + 128;
+    db.n_samples = round_up(nsample, 64) + 320;
     DevBuf d_pa, d_o, d_l;
     if (d_pa.alloc((size_t)db.n_samples * sizeof(float)) != SGK_OK) return et;
     if (d_o.alloc(8) != SGK_OK || d_l.alloc(4) != SGK_OK) return et;
     if (hipMemset(d_pa.p, 0, (size_t)db.n_samples * sizeof(float)) != hipSuccess) return et;
-    if (hipMemcpy(d_pa.as<float>() + 64, rawptr, nsample * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(d_pa.as<float>() + 256, rawptr, nsample * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return et;
     if (hipMemcpy(d_o.p, db.offsets.data(), 8, hipMemcpyHostToDevice) != hipSuccess) return et;
     if (hipMemcpy(d_l.p, db.lengths.data(), 4, hipMemcpyHostToDevice) != hipSuccess) return et;

@@ -43,6 +43,14 @@
 
 namespace sgk {
 
+#ifndef SGK_LDS_HISTORY_DNA
+#define SGK_LDS_HISTORY_DNA 0
+#endif
+// which fast-pass variant a preset uses: register ring (DNA, W1 = 3) or LDS history (RNA, W1 = 7)
+#define USE_LDS_HISTORY(W1) ((W1) == 7 || SGK_LDS_HISTORY_DNA)
+#ifndef SGK_LEAD_RNA
+#define SGK_LEAD_RNA 256
+#endif
 constexpr int LEAD = 64;   // speculative warm-up (samples); multiple of 64
 constexpr int BACK = 32;   // row margin before the pass start (>= W2 + 1)
 
@@ -709,15 +717,237 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
     }
 }
 
+// ---------------------------------------------------------------- fast pass, LDS-history variant
+// Same contract as pass_fast.  Instead of a register ring of partial window sums (which needs a
+// 3*W1+1 deep ring and an unroll by its length: too much for W1 = 7), it keeps the eight running
+// window sums and reads the four trailing samples x[i-2W1], x[i-W1], x[i], x[i+W1] from a per-lane
+// history ring in LDS (64 raw samples per lane; the leading 16-sample group of each block is
+// written into it once).  16-step unroll for every window size.
+template <typename T>
+struct HistRing {
+    static constexpr int ROW_BYTES = 64 * (int)sizeof(T) + 4;  // odd dword stride: conflict-free lane-per-row
+    static constexpr int LDS_BYTES = 64 * ROW_BYTES;
+};
+
+template <int W1, typename T>
+struct FastPassL {
+    static constexpr int W2 = 2 * W1;
+    double A1, A1q, B1, B1q, A2, A2q, B2, B2q;
+    float t1[4], t2[4];
+    Lead16<T> cur;
+    DetState d;
+    unsigned long long wcur, wprev;
+    unsigned long long *bm;
+    const T *base;
+    char *row;   // this lane's history row in LDS; ring index of position p is (p - W2) & 63
+    int lo, hi;
+    Scale sc;
+    int n, s, e, ib, wb;
+    unsigned cnt1, cnt2;
+    unsigned bad1, bad2;
+    bool done;
+
+    __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
+        int p = pos > hi - 16 ? hi - 16 : pos;
+        p = p < lo ? lo : p;
+        constexpr int NV = 16 * (int)sizeof(T) / 16;
+        const sgk_u32x4_a4 *src = reinterpret_cast<const sgk_u32x4_a4 *>(base + p);
+        sgk_u32x4_a4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = src[k];
+        __builtin_memcpy(dst.w, v, sizeof(dst.w));
+    }
+    __device__ __forceinline__ float hist(int pos) const {  // x[pos], pos within the resident window
+        const T v = *reinterpret_cast<const T *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
+        return to_pa(v, sc);
+    }
+    __device__ __forceinline__ void store_group(const Lead16<T> &g, int pos) {  // x[pos..pos+16), pos-W2 multiple of 16
+        uint32_t *dst = reinterpret_cast<uint32_t *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
+        constexpr int ND = 16 * (int)sizeof(T) / 4;
+        uint32_t tmp[ND];
+        __builtin_memcpy(tmp, g.w, sizeof(tmp));
+#pragma unroll
+        for (int k = 0; k < ND; ++k) dst[k] = tmp[k];
+    }
+
+    template <int U>
+    __device__ __forceinline__ void tstep() {
+        const int i = ib + U;
+        bool ok1, ok2;
+        const float v1 = sgk_tstat_try<W1>(A1, A1q, B1, B1q, ok1);
+        const float v2 = sgk_tstat_try<W2>(A2, A2q, B2, B2q, ok2);
+        const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
+        t1[U & 3] = in1 ? v1 : 0.0f;
+        t2[U & 3] = in2 ? v2 : 0.0f;
+        bad1 |= (in1 && !ok1) ? (1u << (U & 3)) : 0u;
+        bad2 |= (in2 && !ok2) ? (1u << (U & 3)) : 0u;
+        // slide the four windows from index i to i+1 (exact in double)
+        const float xp2 = cur.template get<U>(sc);  // x[i + 2*W1]
+        const float xm2 = hist(i - W2), xm1 = hist(i - W1), x0 = hist(i), xp1 = hist(i + W1);
+        const double d0 = (double)x0, d0q = (double)(x0 * x0);
+        A1 = (A1 + d0) - (double)xm1;  A1q = (A1q + d0q) - (double)(xm1 * xm1);
+        A2 = (A2 + d0) - (double)xm2;  A2q = (A2q + d0q) - (double)(xm2 * xm2);
+        B1 = (B1 + (double)xp1) - d0;  B1q = (B1q + (double)(xp1 * xp1)) - d0q;
+        B2 = (B2 + (double)xp2) - d0;  B2q = (B2q + (double)(xp2 * xp2)) - d0q;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int U>
+    __device__ __forceinline__ void dstep() {
+        const int i = ib + U;
+        if (!done && (unsigned)i < (unsigned)n) {
+            const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
+            if (p >= s && p < e) {
+                const int wi = p >> 6;
+                const unsigned long long bit = 1ull << (p & 63);
+                if (wi == wb) wcur |= bit;
+                else if (wi == wb - 1) wprev |= bit;
+                else bm[wi] |= bit;
+            }
+        }
+    }
+    template <int U0>
+    __device__ __forceinline__ void quad() {
+        bad1 = 0u;
+        bad2 = 0u;
+        tstep<U0>();
+        tstep<U0 + 1>();
+        tstep<U0 + 2>();
+        tstep<U0 + 3>();
+        while (__any((bad1 | bad2) != 0u)) {
+            if ((bad1 | bad2) != 0u) {
+                const bool first = bad1 != 0u;
+                const unsigned m = first ? bad1 : bad2;
+                const int u = __ffs((int)m) - 1;
+                const float v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == u) {
+                        if (first) t1[k] = v;
+                        else t2[k] = v;
+                    }
+                }
+                if (first) bad1 &= bad1 - 1u;
+                else bad2 &= bad2 - 1u;
+            }
+        }
+        dstep<U0>();
+        dstep<U0 + 1>();
+        dstep<U0 + 2>();
+        dstep<U0 + 3>();
+    }
+};
+
+template <int W1, typename T>
+__device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_lds, int lead, bool active, int s,
+                                              int e, int K, DetSnap *snap) {
+    using FP = FastPassL<W1, T>;
+    constexpr int W2 = FP::W2, R = 16;
+    if (!__any(active)) return;
+    FP f;
+    f.n = (int)rc.n;
+    f.s = s;
+    f.e = e;
+    f.bm = rc.bm;
+    f.sc = rc.sc;
+    f.base = rc.base;
+    f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
+    f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
+    f.row = hist_lds + lane_id() * HistRing<T>::ROW_BYTES;
+    const int n = f.n;
+    const int i_begin = s - lead;  // multiple of 64
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.t2[k] = 0.0f; }
+    // history: x[i_begin - 2*W2 .. i_begin + W2) must be resident before the first block; fill the
+    // three 16-sample groups that cover it (ring indices (p - W2) & 63)
+#pragma unroll
+    for (int g = -3; g < 0; ++g) {
+        Lead16<T> tmp;
+        f.load_lead(tmp, i_begin + W2 + 16 * g);
+        f.store_group(tmp, i_begin + W2 + 16 * g);
+    }
+    f.load_lead(f.cur, i_begin + W2);
+    __syncthreads();
+    // window sums at i_begin by direct summation from the history ring
+    f.A1 = f.A1q = f.B1 = f.B1q = f.A2 = f.A2q = f.B2 = f.B2q = 0.0;
+#pragma unroll
+    for (int k = 1; k <= W2; ++k) {
+        const float x = f.hist(i_begin - k);
+        const float xq = x * x;
+        f.A2 = f.A2 + (double)x; f.A2q = f.A2q + (double)xq;
+        if (k <= W1) { f.A1 = f.A1 + (double)x; f.A1q = f.A1q + (double)xq; }
+    }
+    {
+        // B windows need x[i_begin .. i_begin+W2): not in the ring yet (that is the cur group's range
+        // shifted by W2), so take them from memory directly (clamped like every other load)
+#pragma unroll
+        for (int k = 0; k < W2; ++k) {
+            int p = i_begin + k;
+            p = p > f.hi - 1 ? f.hi - 1 : p;
+            p = p < f.lo ? f.lo : p;
+            const float x = to_pa(f.base[p], f.sc);
+            const float xq = x * x;
+            f.B2 = f.B2 + (double)x; f.B2q = f.B2q + (double)xq;
+            if (k < W1) { f.B1 = f.B1 + (double)x; f.B1q = f.B1q + (double)xq; }
+        }
+    }
+
+    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : snap->st0[lane_id()];
+    f.wcur = 0ull;
+    f.wprev = 0ull;
+    const int wlo = s >> 6, whi = (e + 63) >> 6;
+    f.done = !active;
+    const int main_steps = lead + K;
+    f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
+    f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
+
+    int jb = 0;
+    for (;; jb += R) {
+        if (jb >= main_steps && !__any(!f.done)) break;
+        const int ib = i_begin + jb;
+        const int wb = ib >> 6;
+        if ((jb & 63) == 0 && jb > 0 && active) {
+            const int wr = wb - 2;
+            if (wr >= wlo && wr < whi) f.bm[wr] = f.wprev;
+            f.wprev = f.wcur;
+            f.wcur = 0ull;
+        }
+        if (active) {
+            if (lead > 0 && jb == lead) snap->init[lane_id()] = det_norm(f.d, ib);
+            if (ib == e) snap->at_e[lane_id()] = det_norm(f.d, ib);
+            if (ib >= e) {
+                const bool pend = (f.d.sp >= 0 && f.d.sp < e) || (f.d.lp >= 0 && f.d.lp < e);
+                if (!pend || ib >= n) f.done = true;
+            }
+        }
+        f.ib = ib;
+        f.wb = wb;
+        // publish this block's leading group to the history ring (it becomes x[i+W1], x[i], ... later)
+        f.store_group(f.cur, ib + W2);
+        Lead16<T> nxt;
+        f.load_lead(nxt, ib + R + W2);
+        __syncthreads();
+        f.template quad<0>();
+        f.template quad<4>();
+        f.template quad<8>();
+        f.template quad<12>();
+        f.cur = nxt;
+    }
+    if (active) {
+        const int wbl = (i_begin + jb - 1) >> 6;
+        if (wbl - 1 >= wlo && wbl - 1 < whi) f.bm[wbl - 1] = f.wprev;
+        if (wbl >= wlo && wbl < whi) f.bm[wbl] = f.wcur;
+    }
+}
+
 // speculative pass + verification / re-run loop (one inlined copy of pass_fast)
 template <int W1, typename T>
-__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap) {
+__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap, char *hist_lds) {
     const int n = (int)rc.n;
     if (n <= 0) return true;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 64 readable samples
     // before the read (speculative warm-up of chunk 0) and 16 after it; other reads (e.g. a read at
     // the very start of a caller's buffer) take the exact fallback
-    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -64 || rc.hi < (int64_t)n + 16) return false;
+    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -((W1 == 7) ? SGK_LEAD_RNA : LEAD) || rc.hi < (int64_t)n + 16) return false;
     const int K = (int)chunk_len(n);
     const int c = lane_id();
     const int s = c * K;
@@ -725,10 +955,11 @@ __device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *s
     const bool active = (int64_t)c * K < (int64_t)n;
     snap->init[c] = det_fresh(0);
     snap->at_e[c] = det_fresh(0);
-    int lead = LEAD;
+    int lead = (W1 == 7) ? SGK_LEAD_RNA : LEAD;  // RNA events are ~5x longer: states converge later
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
-        pass_fast<W1, T>(rc, lead, run, s, e, K, snap);
+        if constexpr (USE_LDS_HISTORY(W1)) pass_fast_lds<W1, T>(rc, hist_lds, lead, run, s, e, K, snap);
+        else pass_fast<W1, T>(rc, lead, run, s, e, K, snap);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
         const DetState pe = snap->at_e[c > 0 ? c - 1 : 0];
@@ -1023,9 +1254,10 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
     __shared__ DetSnap snap;
+    __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const bool ok = detect_read_fast<W1, T>(rc, a.hdr, &snap);
+    const bool ok = detect_read_fast<W1, T>(rc, a.hdr, &snap, hist);
     if (lane_id() == 0) a.flags[r] = ok ? 0 : 2;  // 2: declined by the fast pass -> exact fallback
 }
 

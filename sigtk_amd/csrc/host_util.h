@@ -44,7 +44,7 @@ struct DeviceBatch {
         if (sgk_device_count() <= 0) return SGK_ERR_NODEVICE;
         offsets.resize(nr);
         lengths.resize(nr);
-        uint64_t o = 64;  // head room: the event fast path wants 64 readable samples before a read
+        uint64_t o = 256;  // head room: the event fast path wants up to 256 readable samples before a read
         for (size_t r = 0; r < nr; ++r) {
             const uint64_t n = hb->offsets[r + 1] - hb->offsets[r];
             if (n > 0x7fffffffull) return SGK_ERR_ARG;  // nsample is int32 in the reference (misc.c:20)

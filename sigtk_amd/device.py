@@ -52,10 +52,10 @@ def alloc_reads(lengths: np.ndarray, device: torch.device, align: int = 64) -> D
     n = lengths.size
     padded = (lengths + align - 1) // align * align
     # 64 samples of head room and tail room: the event fast path reads a little outside each read
-    offsets = np.full(n, 64, dtype=np.int64)
+    offsets = np.full(n, 256, dtype=np.int64)
     if n > 1:
         offsets[1:] += np.cumsum(padded[:-1])
-    n_samples = (int(padded.sum()) if n else 0) + 128
+    n_samples = (int(padded.sum()) if n else 0) + 320
     return DeviceReads(
         samples=torch.zeros(n_samples, dtype=torch.int16, device=device),
         offsets=torch.from_numpy(offsets).to(device),
