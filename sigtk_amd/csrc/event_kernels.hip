@@ -1037,8 +1037,11 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
     a.ev_stdv[slot0 + k] = sd;
 }
 
-constexpr int BT = 32;            // samples per lane per builder tile
-constexpr int BREC = 64 * 11;     // max boundaries per tile (peaks are >= 3 apart)
+#ifndef SGK_BT
+#define SGK_BT 16
+#endif
+constexpr int BT = SGK_BT;                       // samples per lane per builder tile (16 or 32)
+constexpr int BREC = 64 * ((BT + 2) / 3);        // max boundaries per tile (peaks are >= 3 apart)
 struct BuildLds {
     double S[BREC];
     double S2[BREC];
@@ -1063,13 +1066,15 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
     float mn = FLT_MAX, mx = 0.0f;     // exactness guard: min non-zero |x| and max |x| over the read
     constexpr int NV = BT * (int)sizeof(T) / 16;
-    for (int64_t tb = 0; tb < n; tb += 64 * BT) {
+    // tile loader: this lane's 32 samples and its 32 bitmap bits.  The next tile is fetched while the
+    // current one is processed (register double buffer).
+    auto load_tile = [&](int64_t tb, T (&buf)[BT], uint32_t &bits, int &nvalid) {
         const int64_t pos0 = tb + (int64_t)l * BT;
-        uint32_t bits = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
+        bits = (pos0 < n) ? (bm32[pos0 >> 5] >> (pos0 & 31)) : 0u;
+        if (BT < 32) bits &= (1u << (BT & 31)) - 1u;
         const int64_t rem = n - pos0;
-        const int nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
+        nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
         if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
-        T buf[BT];
         if (rc.vec_ok && pos0 + BT <= rc.hi && pos0 < n) {
             const uint4 *src = reinterpret_cast<const uint4 *>(rc.base + pos0);
             uint4 v[NV];
@@ -1080,10 +1085,23 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
 #pragma unroll
             for (int k = 0; k < BT; ++k) buf[k] = (k < nvalid) ? rc.base[pos0 + k] : (T)0;
         }
+    };
+    T nbuf[BT];
+    uint32_t nbits;
+    int nnvalid;
+    load_tile(0, nbuf, nbits, nnvalid);
+    for (int64_t tb = 0; tb < n; tb += 64 * BT) {
+        const int64_t pos0 = tb + (int64_t)l * BT;
+        T buf[BT];
+#pragma unroll
+        for (int k = 0; k < BT; ++k) buf[k] = nbuf[k];
+        const uint32_t bits = nbits;
+        const int nvalid = nnvalid;
+        if (tb + 64 * BT < n) load_tile(tb + 64 * BT, nbuf, nbits, nnvalid);
         const int cnt = __popc(bits);
         const int incl = wave_incl_scan_i(cnt);
         const int excl = incl - cnt;
-        const int total = __shfl(incl, 63, 64);
+        const int total = wave_last_i(incl);
         // walk: lane-relative prefix sums, boundary records
         double S = 0.0, S2 = 0.0;
         int idx = excl;
@@ -1109,7 +1127,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
         L->pt[l] = inS - S;
         L->pt2[l] = inS2 - S2;
-        const double tileS = shfl_d(inS, 63), tileS2 = shfl_d(inS2, 63);
+        const double tileS = wave_last_d(inS), tileS2 = wave_last_d(inS2);
         __syncthreads();
         const int tot = total < BREC ? total : BREC;
         if (total > BREC) overflow = true;

@@ -53,24 +53,44 @@ __device__ inline double shfl_up_d(double v, int delta) {
     return __hiloint2double(hi, lo);
 }
 
-// inclusive wave scan (sum) of a double; exact whenever every partial sum is representable
-__device__ inline double wave_incl_scan_d(double v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = shfl_up_d(v, d);
-        if (l >= d) v = v + o;
-    }
-    return v;
+// Inclusive wave64 scans with DPP (row_shr 1/2/4/8 inside 16-lane rows, then row_bcast15 / row_bcast31
+// across rows): register-to-register, no LDS crossbar round trips as with __shfl_up / ds_bpermute.
+#define SGK_DPP_ROW_SHR(n) (0x110 + (n))
+#define SGK_DPP_ROW_BCAST15 0x142
+#define SGK_DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_i(int v) {  // lanes without a source read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_d(double v) {  // lanes without a source read +0.0
+    const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(v));
+    const int hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 __device__ inline int wave_incl_scan_i(int v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (l >= d) v += o;
-    }
+    v += dpp_i<SGK_DPP_ROW_SHR(1), 0xf>(v);
+    v += dpp_i<SGK_DPP_ROW_SHR(2), 0xf>(v);
+    v += dpp_i<SGK_DPP_ROW_SHR(4), 0xf>(v);
+    v += dpp_i<SGK_DPP_ROW_SHR(8), 0xf>(v);
+    v += dpp_i<SGK_DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_i<SGK_DPP_ROW_BCAST31, 0xc>(v);
     return v;
+}
+// sum scan of a double; exact whenever every partial sum is representable (any order then agrees)
+__device__ inline double wave_incl_scan_d(double v) {
+    v = v + dpp_d<SGK_DPP_ROW_SHR(1), 0xf>(v);
+    v = v + dpp_d<SGK_DPP_ROW_SHR(2), 0xf>(v);
+    v = v + dpp_d<SGK_DPP_ROW_SHR(4), 0xf>(v);
+    v = v + dpp_d<SGK_DPP_ROW_SHR(8), 0xf>(v);
+    v = v + dpp_d<SGK_DPP_ROW_BCAST15, 0xa>(v);
+    v = v + dpp_d<SGK_DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+__device__ inline int wave_last_i(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ inline double wave_last_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 __device__ inline float wave_min_f(float v) {
 #pragma unroll
