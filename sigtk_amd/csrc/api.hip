@@ -76,6 +76,7 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
 }
 
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
+unsigned long long debug_exact_redo_count(bool reset);
 int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
                  double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed, int kind,
                  hipStream_t st);
@@ -246,6 +247,9 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     out->n_events_total = h.n_events_total;
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
 }
+
+// diagnostics (not part of the stable ABI): t-statistic evaluations redone by the exact path
+unsigned long long sgk_debug_exact_redo_count(int reset) { return sgk::debug_exact_redo_count(reset != 0); }
 
 // ---------------------------------------------------------------- synthetic reads
 int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,

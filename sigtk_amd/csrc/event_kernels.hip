@@ -440,8 +440,11 @@ __device__ __forceinline__ int det_step_sel(DetState &d, int i, float v1, float 
 // Exact (reference-expression) t-statistic at index i of a read, window sums formed directly from
 // the samples in global memory.  Out of line: only reached when a fast evaluation's certificate
 // fails (about 2^-13 of the evaluations).
+__device__ unsigned long long g_exact_redo_count = 0;  // diagnostics: uncertified evaluations redone
+
 template <typename T>
 __device__ __attribute__((noinline)) float tstat_exact_at(const T *base, Scale sc, int i, int w) {
+    atomicAdd(&g_exact_redo_count, 1ull);
     double A = 0.0, A2 = 0.0, B = 0.0, B2 = 0.0;
     for (int k = 0; k < w; ++k) {
         const float xa = to_pa(base[i - w + k], sc);
@@ -1335,6 +1338,16 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
+}
+
+unsigned long long debug_exact_redo_count(bool reset) {
+    unsigned long long v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_exact_redo_count), sizeof v);
+    if (reset) {
+        const unsigned long long z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exact_redo_count), &z, sizeof z);
+    }
+    return v;
 }
 
 int launch_event(const EvArgs &a, int rna, bool float_input, uint32_t n_fb_blocks, hipStream_t st) {
