@@ -42,7 +42,11 @@ def sp1():
 def gpu():
     """The HIP library on a real GPU.  Fails (does not skip) when it is missing: the GPU tests
     must never pass on a silent fallback."""
+    # torch bundles its own HIP runtime: initialise it before libsigtk_gpu.so pulls in /opt/rocm's,
+    # otherwise torch.cuda stays unavailable in this process (the reverse order works, as in bench.py)
+    import torch
+    assert torch.cuda.is_available(), "no GPU visible to torch"
     from sigtk_amd import api
-    lib = api.load_library()
+    api.load_library()
     assert api.device_count() > 0, "no GPU visible to libsigtk_gpu.so"
     return api

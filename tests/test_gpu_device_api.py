@@ -1,0 +1,148 @@
+"""GPU: the device-pointer API (sgk_event on caller-laid-out HBM buffers) -- odd layouts, overflow
+reporting, and size-independent properties at a BASELINE-sized batch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n: n // 3 + 2):
+    """Place reads at the given sample offsets of one buffer and run sgk_event through the device API."""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    host = np.zeros(n_samples, dtype=np.int16)
+    host[:] = 777  # gap samples are arbitrary data, not zeros
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    for r, o in zip(reads, offsets):
+        host[o:o + len(r)] = r
+    b = device.DeviceReads(
+        samples=torch.from_numpy(host).to(dev), offsets=torch.tensor(offsets, dtype=torch.int64, device=dev),
+        lengths=torch.tensor(lens, dtype=torch.int32, device=dev),
+        dig=torch.full((len(reads),), 8192.0, dtype=torch.float64, device=dev),
+        off=torch.full((len(reads),), 7.0, dtype=torch.float64, device=dev),
+        rng=torch.full((len(reads),), 1402.882324, dtype=torch.float64, device=dev),
+        n_reads=len(reads), max_read_len=int(lens.max()), n_samples=n_samples,
+        offsets_host=np.array(offsets, dtype=np.uint64), lengths_host=lens.astype(np.uint32))
+    arena = device.EventArena(b)
+    if slots_for is not None:
+        slots = np.zeros(len(reads) + 1, dtype=np.int64)
+        np.cumsum([slots_for(int(n)) for n in lens], out=slots[1:])
+        arena.slots_host = slots
+        arena.slots = torch.from_numpy(slots).to(dev)
+    device.event(b, arena, rna)
+    torch.cuda.synchronize()
+    return b, arena
+
+
+def test_unaligned_and_edge_reads_take_the_exact_fallback(gpu, oracle):
+    reads, _, _, _ = gpu.synth_reads_host(5, [30000, 20001, 9999, 15000, 12000], seed=31, kind=0)
+    # read 0 at the very start of the buffer (no head room), read 1 on an odd sample, read 2 on a
+    # 2-byte-but-not-16-byte boundary, read 3 aligned with room, read 4 flush against the buffer end
+    offsets = [0, 30001, 50008, 60032, 0]
+    offsets[4] = 75040
+    n_samples = offsets[4] + len(reads[4])
+    n_samples = (n_samples + 7) // 8 * 8
+    b, arena = _run_layout(gpu, oracle, reads, offsets, n_samples, 0)
+    st = arena.status()
+    assert st.n_capacity_overflow == 0
+    assert st.n_fallback_reads >= 3  # reads 0, 1 and 4 cannot use the fast path
+    for r, raw in enumerate(reads):
+        exp = oracle.event_raw(raw, 8192.0, 7.0, 1402.882324, 0)
+        got = arena.read_events(r)
+        assert got.start.size == exp.start.size, "read %d" % r
+        assert np.array_equal(got.start.astype(np.uint64), exp.start)
+        assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+        assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+def test_capacity_overflow_is_reported_not_silent(gpu, oracle):
+    reads, _, _, _ = gpu.synth_reads_host(2, [20000, 20000], seed=32, kind=0)
+    offsets = [256, 256 + 20032]
+    b, arena = _run_layout(gpu, oracle, reads, offsets, 256 + 2 * 20032 + 320, 0,
+                           slots_for=lambda n: 100)  # far too few slots
+    st = arena.status()
+    assert st.n_capacity_overflow == 2
+    exp = oracle.event_raw(reads[0], 8192.0, 7.0, 1402.882324, 0)
+    assert int(arena.n_events[0].item()) == exp.start.size  # the true count is still reported
+    got = arena.read_events(0)
+    assert np.array_equal(got.start[:100].astype(np.uint64), exp.start[:100])  # the slots that exist are right
+
+
+def test_baseline_sized_batch_properties(gpu, oracle):
+    """2000 reads x 100 000 samples (a fifth of BASELINE config 2, same per-read shape): properties
+    that do not need the oracle on every read, plus the oracle on a sample of reads."""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    b = device.synth_reads(2000, 100000, seed=1, kind=0, device=dev)
+    arena = device.EventArena(b)
+    device.event(b, arena, 0)
+    torch.cuda.synchronize()
+    st = arena.status()
+    nev = arena.n_events[:b.n_reads].to(torch.int64)
+    assert st.n_capacity_overflow == 0 and int(nev.sum().item()) == st.n_events_total
+    slots = torch.from_numpy(arena.slots_host[:-1]).to(dev)
+    # every read: first event starts at 0, events are contiguous, lengths sum to n, last ends at n
+    first = arena.start[slots].to(torch.int64)
+    assert bool((first == 0).all())
+    last = slots + nev - 1
+    assert bool(((arena.start[last].to(torch.int64) + arena.length[last].to(torch.int64)) == 100000).all())
+    for r in (0, 999, 1999):
+        s = int(arena.slots_host[r]); k = int(nev[r].item())
+        st_r = arena.start[s:s + k].to(torch.int64); ln_r = arena.length[s:s + k].to(torch.int64)
+        assert bool((st_r[1:] == st_r[:-1] + ln_r[:-1]).all()) and int(ln_r.sum().item()) == 100000
+        assert bool((ln_r >= 1).all()) and bool(torch.isfinite(arena.mean[s:s + k]).all())
+    # idempotence: a second pass over the same batch gives identical bytes
+    snap = (arena.start.clone(), arena.length.clone(), arena.mean.clone(), arena.stdv.clone(), nev.clone())
+    device.event(b, arena, 0)
+    torch.cuda.synchronize()
+    nev2 = arena.n_events[:b.n_reads].to(torch.int64)
+    assert bool((nev2 == snap[4]).all())
+    for r in (5, 1234):
+        s = int(arena.slots_host[r]); k = int(nev2[r].item())
+        assert bool((arena.start[s:s + k] == snap[0][s:s + k]).all())
+        assert bool((arena.mean[s:s + k].view(torch.int32) == snap[2][s:s + k].view(torch.int32)).all())
+    # oracle on a sample
+    for r in (0, 777, 1999):
+        o = int(b.offsets_host[r]); n = int(b.lengths_host[r])
+        raw = b.samples[o:o + n].cpu().numpy()
+        exp = oracle.event_raw(raw, float(b.dig[r]), float(b.off[r]), float(b.rng[r]), 0)
+        got = arena.read_events(r)
+        assert np.array_equal(got.start.astype(np.uint64), exp.start)
+        assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+def test_getevents_shim_matches_reference_signature(gpu, oracle, sp1):
+    """sgk_getevents(nsample, pA*, rna): the drop-in for getevents() (src/events.c:553) fed with pA floats."""
+    L = gpu.load_library()
+
+    class Ev(C.Structure):
+        _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
+
+    class Tab(C.Structure):
+        _fields_ = [("n", C.c_size_t), ("start", C.c_size_t), ("end", C.c_size_t), ("event", C.POINTER(Ev))]
+
+    L.sgk_getevents.restype = Tab
+    L.sgk_getevents.argtypes = [C.c_size_t, C.c_void_p, C.c_int8]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for r in sp1.reads[:3]:
+        pa = oracle.pa(r.raw, r.digitisation, r.offset, r.range)
+        exp = oracle.getevents(pa, 0)
+        t = L.sgk_getevents(pa.size, pa.ctypes.data, 0)
+        assert t.n == exp.start.size and t.start == 0 and t.end == t.n
+        got = np.array([(t.event[i].start, t.event[i].length, t.event[i].mean, t.event[i].stdv)
+                        for i in range(t.n)], dtype=np.float64)
+        assert np.array_equal(got[:, 0].astype(np.uint64), exp.start)
+        assert np.array_equal(got[:, 1].astype(np.float32), exp.length)
+        assert np.array_equal(got[:, 2].astype(np.float32).view(np.uint32), exp.mean.view(np.uint32))
+        libc.free(t.event)
