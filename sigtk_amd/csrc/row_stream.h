@@ -66,3 +66,67 @@ struct RowStream {
 };
 
 }  // namespace sgk
+
+namespace sgk {
+
+// Prefetching variant for int16 rows, used by the lane-per-read kernels (stat / jnn / prefix):
+//   issue(t)   every lane starts its eight 16-byte global loads of tile t (no wait),
+//   commit(t)  waits for them and writes them into LDS slot t&1,
+//   row(t, w)  copies this lane's 64-sample row of tile t from LDS into 32 registers.
+// A sweep issues tile t+1, consumes tile t out of registers (pure arithmetic, no memory op on the
+// serial float chain), then commits t+1.  Rows must start on a multiple of 8 samples (callers align
+// the row base down and skip the leading samples) and the buffer base must be 16-byte aligned.
+struct RowPrefetch {
+    static constexpr int ROW_BYTES = 2 * TILE * 2 + 4;
+    static constexpr int LDS_BYTES = 64 * ROW_BYTES;
+    char *lds;
+    const int16_t *base;
+    int64_t hi;   // readable samples in [0, hi), hi a multiple of 8
+    int64_t rb;   // this lane's row base (multiple of 8)
+    uint4 pf[8];
+    int64_t rb_of[8];  // row bases of the eight rows this lane fetches pieces of
+    unsigned long long rowmask;
+
+    __device__ void init(char *lds_, const int16_t *base_, int64_t hi_, int64_t rb_, unsigned long long rowmask_) {
+        lds = lds_; base = base_; hi = hi_; rb = rb_; rowmask = rowmask_;
+        const int l = lane_id();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rb_of[it] = (int64_t)__shfl((long long)rb, it * 8 + l / 8, 64);
+    }
+    __device__ __forceinline__ void issue(int tile) {
+        const int v = lane_id() & 7;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int64_t p0 = rb_of[it] + (int64_t)tile * TILE + v * 8;
+            p0 = p0 > hi - 8 ? hi - 8 : p0;
+            p0 = p0 < 0 ? 0 : p0;
+            pf[it] = *reinterpret_cast<const uint4 *>(base + p0);
+        }
+    }
+    __device__ __forceinline__ void commit(int tile) {
+        const int l = lane_id();
+        const int v = l & 7;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + l / 8;
+            const int64_t p0 = rb_of[it] + (int64_t)tile * TILE + v * 8;
+            uint4 q = pf[it];
+            if (p0 < 0 || p0 > hi - 8) q = make_uint4(0u, 0u, 0u, 0u);  // outside the buffer: zeros
+            uint32_t *dst = reinterpret_cast<uint32_t *>(lds + row * ROW_BYTES + (tile & 1) * TILE * 2 + v * 16);
+            dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void row(int tile, uint32_t (&w)[32]) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES + (tile & 1) * TILE * 2);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w[k] = src[k];
+    }
+    template <int K>
+    static __device__ __forceinline__ int16_t sample(const uint32_t (&w)[32]) {
+        return (K & 1) ? (int16_t)(w[K / 2] >> 16) : (int16_t)(w[K / 2] & 0xffffu);
+    }
+};
+
+}  // namespace sgk

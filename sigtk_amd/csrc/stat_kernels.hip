@@ -18,7 +18,7 @@
 
 namespace sgk {
 
-using Stream1 = RowStream<int16_t, 1>;
+using Stream1 = RowPrefetch;
 
 __device__ inline int wave_max_i(int v) {
 #pragma unroll
@@ -63,33 +63,47 @@ __device__ inline float clampf_pa(float v) {     // rm_outlierf, src/jnn.c:79-95
 }
 
 // Lane-per-row sequential sweep: calls f(j, raw) for j = 0..len-1 in order.  All lanes of the wave
-// must call it (cooperative tile loads); lanes with len == 0 just help loading.
+// must call it (cooperative tile loads); lanes with len == 0 just help loading.  Tile t+1 is in
+// flight while tile t is consumed out of registers.
+template <int K, typename F>
+__device__ __forceinline__ void sweep_tile_elems(const uint32_t (&w)[32], int64_t j0, int64_t len, F &f) {
+    if constexpr (K < TILE) {
+        const int64_t j = j0 + K;
+        if (j >= 0 && j < len) f(j, RowPrefetch::sample<K>(w));
+        sweep_tile_elems<K + 1>(w, j0, len, f);
+    }
+}
+template <int K, typename F>
+__device__ __forceinline__ void sweep_tile_full(const uint32_t (&w)[32], int j0, F &f) {
+    if constexpr (K < TILE) {
+        f((int64_t)(j0 + K), RowPrefetch::sample<K>(w));
+        sweep_tile_full<K + 1>(w, j0, f);
+    }
+}
 template <typename F>
-__device__ inline void sweep_rows(Stream1 &rs, int skip, int64_t len, unsigned long long rowmask, F f) {
+__device__ inline void sweep_rows(RowPrefetch &rs, int skip, int64_t len, F f) {
     const int maxq = wave_max_i((int)(len > 0 ? skip + len : 0));
     const int ntiles = (maxq + TILE - 1) / TILE;
+    if (ntiles == 0) return;
+    rs.issue(0);
+    rs.commit(0);
     for (int t = 0; t < ntiles; ++t) {
-        rs.load_tile(t, rowmask);
-        const int q0 = t * TILE;
-        if (q0 + TILE > skip && q0 < skip + len) {
-#pragma unroll 4
-            for (int k = 0; k < TILE; ++k) {
-                const int64_t j = (int64_t)(q0 + k) - skip;
-                if (j >= 0 && j < len) f(j, rs.get(q0 + k));
-            }
-        }
+        if (t + 1 < ntiles) rs.issue(t + 1);
+        uint32_t w[32];
+        rs.row(t, w);
+        const int64_t j0 = (int64_t)t * TILE - skip;
+        // common case: the whole tile lies inside every lane's row -> no per-sample predicates
+        if (__all(j0 >= 0 && j0 + TILE <= len)) sweep_tile_full<0>(w, (int)j0, f);
+        else if (j0 + TILE > 0 && j0 < len) sweep_tile_elems<0>(w, j0, len, f);
+        if (t + 1 < ntiles) rs.commit(t + 1);
     }
 }
 
-__device__ inline Stream1 make_stream(char *lds, const sgk_batch_t &b, int64_t start, int &skip) {
-    Stream1 rs;
-    rs.lds = lds;
-    rs.base = b.samples;
-    rs.lo = 0;
-    rs.hi = (int64_t)b.n_samples;
-    rs.rb = start & ~(int64_t)7;
-    skip = (int)(start - rs.rb);
-    rs.base_al = true;  // checked by the launcher
+__device__ inline RowPrefetch make_stream(char *lds, const sgk_batch_t &b, int64_t start, bool wanted, int &skip) {
+    RowPrefetch rs;
+    const int64_t rb = start & ~(int64_t)7;
+    skip = (int)(start - rb);
+    rs.init(lds, b.samples, (int64_t)b.n_samples, rb, __ballot(wanted));
     return rs;
 }
 
@@ -106,17 +120,16 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
         sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
     }
     int skip;
-    Stream1 rs = make_stream(lds, a.b, g.start, skip);
-    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    Stream1 rs = make_stream(lds, a.b, g.start, valid && g.len > 0, skip);
     const float nf = (float)(int)g.len;
     float sraw = 0.0f, spa = 0.0f;
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
         sraw = sraw + (float)v;
         spa = spa + to_pa(v, sc);
     });
     const float mraw = sraw / nf, mpa = spa / nf;
     float qraw = 0.0f, qpa = 0.0f;
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
         const float d = (float)v - mraw;
         qraw = qraw + d * d;
         const float e = to_pa(v, sc) - mpa;
@@ -263,14 +276,13 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
     Region g = {0, 0};
     if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
     int skip;
-    Stream1 rs = make_stream(lds, a.b, g.start, skip);
-    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    Stream1 rs = make_stream(lds, a.b, g.start, valid && g.len > 0, skip);
     const float nf = (float)(int)g.len;
     float s = 0.0f;
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) { s = s + clampf_raw(v); });
+    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) { s = s + clampf_raw(v); });
     const float mn = s / nf;
     float q = 0.0f;
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t, int16_t v) {
+    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
         const float d = clampf_raw(v) - mn;
         q = q + d * d;
     });
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
         if ((uint64_t)k < cap) { a.seg_x[slot0 + k] = x; a.seg_y[slot0 + k] = y; }
         else overflow = true;
     };
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
+    sweep_rows(rs, skip, g.len, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
     A.finish(emit);
     if (valid) a.n_segs[r] = (uint32_t)A.nseg;
     if (overflow) atomicAdd(a.err_count, 1u);
@@ -306,8 +318,7 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
         m_a = a.prefix[r].adapt_mean;
     }
     int skip;
-    Stream1 rs = make_stream(lds, a.b, g.start, skip);
-    const unsigned long long rowmask = __ballot(valid && g.len > 0);
+    Stream1 rs = make_stream(lds, a.b, g.start, valid && g.len > 0, skip);
     const float mid = m_a + 30.0f;
     JnnAuto A;
     A.init(mid + 20.0f, mid - 20.0f, 50, 200, 250, 1.0f, 30);
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
         if (k == 0) { px = x; py = y; }
     };
     // (a lane whose first segment is final could stop; the sweep is wave-cooperative, so it just idles)
-    sweep_rows(rs, skip, g.len, rowmask, [&](int64_t j, int16_t v) {
+    sweep_rows(rs, skip, g.len, [&](int64_t j, int16_t v) {
         if (py < 0 || A.nseg < 2) A.step((int)j, clampf_pa(to_pa(v, sc)), emit);
     });
     if (A.nseg == 1 || (A.nseg >= 2 && py < 0)) A.finish(emit);
@@ -358,32 +369,65 @@ struct RunFinder {
 
 constexpr int ADW = 2000;  // jnnv2 window (both presets, src/jnn.h:84-98)
 
-// one rolling-window sweep: calls f(i, t_i) for i = 0..m-1 (m = n - ADW) in order
-template <typename F>
-__device__ inline void sweep_rolling(Stream1 &lead, Stream1 &trail, int skip, int64_t n, unsigned long long rowmask, F f) {
-    const int maxq = wave_max_i((int)(n > ADW ? skip + n : 0));
-    float tot = 0.0f;
-    for (int q0 = 0; q0 < maxq; q0 += 16) {
-        if ((q0 & 63) == 0) lead.load_tile(q0 >> 6, rowmask);
-        if (q0 >= ADW && ((q0 - ADW) & 63) == 0) trail.load_tile((q0 - ADW) >> 6, rowmask);
-        if (n > ADW) {
-#pragma unroll 4
-            for (int k = 0; k < 16; ++k) {
-                const int q = q0 + k;
-                const int64_t il = (int64_t)q - skip;  // lead index
-                if (il < 0 || il >= n) continue;
-                const float cl = clampf_raw(lead.get(q));
-                if (il < ADW) {
-                    tot = tot + cl;
-                    if (il == ADW - 1) f((int64_t)0, tot / (float)ADW);
-                } else {
-                    const float ct = clampf_raw(trail.get(q - ADW));
-                    tot = tot - ct;
-                    tot = tot + cl;
-                    f(il - ADW + 1, tot / (float)ADW);
-                }
+// One rolling-window sweep: calls f(i, t_i) for i = 0..m-1 (m = n - ADW) in order.  The trailing
+// edge is a second row stream whose base is shifted by 16 samples, so that its tiles line up with
+// the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
+template <int K, typename F>
+__device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int64_t il0,
+                                              int64_t n, float &tot, F &f) {
+    if constexpr (K < TILE) {
+        const int64_t il = il0 + K;  // lead index
+        if (il >= 0 && il < n) {
+            const float cl = clampf_raw(RowPrefetch::sample<K>(wl));
+            if (il < ADW) {
+                tot = tot + cl;
+                if (il == ADW - 1) f((int64_t)0, tot / (float)ADW);
+            } else {
+                const float ct = clampf_raw(RowPrefetch::sample<K>(wt));
+                tot = tot - ct;
+                tot = tot + cl;
+                f(il - ADW + 1, tot / (float)ADW);
             }
         }
+        rolling_elems<K + 1>(wl, wt, il0, n, tot, f);
+    }
+}
+template <int K, typename F>
+__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int il0, float &tot,
+                                             F &f) {
+    if constexpr (K < TILE) {
+        const float cl = clampf_raw(RowPrefetch::sample<K>(wl));
+        const float ct = clampf_raw(RowPrefetch::sample<K>(wt));
+        tot = tot - ct;
+        tot = tot + cl;
+        f((int64_t)(il0 + K - ADW + 1), tot / (float)ADW);
+        rolling_full<K + 1>(wl, wt, il0, tot, f);
+    }
+}
+template <typename F>
+__device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int skip, int64_t n, F f) {
+    const int maxq = wave_max_i((int)(n > ADW ? skip + n : 0));
+    const int ntiles = (maxq + TILE - 1) / TILE;
+    if (ntiles == 0) return;
+    constexpr int LAG = 31;  // tiles between the two streams
+    float tot = 0.0f;
+    lead.issue(0);
+    lead.commit(0);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) lead.issue(t + 1);
+        if (t + 1 >= LAG && t + 1 < ntiles) trail.issue(t + 1 - LAG);
+        uint32_t wl[32], wt[32];
+        lead.row(t, wl);
+        if (t >= LAG) trail.row(t - LAG, wt);
+        else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) wt[k] = 0u;
+        }
+        const int64_t il0 = (int64_t)t * TILE - skip;
+        if (__all(il0 >= ADW && il0 + TILE <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
+        else if (n > ADW) rolling_elems<0>(wl, wt, il0, n, tot, f);
+        if (t + 1 < ntiles) lead.commit(t + 1);
+        if (t + 1 >= LAG && t + 1 < ntiles) trail.commit(t + 1 - LAG);
     }
 }
 
@@ -394,26 +438,26 @@ __global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
     Region g = {0, 0};
     if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
-    int skip;
-    Stream1 lead = make_stream(lds, a.b, g.start, skip);
-    Stream1 trail = lead;
-    trail.lds = lds + Stream1::LDS_BYTES;
     const bool run = valid && n > ADW;
-    const unsigned long long rowmask = __ballot(run);
+    int skip;
+    Stream1 lead = make_stream(lds, a.b, g.start, run, skip);
+    Stream1 trail;
+    // trail position = lead position - 2000 = (row base - 16) + (q - 31*64)
+    trail.init(lds + Stream1::LDS_BYTES, a.b.samples, (int64_t)a.b.n_samples, lead.rb - 16, lead.rowmask);
     const int64_t m = n - ADW;
     const float mf = (float)(int)m;
     float s = 0.0f;
-    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) { if (i < m) s = s + t; });
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) { if (i < m) s = s + t; });
     const float mn = s / mf;
     float q = 0.0f;
-    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) {
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) {
         if (i < m) { const float d = t - mn; q = q + d * d; }
     });
     const float sd = sqrtf(q / mf);
     const float std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
     RunFinder F;
     F.init(mn - sd * std_scale, 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
-    sweep_rolling(lead, trail, skip, n, rowmask, [&](int64_t i, float t) { if (i < m) F.step((int)i, t); });
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) { if (i < m) F.step((int)i, t); });
     F.finish();
     if (!valid) return;
     sgk_prefix_rec_t *o = a.prefix + r;

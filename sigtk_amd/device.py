@@ -135,3 +135,48 @@ def event(b: DeviceReads, arena: EventArena, rna: int) -> None:
     api.check(L.sgk_event(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.start), _ptr(arena.length),
                           _ptr(arena.mean), _ptr(arena.stdv), _ptr(arena.n_events), _ptr(arena.ws),
                           arena.ws_bytes, _stream_ptr()), "sgk_event")
+
+
+# ---------------------------------------------------------------------- stat / jnn / prefix / pa (device API)
+
+def stat(b: DeviceReads) -> torch.Tensor:
+    """sgk_stat -> uint8 tensor holding n_reads sgk_stat_rec_t (view it with api.STAT_DTYPE)."""
+    L = api.load_library()
+    out = torch.zeros(max(b.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
+    view = b.view()
+    api.check(L.sgk_stat(C.byref(view), _ptr(out), None, 0, _stream_ptr()), "sgk_stat")
+    return out
+
+
+def prefix(b: DeviceReads, rna: int, pore: int) -> torch.Tensor:
+    L = api.load_library()
+    out = torch.zeros(max(b.n_reads, 1) * api.PREFIX_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
+    view = b.view()
+    api.check(L.sgk_prefix(C.byref(view), int(rna), int(pore), _ptr(out), None, 0, _stream_ptr()), "sgk_prefix")
+    return out
+
+
+class SegArena:
+    def __init__(self, b: DeviceReads):
+        dev = b.samples.device
+        slots = np.zeros(b.n_reads + 1, dtype=np.int64)
+        np.cumsum(b.lengths_host.astype(np.int64) // 32 + 2, out=slots[1:])
+        self.slots_host = slots
+        self.slots = torch.from_numpy(slots).to(dev)
+        self.x = torch.empty(max(int(slots[-1]), 1), dtype=torch.int32, device=dev)
+        self.y = torch.empty(max(int(slots[-1]), 1), dtype=torch.int32, device=dev)
+        self.n_segs = torch.zeros(max(b.n_reads, 1), dtype=torch.int32, device=dev)
+        self.ws = torch.zeros(64, dtype=torch.uint8, device=dev)
+
+
+def jnn(b: DeviceReads, arena: SegArena, rna: int) -> None:
+    L = api.load_library()
+    view = b.view()
+    api.check(L.sgk_jnn(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.x), _ptr(arena.y),
+                        _ptr(arena.n_segs), _ptr(arena.ws), 64, _stream_ptr()), "sgk_jnn")
+
+
+def pa(b: DeviceReads, out: torch.Tensor) -> None:
+    L = api.load_library()
+    view = b.view()
+    api.check(L.sgk_pa(C.byref(view), _ptr(out), _stream_ptr()), "sgk_pa")

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Throughput of the non-headline subtools (pa, stat, stat+pa, jnn, prefix) on device-resident
+synthetic reads; prints one JSON object per subtool with per-kernel HIP-event times and the
+achieved fraction of the HBM roofline on ALGORITHMIC bytes.
+    python tools/bench_subtools.py [--reads 20000] [--read-len 100000] [--rna 1]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--read-len", type=int, default=100000)
+    ap.add_argument("--rna", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from sigtk_amd import api, device
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    L = api.load_library()
+    b = device.synth_reads(args.reads, args.read_len, seed=2, kind=args.rna, device=dev)
+    S, R = b.total_samples, b.n_reads
+    pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=dev)
+    segs = device.SegArena(b)
+
+    def run(name, fn, alg_bytes):
+        fn(); torch.cuda.synchronize()
+        L.sgk_profile_reset(); L.sgk_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        L.sgk_profile_enable(0)
+        prof = {k: round(v[0] / max(v[1], 1), 4) for k, v in api.profile_read().items()}
+        L.sgk_profile_reset()
+        print(json.dumps({"subtool": name, "reads": R, "samples": S, "ms": round(dt * 1e3, 3),
+                          "samples_per_s": round(S / dt, 1), "reads_per_s": round(R / dt, 1),
+                          "algorithmic_GBps": round(alg_bytes / dt / 1e9, 1),
+                          "hbm_frac": round(alg_bytes / dt / 1e9 / 8000.0, 4), "kernels_ms": prof}), flush=True)
+
+    run("pa", lambda: device.pa(b, pa_out), 6 * S)
+    run("stat", lambda: device.stat(b), 2 * S + 32 * R)
+    run("jnn", lambda: device.jnn(b, segs, args.rna), 2 * S)
+    run("prefix", lambda: device.prefix(b, args.rna, 0), 2 * S + 48 * R)
+
+
+if __name__ == "__main__":
+    main()
