@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=100000)
     ap.add_argument("--rna", type=int, default=0)
     ap.add_argument("--cpu-reads", type=int, default=2000, help="reads in the CPU baseline subsample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / MAX-reduce "
+                    "(nccl = RCCL; 'gloo' lets several ranks share one GPU for testing)")
     args = ap.parse_args()
 
     import torch
@@ -48,11 +50,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     api.load_library()  # raises if the HIP extension is missing: no fallback
     kind = 1 if args.rna else 0
@@ -104,7 +111,7 @@ def main():
     L.sgk_profile_enable(0)
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = api.profile_read()
