@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""End-to-end CLI comparison on the GPU box: sigtk-amd vs the real reference binary
+(oracle/_ref/sigtk_ref) on a synthetic BLOW5 -- byte-compare stdout and report wall times.
+    python tools/e2e_compare.py [--reads 500] [--read-len 100000] [--kind 0]"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sigtk_amd import api, blow5, build  # noqa: E402
+from oracle.oracle import REF_BIN  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=500)
+    ap.add_argument("--read-len", type=int, default=100000)
+    ap.add_argument("--kind", type=int, default=0)
+    a = ap.parse_args()
+    reads, dig, off, rng = api.synth_reads_host(a.reads, a.read_len, 77, a.kind)
+    recs = [blow5.Read("synth-%08d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
+            for i in range(a.reads)]
+    attrs = {"experiment_type": "rna" if a.kind else "genomic_dna",
+             "sequencing_kit": "sqk-rna002" if a.kind else "sqk-lsk109"}
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "e2e.blow5")
+        blow5.write_blow5(f, recs, attrs)
+        out = {"reads": a.reads, "samples": a.reads * a.read_len, "file_mb": round(os.path.getsize(f) / 1e6, 1)}
+        for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"]):
+            name = " ".join(tool)
+            t0 = time.perf_counter(); g = subprocess.run([build.CLI, *tool, f], capture_output=True); tg = time.perf_counter() - t0
+            t0 = time.perf_counter(); r = subprocess.run([REF_BIN, *tool, f], capture_output=True, cwd=tmp); tr = time.perf_counter() - t0
+            out[name] = {"identical": g.stdout == r.stdout and g.returncode == 0, "sigtk_amd_s": round(tg, 3),
+                         "reference_s": round(tr, 3), "stdout_mb": round(len(r.stdout) / 1e6, 1)}
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
