@@ -1273,7 +1273,7 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 // ---------------------------------------------------------------- kernels
 
 template <int W1, typename T>
-__global__ __launch_bounds__(64) void k_event_detect(EvArgs a) {
+__global__ __launch_bounds__(64, 3) void k_event_detect(EvArgs a) {
     __shared__ DetSnap snap;
     __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
     const uint32_t r = blockIdx.x;

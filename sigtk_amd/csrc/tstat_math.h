@@ -62,7 +62,11 @@ SGK_TM float sgk_div_f32(float a) {
 }
 #define SGK_F32_TINY 7.8886090522101181e-31f /* 2^-100 */
 
+SGK_TM uint32_t sgk_hi32(double x) { return (uint32_t)(sgk_d2u(x) >> 32); }
+
 // Fast form of (float)( fabs((double)delta) / sqrt((double)cvw) ) plus its certificate.
+// The range / residual / midpoint tests are done on the bit patterns (integer ops issue at the f32
+// rate, f64 compares at the f64 rate).
 SGK_TM float sgk_tail_fast(float delta, float cvw, bool &ok) {
     const double ad = fabs((double)delta);
     const double v = (double)cvw;
@@ -71,14 +75,15 @@ SGK_TM float sgk_tail_fast(float delta, float cvw, bool &ok) {
     const double e = fma(-t, y0, 1.0);
     const double y1 = fma(y0, 0.5 * e, y0);
     const double q = ad * y1;
+    // |e| < 2^-20  <=>  biased exponent of e below that of 2^-20 (0x3EB00000 is the high word of 2^-20)
+    const bool e_ok = (sgk_hi32(e) & 0x7FFFFFFFu) < 0x3EB00000u;
+    // 2^-120 <= q < 2^127 (high words 0x38700000 / 0x47E00000): float result comfortably normal
+    const bool q_ok = (sgk_hi32(q) - 0x38700000u) < (0x47E00000u - 0x38700000u);
+    // q not within 2^15 double-ulps of a float rounding midpoint (low 29 bits near 2^28)
     const uint32_t lo29 = (uint32_t)sgk_d2u(q) & 0x1FFFFFFFu;
-    const uint32_t dist = lo29 > 0x10000000u ? lo29 - 0x10000000u : 0x10000000u - lo29;
-    const bool cert = (fabs(e) < 9.5367431640625e-07) &   // 2^-20: y1 within 2^-40 of rsqrt(v)
-                      (dist > 0x8000u) &                  // q not near a float rounding midpoint
-                      (q > 7.5231638452626401e-37) &      // 2^-120: float result comfortably normal
-                      (q < 1.7014118346046923e+38);       // 2^127
+    const bool mid = (uint32_t)(lo29 - (0x10000000u - 0x8000u)) <= 0x10000u;
     // delta == 0 gives exactly 0 whenever the residual certificate holds (v is finite and positive)
-    ok = cert | ((ad == 0.0) & (fabs(e) < 9.5367431640625e-07));
+    ok = e_ok & ((q_ok & !mid) | (delta == 0.0f));
     return (float)q;
 }
 // standalone tail with its exact fallback (used by the verification tool)
@@ -117,9 +122,9 @@ SGK_TM float sgk_tstat_try(double A, double A2, double B, double B2, bool &ok) {
     const float cvw = at_floor ? floor_q : sgk_div_f32<W>(cv);
     bool tail_ok;
     const float tq = sgk_tail_fast(delta, cvw, tail_ok);
-    // an exactly-zero dividend divides exactly (+0 in, +0 out); other tiny inputs take the exact path
-    ok = ((fabsf(sum2) >= SGK_F32_TINY) | (sum2 == 0.0f)) & ((sumsq2 >= SGK_F32_TINY) | (sumsq2 == 0.0f)) &
-         ((cv >= SGK_F32_TINY) | at_floor) & tail_ok;
+    // tiny (or zero) dividends take the exact path; the variance floor is handled above
+    const float cvx = at_floor ? 1.0f : cv;
+    ok = (fminf(fminf(fabsf(sum2), sumsq2), cvx) >= SGK_F32_TINY) & tail_ok;
     return tq;
 }
 
