@@ -62,7 +62,7 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.off_scratch = o;
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
     const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
-    uint64_t nb = nr < 64 ? nr : 64;
+    uint64_t nb = nr < 256 ? nr : 256;  // persistent fallback blocks (each owns a scratch region)
     if (available) {
         const size_t room = available > o ? available - o : 0;
         uint64_t fit = room / per_block;

@@ -312,13 +312,13 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
                 if (PREFIX) {
                     if (t1_ok && i >= W1 && i <= n - W1) {
                         const double p0 = rc.P[i], q0 = rc.P2[i];
-                        v1 = tstat_from_sums<W1>(p0 - rc.P[i - W1], q0 - rc.P2[i - W1], rc.P[i + W1] - p0,
-                                                 rc.P2[i + W1] - q0);
+                        v1 = sgk_tstat_fast<W1>(p0 - rc.P[i - W1], q0 - rc.P2[i - W1], rc.P[i + W1] - p0,
+                                                rc.P2[i + W1] - q0);
                     }
                     if (t2_ok && i >= W2 && i <= n - W2) {
                         const double p0 = rc.P[i], q0 = rc.P2[i];
-                        v2 = tstat_from_sums<W2>(p0 - rc.P[i - W2], q0 - rc.P2[i - W2], rc.P[i + W2] - p0,
-                                                 rc.P2[i + W2] - q0);
+                        v2 = sgk_tstat_fast<W2>(p0 - rc.P[i - W2], q0 - rc.P2[i - W2], rc.P[i + W2] - p0,
+                                                rc.P2[i + W2] - q0);
                     }
                 } else {
                     if (t1_ok && i >= W1 && i <= n - W1) v1 = tstat_from_sums<W1>(A1, A1q, B1, B1q);
@@ -1246,8 +1246,10 @@ template <typename T>
 __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLds *L) {
     const int l = lane_id();
     const int64_t n = rc.n;
-    double s = 0.0, sq = 0.0;
-    if (l == 0) { P[0] = 0.0; P2[0] = 0.0; }
+    // lane 0 runs the chain of sums, lane 1 the chain of squares: each is strictly sequential
+    double acc = 0.0;
+    double *out = (l == 0) ? P : P2;
+    if (l < 2) out[0] = 0.0;
     for (int64_t tb = 0; tb < n; tb += SP_TILE) {
         const int m = (n - tb) < SP_TILE ? (int)(n - tb) : SP_TILE;
         __syncthreads();
@@ -1257,12 +1259,22 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
             L->xq[k] = x * x;
         }
         __syncthreads();
-        if (l == 0) {
-            for (int k = 0; k < m; ++k) {
-                s = s + (double)L->x[k];
-                sq = sq + (double)L->xq[k];
-                P[tb + k + 1] = s;
-                P2[tb + k + 1] = sq;
+        if (l < 2) {
+            const float *src = (l == 0) ? L->x : L->xq;
+            int k = 0;
+            for (; k + 8 <= m; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = acc + (double)v[u];
+                    out[tb + k + u + 1] = acc;
+                }
+            }
+            for (; k < m; ++k) {
+                acc = acc + (double)src[k];
+                out[tb + k + 1] = acc;
             }
         }
     }
