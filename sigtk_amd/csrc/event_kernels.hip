@@ -481,6 +481,57 @@ struct Lead16<float> {
 };
 typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// ---- repair context of a read that failed the exactness guard (fallback kernel only) ----------
+// The reference's window sums are differences of its sequentially rounded prefix arrays.  They equal
+// the exact sums the fast pass forms EXCEPT where an inexact addition of the sequential scan ("event"
+// at sample t: prefix[t+1] != prefix[t] + y_t exactly) lies inside the window, i.e. for the indices
+// i in [t-w+1, t+w].  The fast pass therefore runs unchanged on such reads and only those indices
+// (plus uncertified evaluations) are re-evaluated from the scratch prefix arrays.
+constexpr int REP_MAX_EVENTS = 32;
+struct RepairCtx {
+    const double *P, *P2;   // reference prefix arrays (n+1 entries each)
+    const int *ev;          // sorted event positions (LDS)
+    int nev;
+    bool all_dirty;         // more events than REP_MAX_EVENTS: every index is evaluated from the prefix arrays
+};
+
+__device__ __attribute__((noinline)) float tstat_prefix_at(const double *P, const double *P2, int i, int w) {
+    const double p0 = P[i], q0 = P2[i];
+    const double A = p0 - P[i - w], A2 = q0 - P2[i - w], B = P[i + w] - p0, B2 = P2[i + w] - q0;
+    if (w == 3) return sgk_tstat_ref<3>(A, A2, B, B2);
+    if (w == 6) return sgk_tstat_ref<6>(A, A2, B, B2);
+    if (w == 7) return sgk_tstat_ref<7>(A, A2, B, B2);
+    return sgk_tstat_ref<14>(A, A2, B, B2);
+}
+
+// marks (as "redo exactly") the indices q0..q0+3 that lie within a window length of an event
+template <int W1>
+__device__ __forceinline__ void repair_mark(const RepairCtx &rep, int &next_t, int q0, unsigned cnt1, unsigned cnt2,
+                                            unsigned &bad1, unsigned &bad2) {
+    constexpr int W2 = 2 * W1;
+    if (rep.all_dirty) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((unsigned)(q0 + u - W1) < cnt1) bad1 |= 1u << u;
+            if ((unsigned)(q0 + u - W2) < cnt2) bad2 |= 1u << u;
+        }
+        return;
+    }
+    if (next_t > q0 + 3 + W2 - 1) return;  // no event can reach this quad (the usual case)
+    int nt = 0x7fffffff;
+    for (int k = 0; k < rep.nev; ++k) {
+        const int t = rep.ev[k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = q0 + u;
+            if ((unsigned)(i - t + W1 - 1) < (unsigned)(2 * W1) && (unsigned)(i - W1) < cnt1) bad1 |= 1u << u;
+            if ((unsigned)(i - t + W2 - 1) < (unsigned)(2 * W2) && (unsigned)(i - W2) < cnt2) bad2 |= 1u << u;
+        }
+        if (t + W2 >= q0 + 4 && t < nt) nt = t;  // may still reach a later quad
+    }
+    next_t = nt;
+}
+
 // State of one fast pass.  Every ring access uses a compile-time index (U is a template parameter
 // and the pass starts on a multiple of the ring length), so the arrays live in registers; the R
 // steps of one loop iteration are expanded with fold expressions, four at a time:
@@ -492,7 +543,7 @@ typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // different 128-byte lines per load instruction; each line is consumed over 4 consecutive blocks
 // and stays in L2 meanwhile, so HBM traffic remains one pass over the samples and there are no
 // barriers or cooperative loads in the loop.
-template <int W1, typename T>
+template <int W1, typename T, bool FLAGGED>
 struct FastPass {
     static constexpr int W2 = 2 * W1, R = RingCfg<W1>::R, XR = RingCfg<W1>::XR;
     static constexpr int NL = R / 16;  // 16-sample lead groups per block
@@ -510,6 +561,8 @@ struct FastPass {
     unsigned cnt1, cnt2;
     unsigned bad1, bad2;
     bool done;
+    RepairCtx rep;   // FLAGGED only
+    int next_t;      // FLAGGED only: smallest event position that can still matter
 
     // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are
     // redirected to the nearest readable group: whatever finite value a position yields is used
@@ -576,13 +629,16 @@ struct FastPass {
         tstep<U0 + 1>();
         tstep<U0 + 2>();
         tstep<U0 + 3>();
+        if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
         // rare: evaluations whose certificate failed are redone with the reference expression
         while (__any((bad1 | bad2) != 0u)) {
             if ((bad1 | bad2) != 0u) {
                 const bool first = bad1 != 0u;
                 const unsigned m = first ? bad1 : bad2;
                 const int u = __ffs((int)m) - 1;
-                const float v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
+                float v;
+                if constexpr (FLAGGED) v = tstat_prefix_at(rep.P, rep.P2, ib + U0 + u, first ? W1 : W2);
+                else v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k == u) {
@@ -620,10 +676,10 @@ struct FastPass {
     }
 };
 
-template <int W1, typename T>
+template <int W1, typename T, bool FLAGGED>
 __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool active, int s, int e, int K,
-                                          DetSnap *snap) {
-    using FP = FastPass<W1, T>;
+                                          DetSnap *snap, const RepairCtx *rep) {
+    using FP = FastPass<W1, T, FLAGGED>;
     constexpr int W2 = FP::W2, R = FP::R, XR = FP::XR, NL = FP::NL;
     if (!__any(active)) return;
     FP f;
@@ -679,6 +735,15 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
     f.wprev = 0ull;
     const int wlo = s >> 6, whi = (e + 63) >> 6;
     f.done = !active;
+    if constexpr (FLAGGED) {
+        f.rep = *rep;
+        // first event whose influence [t-W2+1, t+W2] is not entirely before this pass' first index
+        f.next_t = 0x7fffffff;
+        for (int k = 0; k < f.rep.nev; ++k) {
+            const int t = f.rep.ev[k];
+            if (t + W2 >= i_begin && t < f.next_t) f.next_t = t;
+        }
+    }
     const int main_steps = lead + K;
     f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
     f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
@@ -732,7 +797,7 @@ struct HistRing {
     static constexpr int LDS_BYTES = 64 * ROW_BYTES;
 };
 
-template <int W1, typename T>
+template <int W1, typename T, bool FLAGGED>
 struct FastPassL {
     static constexpr int W2 = 2 * W1;
     double A1, A1q, B1, B1q, A2, A2q, B2, B2q;
@@ -749,6 +814,8 @@ struct FastPassL {
     unsigned cnt1, cnt2;
     unsigned bad1, bad2;
     bool done;
+    RepairCtx rep;   // FLAGGED only
+    int next_t;      // FLAGGED only: smallest event position that can still matter
 
     __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
         int p = pos > hi - 16 ? hi - 16 : pos;
@@ -816,12 +883,15 @@ struct FastPassL {
         tstep<U0 + 1>();
         tstep<U0 + 2>();
         tstep<U0 + 3>();
+        if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
         while (__any((bad1 | bad2) != 0u)) {
             if ((bad1 | bad2) != 0u) {
                 const bool first = bad1 != 0u;
                 const unsigned m = first ? bad1 : bad2;
                 const int u = __ffs((int)m) - 1;
-                const float v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
+                float v;
+                if constexpr (FLAGGED) v = tstat_prefix_at(rep.P, rep.P2, ib + U0 + u, first ? W1 : W2);
+                else v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k == u) {
@@ -840,10 +910,10 @@ struct FastPassL {
     }
 };
 
-template <int W1, typename T>
+template <int W1, typename T, bool FLAGGED>
 __device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_lds, int lead, bool active, int s,
-                                              int e, int K, DetSnap *snap) {
-    using FP = FastPassL<W1, T>;
+                                              int e, int K, DetSnap *snap, const RepairCtx *rep) {
+    using FP = FastPassL<W1, T, FLAGGED>;
     constexpr int W2 = FP::W2, R = 16;
     if (!__any(active)) return;
     FP f;
@@ -899,6 +969,15 @@ __device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_l
     f.wprev = 0ull;
     const int wlo = s >> 6, whi = (e + 63) >> 6;
     f.done = !active;
+    if constexpr (FLAGGED) {
+        f.rep = *rep;
+        // first event whose influence [t-W2+1, t+W2] is not entirely before this pass' first index
+        f.next_t = 0x7fffffff;
+        for (int k = 0; k < f.rep.nev; ++k) {
+            const int t = f.rep.ev[k];
+            if (t + W2 >= i_begin && t < f.next_t) f.next_t = t;
+        }
+    }
     const int main_steps = lead + K;
     f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
     f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
@@ -943,8 +1022,9 @@ __device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_l
 }
 
 // speculative pass + verification / re-run loop (one inlined copy of pass_fast)
-template <int W1, typename T>
-__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap, char *hist_lds) {
+template <int W1, typename T, bool FLAGGED>
+__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap, char *hist_lds,
+                                 const RepairCtx *rep) {
     const int n = (int)rc.n;
     if (n <= 0) return true;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 64 readable samples
@@ -961,8 +1041,8 @@ __device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *s
     int lead = (W1 == 7) ? SGK_LEAD_RNA : LEAD;  // RNA events are ~5x longer: states converge later
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
-        if constexpr (USE_LDS_HISTORY(W1)) pass_fast_lds<W1, T>(rc, hist_lds, lead, run, s, e, K, snap);
-        else pass_fast<W1, T>(rc, lead, run, s, e, K, snap);
+        if constexpr (USE_LDS_HISTORY(W1)) pass_fast_lds<W1, T, FLAGGED>(rc, hist_lds, lead, run, s, e, K, snap, rep);
+        else pass_fast<W1, T, FLAGGED>(rc, lead, run, s, e, K, snap, rep);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
         const DetState pe = snap->at_e[c > 0 ? c - 1 : 0];
@@ -1234,22 +1314,28 @@ __device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_
     if (__any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
 }
 
-// sequential double prefix sums, src/events.c:293-303: strictly in order, by one lane.
-// The wave converts a tile to pA (and float squares) in parallel into LDS; lane 0 then runs
-// the two dependent double accumulations and writes sum[i+1], sumsq[i+1].
+// Sequential double prefix sums, src/events.c:293-303: strictly in order.  Per 2048-sample tile the wave
+// converts to pA (and float squares) in parallel into LDS; lane 0 runs the dependent chain of sums and
+// lane 1 the chain of squares, writing the prefix values to LDS; then all lanes store the tile to the
+// scratch arrays (coalesced) and test every addition for exactness (TwoSum residual): positions where
+// the scan rounded are the "events" the repair logic needs.
 constexpr int SP_TILE = 2048;
 struct PrefixLds {
     float x[SP_TILE];
     float xq[SP_TILE];
+    double ps[SP_TILE + 1];   // ps[0] = prefix before the tile, ps[k+1] = prefix after sample k
+    double pq[SP_TILE + 1];
+};
+struct EventList {
+    int ev[REP_MAX_EVENTS];
+    int count;
 };
 template <typename T>
-__device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLds *L) {
+__device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLds *L, EventList *E) {
     const int l = lane_id();
     const int64_t n = rc.n;
-    // lane 0 runs the chain of sums, lane 1 the chain of squares: each is strictly sequential
     double acc = 0.0;
-    double *out = (l == 0) ? P : P2;
-    if (l < 2) out[0] = 0.0;
+    if (l == 0) { P[0] = 0.0; P2[0] = 0.0; E->count = 0; }
     for (int64_t tb = 0; tb < n; tb += SP_TILE) {
         const int m = (n - tb) < SP_TILE ? (int)(n - tb) : SP_TILE;
         __syncthreads();
@@ -1261,6 +1347,8 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
         __syncthreads();
         if (l < 2) {
             const float *src = (l == 0) ? L->x : L->xq;
+            double *dst = (l == 0) ? L->ps : L->pq;
+            dst[0] = acc;
             int k = 0;
             for (; k + 8 <= m; k += 8) {
                 float v[8];
@@ -1269,16 +1357,39 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     acc = acc + (double)v[u];
-                    out[tb + k + u + 1] = acc;
+                    dst[k + u + 1] = acc;
                 }
             }
             for (; k < m; ++k) {
                 acc = acc + (double)src[k];
-                out[tb + k + 1] = acc;
+                dst[k + 1] = acc;
+            }
+        }
+        __syncthreads();
+        for (int k = l; k < m; k += 64) {
+            const double s0 = L->ps[k], s1 = L->ps[k + 1], q0 = L->pq[k], q1 = L->pq[k + 1];
+            P[tb + k + 1] = s1;
+            P2[tb + k + 1] = q1;
+            const double ys = (double)L->x[k], yq = (double)L->xq[k];
+            const double bs = s1 - s0, bq = q1 - q0;
+            const double es = (s0 - (s1 - bs)) + (ys - bs), eq = (q0 - (q1 - bq)) + (yq - bq);
+            if (es != 0.0 || eq != 0.0) {
+                const int idx = atomicAdd(&E->count, 1);
+                if (idx < REP_MAX_EVENTS) E->ev[idx] = (int)(tb + k);
             }
         }
     }
     __threadfence();
+    __syncthreads();
+    if (l == 0) {  // sort the (few) event positions
+        const int m = E->count < REP_MAX_EVENTS ? E->count : REP_MAX_EVENTS;
+        for (int i = 1; i < m; ++i) {
+            const int v = E->ev[i];
+            int j = i - 1;
+            while (j >= 0 && E->ev[j] > v) { E->ev[j + 1] = E->ev[j]; --j; }
+            E->ev[j + 1] = v;
+        }
+    }
     __syncthreads();
 }
 
@@ -1290,7 +1401,7 @@ __global__ __launch_bounds__(64, 3) void k_event_detect(EvArgs a) {
     __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const bool ok = detect_read_fast<W1, T>(rc, a.hdr, &snap, hist);
+    const bool ok = detect_read_fast<W1, T, false>(rc, a.hdr, &snap, hist, nullptr);
     if (lane_id() == 0) a.flags[r] = ok ? 0 : 2;  // 2: declined by the fast pass -> exact fallback
 }
 
@@ -1305,6 +1416,9 @@ __global__ __launch_bounds__(64) void k_event_build(EvArgs a) {
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
     __shared__ PrefixLds L;
+    __shared__ DetSnap snap;
+    __shared__ EventList events;
+    __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
     double *P = a.scratch + (uint64_t)blockIdx.x * a.scratch_stride;
     double *P2 = P + a.scratch_stride / 2;
     const uint32_t nf = a.hdr->n_flagged;
@@ -1315,10 +1429,19 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
         if (w >= nf) break;
         const uint32_t r = a.flag_list[w];
         ReadCtx<T> rc = make_ctx<T>(a, r);
-        seq_prefix<T>(rc, P, P2, &L);
+        seq_prefix<T>(rc, P, P2, &L, &events);
         rc.P = P;
         rc.P2 = P2;
-        detect_read<W1, T, true>(rc, nullptr, a.hdr);
+        // fast pass + event-local repair; reads the fast pass cannot take (odd alignment, no room around
+        // the read) go through the generic pass that takes every window sum from the prefix arrays
+        RepairCtx rep;
+        rep.P = P;
+        rep.P2 = P2;
+        rep.ev = events.ev;
+        rep.nev = events.count < REP_MAX_EVENTS ? events.count : REP_MAX_EVENTS;
+        rep.all_dirty = events.count > REP_MAX_EVENTS;
+        const bool fast = detect_read_fast<W1, T, true>(rc, a.hdr, &snap, hist, &rep);
+        if (!fast) detect_read<W1, T, true>(rc, nullptr, a.hdr);
         __threadfence();
         __syncthreads();
         build_read_prefix<T>(a, rc, r);
