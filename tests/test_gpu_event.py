@@ -87,3 +87,20 @@ def test_pa_matches_oracle(gpu, oracle, sp1):
     for r, raw in enumerate(reads):
         exp = oracle.pa(raw, dig[r], off[r], rng[r])
         np.testing.assert_array_equal(got[r].view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_event_guard_failing_reads_repair_path(gpu, oracle, rna):
+    """Reads with tiny-|pA| samples make the reference's sequential double prefix sums round; the
+    fallback kernel must reproduce exactly that (event-local repair, and the all-dirty mode when a
+    read has more rounding events than the repair list holds)."""
+    reads, dig, off, rng = gpu.synth_reads_host(8, 100000, seed=41, kind=rna)
+    tiny = [int(1 - off[r]) for r in range(8)]   # raw + offset == 1 -> |pA| = 0.17
+    for r, positions in enumerate([[50000], [1599], [1600], [99990], [7], [30000, 30001, 70000],
+                                   list(range(1000, 99000, 1000)),          # ~98 tiny samples -> all-dirty mode
+                                   []]):
+        for p in positions:
+            reads[r][p] = tiny[r]
+    got, status = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+    assert status.n_fallback_reads >= 7
