@@ -388,33 +388,36 @@ struct RingCfg {
 
 template <int W1>
 __device__ __forceinline__ int det_step_sel(DetState &d, int i, float v1, float v2) {
+    // Pure boolean algebra on the comparison results (they stay in scalar mask registers) and one
+    // select per state variable; no data-dependent branches.
     constexpr int W2 = 2 * W1;
     constexpr float ph = DetParam<W1>::ph, thr1 = DetParam<W1>::thr1, thr2 = DetParam<W1>::thr2;
-    int emit = -1;
+    int emit;
     {   // short detector (masked_to == 0: only index 0 is skipped)
         const bool on = i > 0;
         const bool inpk = d.sp >= 0;
         const bool lower = v1 < d.sv;
         const bool rise = (v1 - d.sv) > ph;
         const bool higher = v1 > d.sv;
-        const bool upd = on && (inpk ? higher : (lower || rise));
-        const bool pos = on && (inpk ? higher : (!lower && rise));
+        const bool c1 = on & !inpk;   // no peak recorded yet
+        const bool c2 = on & inpk;    // in a peak
+        const bool upd = (c2 & higher) | (c1 & (lower | rise));
+        const bool pos = (c2 & higher) | (c1 & !lower & rise);
         const float sv = upd ? v1 : d.sv;
         const int sp = pos ? i : d.sp;
-        const bool c2 = on && inpk;
         const bool strong = sv > thr1;
-        if (c2 && strong) {  // events.c:414-422
-            d.lmask = sp + W1;
-            d.lp = -1;
-            d.lv = FLT_MAX;
-            d.lvalid = 0;
-        }
-        const bool val = (d.svalid != 0) || (c2 && ((sv - v1) > ph) && strong);
-        const bool em = c2 && val && (i - sp) > W1 / 2;
-        emit = em ? sp : emit;
+        const bool dom = c2 & strong;  // events.c:414-422: the short detector dominates the long one
+        d.lmask = dom ? sp + W1 : d.lmask;
+        d.lp = dom ? -1 : d.lp;
+        d.lv = dom ? FLT_MAX : d.lv;
+        const int lvalid0 = dom ? 0 : d.lvalid;
+        const bool val = (d.svalid != 0) | (c2 & ((sv - v1) > ph) & strong);
+        const bool em = c2 & val & ((i - sp) > W1 / 2);
+        emit = em ? sp : -1;
         d.sp = em ? -1 : sp;
         d.sv = em ? v1 : sv;
-        d.svalid = (val && !em) ? 1 : 0;
+        d.svalid = (val & !em) ? 1 : 0;
+        d.lvalid = lvalid0;
     }
     {   // long detector
         const bool on = !(d.lmask >= i);
@@ -422,17 +425,18 @@ __device__ __forceinline__ int det_step_sel(DetState &d, int i, float v1, float 
         const bool lower = v2 < d.lv;
         const bool rise = (v2 - d.lv) > ph;
         const bool higher = v2 > d.lv;
-        const bool upd = on && (inpk ? higher : (lower || rise));
-        const bool pos = on && (inpk ? higher : (!lower && rise));
+        const bool c1 = on & !inpk;
+        const bool c2 = on & inpk;
+        const bool upd = (c2 & higher) | (c1 & (lower | rise));
+        const bool pos = (c2 & higher) | (c1 & !lower & rise);
         const float lv = upd ? v2 : d.lv;
         const int lp = pos ? i : d.lp;
-        const bool c2 = on && inpk;
-        const bool val = (d.lvalid != 0) || (c2 && ((lv - v2) > ph) && lv > thr2);
-        const bool em = c2 && val && (i - lp) > W2 / 2;
+        const bool val = (d.lvalid != 0) | (c2 & ((lv - v2) > ph) & (lv > thr2));
+        const bool em = c2 & val & ((i - lp) > W2 / 2);
         emit = em ? lp : emit;
         d.lp = em ? -1 : lp;
         d.lv = em ? v2 : lv;
-        d.lvalid = (val && !em) ? 1 : 0;
+        d.lvalid = (val & !em) ? 1 : 0;
     }
     return emit;
 }
@@ -611,13 +615,14 @@ struct FastPass {
         const int i = ib + U;
         if (!done && (unsigned)i < (unsigned)n) {
             const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
-            if (p >= s && p < e) {
-                const int wi = p >> 6;
-                const unsigned long long bit = 1ull << (p & 63);
-                if (wi == wb) wcur |= bit;
-                else if (wi == wb - 1) wprev |= bit;
-                else bm[wi] |= bit;  // older word: already retired, owned by this lane only
-            }
+            // record the emitted peak if this lane owns its position (selects; the store is the rare case
+            // of a peak older than the two bitmap words held in registers)
+            const bool own = (p >= s) & (p < e);
+            const int wi = p >> 6;
+            const unsigned long long bit = 1ull << (p & 63);
+            wcur |= (own & (wi == wb)) ? bit : 0ull;
+            wprev |= (own & (wi == wb - 1)) ? bit : 0ull;
+            if (own & (wi < wb - 1)) bm[wi] |= bit;  // already retired word, owned by this lane only
         }
     }
     // four indices U0..U0+3
@@ -631,6 +636,7 @@ struct FastPass {
         tstep<U0 + 3>();
         if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
         // rare: evaluations whose certificate failed are redone with the reference expression
+        if (__any((bad1 | bad2) != 0u))
         while (__any((bad1 | bad2) != 0u)) {
             if ((bad1 | bad2) != 0u) {
                 const bool first = bad1 != 0u;
@@ -866,13 +872,14 @@ struct FastPassL {
         const int i = ib + U;
         if (!done && (unsigned)i < (unsigned)n) {
             const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
-            if (p >= s && p < e) {
-                const int wi = p >> 6;
-                const unsigned long long bit = 1ull << (p & 63);
-                if (wi == wb) wcur |= bit;
-                else if (wi == wb - 1) wprev |= bit;
-                else bm[wi] |= bit;
-            }
+            // record the emitted peak if this lane owns its position (selects; the store is the rare case
+            // of a peak older than the two bitmap words held in registers)
+            const bool own = (p >= s) & (p < e);
+            const int wi = p >> 6;
+            const unsigned long long bit = 1ull << (p & 63);
+            wcur |= (own & (wi == wb)) ? bit : 0ull;
+            wprev |= (own & (wi == wb - 1)) ? bit : 0ull;
+            if (own & (wi < wb - 1)) bm[wi] |= bit;  // already retired word, owned by this lane only
         }
     }
     template <int U0>
@@ -884,6 +891,7 @@ struct FastPassL {
         tstep<U0 + 2>();
         tstep<U0 + 3>();
         if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
+        if (__any((bad1 | bad2) != 0u))
         while (__any((bad1 | bad2) != 0u)) {
             if ((bad1 | bad2) != 0u) {
                 const bool first = bad1 != 0u;
