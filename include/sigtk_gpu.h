@@ -173,6 +173,18 @@ size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t
 int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
                size_t workspace_bytes, void *stream);
 
+/* ---- svb-zd signal decode on the device ------------------------------- */
+/* Expands BLOW5 svb-zd signal blobs (slow5lib/src/slow5_press.c:1116-1146: u32 count, streamvbyte
+ * keys + data of the zigzag deltas) into int16 samples, one wavefront per read.  The record layer
+ * (zlib) stays on the host; files written with signal compression svb-zd hand the blob over as it
+ * sits in the record.  blobs: device buffer; blob_offsets/blob_lengths: byte offset and byte length
+ * of each read's blob (the length INCLUDES the 4-byte count); samples/offsets/lengths as in
+ * sgk_batch_t (lengths[r] must equal the blob's count); status[r]: 0 ok, 1 count mismatch,
+ * 2 truncated / inconsistent blob (the read's samples are then undefined). */
+int sgk_svbzd_decode(const uint8_t *blobs, const uint64_t *blob_offsets, const uint32_t *blob_lengths,
+                     uint32_t n_reads, int16_t *samples, const uint64_t *offsets, const uint32_t *lengths,
+                     uint32_t *status, void *stream);
+
 /* ---- synthetic reads (BASELINE configs 2-5) ---------------------------- */
 /* Deterministic counter-based generator, identical on host and device (integer only).
  * kind 0: DNA-like (mean dwell 9 samples); kind 1: RNA-like (mean dwell 36, adaptor +

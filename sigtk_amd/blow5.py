@@ -192,5 +192,35 @@ def write_blow5(path: str, reads: Sequence[Read], attrs: Dict[str, str] | None =
         fh.write(EOF_MARK)
 
 
+def read_signal_blobs(path: str):
+    """-> list of (Read with an EMPTY raw array, svb-zd blob bytes): the signal exactly as it sits in
+    the (inflated) record, for the GPU decoder (sgk_svbzd_decode).  Only for signal_press == 1 files."""
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if buf[:6] != MAGIC:
+        raise ValueError("not a BLOW5 file")
+    record_press = buf[9]
+    signal_press = buf[14]
+    if signal_press != 1:
+        raise ValueError("file does not use svb-zd signal compression")
+    (hsize,) = struct.unpack_from("<I", buf, 64)
+    pos = 68 + hsize
+    out = []
+    while buf[pos : pos + 5] != EOF_MARK or pos + 5 != len(buf):
+        (size,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        rec = buf[pos : pos + size]
+        pos += size
+        if record_press == 1:
+            rec = zlib.decompress(rec)
+        (idl,) = struct.unpack_from("<H", rec, 0)
+        rid = rec[2 : 2 + idl].decode("ascii")
+        p = 2 + idl
+        rg, dig, off, rng, sr, ln = struct.unpack_from("<IddddQ", rec, p)
+        p += 44
+        out.append((Read(rid, rg, dig, off, rng, sr, np.zeros(0, dtype=np.int16)), bytes(rec[p : p + ln])))
+    return out
+
+
 def iter_reads(path: str) -> Iterator[Read]:
     yield from read_blow5(path).reads

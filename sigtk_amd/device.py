@@ -180,3 +180,29 @@ def pa(b: DeviceReads, out: torch.Tensor) -> None:
     L = api.load_library()
     view = b.view()
     api.check(L.sgk_pa(C.byref(view), _ptr(out), _stream_ptr()), "sgk_pa")
+
+
+# ---------------------------------------------------------------------- svb-zd decode (device API)
+
+def svbzd_decode(blobs, counts, device: torch.device):
+    """Decode svb-zd signal blobs (bytes objects) on the device.
+    -> (DeviceReads with the decoded samples and zeroed scaling, status tensor [n_reads] int32)"""
+    L = api.load_library()
+    n = len(blobs)
+    blens = np.array([len(b) for b in blobs], dtype=np.uint32)
+    boffs = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        boffs[1:] = np.cumsum((blens[:-1].astype(np.int64) + 15) // 16 * 16)  # 16-byte aligned blob starts
+    total = int(boffs[-1] + blens[-1]) if n else 0
+    host = np.zeros(max(total + 16, 16), dtype=np.uint8)
+    for i, b in enumerate(blobs):
+        host[int(boffs[i]):int(boffs[i]) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    d_blobs = torch.from_numpy(host).to(device)
+    d_boffs = torch.from_numpy(boffs).to(device)
+    d_blens = torch.from_numpy(blens.astype(np.int32)).to(device)
+    reads = alloc_reads(np.asarray(counts, dtype=np.int64), device)
+    status = torch.full((max(n, 1),), -1, dtype=torch.int32, device=device)
+    api.check(L.sgk_svbzd_decode(_ptr(d_blobs), _ptr(d_boffs), _ptr(d_blens), n, _ptr(reads.samples),
+                                 _ptr(reads.offsets), _ptr(reads.lengths), _ptr(status), _stream_ptr()),
+              "sgk_svbzd_decode")
+    return reads, status
