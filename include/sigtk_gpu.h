@@ -177,7 +177,8 @@ int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *ou
 /* Expands BLOW5 svb-zd signal blobs (slow5lib/src/slow5_press.c:1116-1146: u32 count, streamvbyte
  * keys + data of the zigzag deltas) into int16 samples, one wavefront per read.  The record layer
  * (zlib) stays on the host; files written with signal compression svb-zd hand the blob over as it
- * sits in the record.  blobs: device buffer; blob_offsets/blob_lengths: byte offset and byte length
+ * sits in the record.  blobs: device buffer, readable up to its size rounded up to a multiple of 4
+ * bytes (the kernel uses aligned 4-byte loads); blob_offsets/blob_lengths: byte offset and byte length
  * of each read's blob (the length INCLUDES the 4-byte count); samples/offsets/lengths as in
  * sgk_batch_t (lengths[r] must equal the blob's count); status[r]: 0 ok, 1 count mismatch,
  * 2 truncated / inconsistent blob (the read's samples are then undefined). */

@@ -15,7 +15,7 @@ namespace sgk {
 
 constexpr int SVB_VPL = 16;                 // values per lane per tile
 constexpr int SVB_TILE = 64 * SVB_VPL;      // values per tile
-constexpr int SVB_STAGE = SVB_TILE * 4 + 16;  // worst-case data bytes of a tile (+ slack for the 8-byte reads)
+constexpr int SVB_STAGE = SVB_TILE * 4 + 16;  // worst-case data bytes of a tile (+ alignment lead-in)
 
 struct SvbArgs {
     const uint8_t *blobs;
@@ -73,13 +73,18 @@ __global__ __launch_bounds__(64) void k_svbzd_decode(SvbArgs a) {
             if (l == 0) a.status[r] = 2;
             return;
         }
-        // stage the tile's data bytes in LDS (byte loop over a coalesced range; ~1.5 KB per tile)
+        // stage the tile's data bytes in LDS with aligned dword loads (the byte range is contiguous;
+        // `shift` bytes of lead-in keep the global loads 4-byte aligned)
+        const uint8_t *src = data + cursor;
+        const int shift = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
+        const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src - shift);
+        const int ndw = (tile_bytes + shift + 3) >> 2;
         __syncthreads();
-        for (int b = l; b < tile_bytes; b += 64) stage[b] = data[cursor + b];
+        for (int b = l; b < ndw; b += 64) reinterpret_cast<uint32_t *>(stage)[b] = src32[b];
         __syncthreads();
         // extract, zigzag-decode, lane-local prefix sum
         int32_t d[SVB_VPL];
-        int pos = lane_off;
+        int pos = lane_off + shift;
         int32_t run = 0;
 #pragma unroll
         for (int k = 0; k < SVB_VPL; ++k) {
