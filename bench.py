@@ -120,8 +120,11 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = S * world / (elapsed / args.steps)
-        kern = {k: v[0] / max(v[1], 1) for k, v in prof.items()}  # avg ms per launch
-        path_ms = sum(kern.values())
+        # per-step device time of each kernel (HIP events on the stream it was launched on, summed over
+        # its launches in a step) and of the whole path ("path:event": first launch -> last kernel done;
+        # the builder overlaps the detector on a side stream, so the path is shorter than the sum)
+        kern = {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("path:")}
+        path_ms = prof["path:event"][0] / args.steps if "path:event" in prof else sum(kern.values())
         dominant = max(kern, key=kern.get) if kern else None
         alg_bytes = 2 * S + 16 * E + 40 * R
         achieved = alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0

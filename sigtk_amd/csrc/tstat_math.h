@@ -128,6 +128,56 @@ SGK_TM float sgk_tstat_try(double A, double A2, double B, double B2, bool &ok) {
     return tq;
 }
 
+// Both windows of one index at once (W and 2W, as in both detector presets).  On the device the f32
+// part of the two expression trees is evaluated on 2-vectors so that it maps onto the packed f32
+// instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per issue slot);
+// every lane of a packed operation is the same correctly rounded IEEE operation as its scalar form,
+// so the results are those of sgk_tstat_try<W> and sgk_tstat_try<2W>.
+template <int W>
+SGK_TM void sgk_tstat_try_pair(double A1, double A1q, double B1, double B1q, double A2, double A2q, double B2,
+                               double B2q, float &v1, float &v2, bool &ok1, bool &ok2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr float FMIN = 1.17549435e-38f;
+    const f2 d = {(float)W, (float)(2 * W)};
+    const f2 r = {1.0f / (float)W, 1.0f / (float)(2 * W)};
+    auto div2 = [&](f2 a) -> f2 {
+        const f2 q = a * r;
+        const f2 rem = __builtin_elementwise_fma(-q, d, a);
+        return __builtin_elementwise_fma(rem, r, q);
+    };
+    const f2 sum2 = {(float)B1, (float)B2};
+    const f2 sumsq2 = {(float)B1q, (float)B2q};
+    const f2 mean1 = {(float)sgk_div_f64<W>(A1), (float)sgk_div_f64<2 * W>(A2)};
+    const f2 mean2 = div2(sum2);
+    const f2 m1sq = mean1 * mean1;
+    const f2 m2sq = mean2 * mean2;
+    const f2 q2 = div2(sumsq2);
+    double acc1 = sgk_div_f64<W>(A1q);
+    double acc2 = sgk_div_f64<2 * W>(A2q);
+    acc1 = acc1 - (double)m1sq.x;
+    acc2 = acc2 - (double)m1sq.y;
+    acc1 = acc1 + (double)q2.x;
+    acc2 = acc2 + (double)q2.y;
+    acc1 = acc1 - (double)m2sq.x;
+    acc2 = acc2 - (double)m2sq.y;
+    f2 cv = {fmaxf((float)acc1, FMIN), fmaxf((float)acc2, FMIN)};
+    const f2 delta = mean2 - mean1;
+    const f2 cvd = div2(cv);
+    const bool fl1 = cv.x == FMIN, fl2 = cv.y == FMIN;
+    const float cvw1 = fl1 ? FMIN / (float)W : cvd.x;
+    const float cvw2 = fl2 ? FMIN / (float)(2 * W) : cvd.y;
+    bool t1ok, t2ok;
+    v1 = sgk_tail_fast(delta.x, cvw1, t1ok);
+    v2 = sgk_tail_fast(delta.y, cvw2, t2ok);
+    ok1 = (fminf(fminf(fabsf(sum2.x), sumsq2.x), fl1 ? 1.0f : cv.x) >= SGK_F32_TINY) & t1ok;
+    ok2 = (fminf(fminf(fabsf(sum2.y), sumsq2.y), fl2 ? 1.0f : cv.y) >= SGK_F32_TINY) & t2ok;
+#else
+    v1 = sgk_tstat_try<W>(A1, A1q, B1, B1q, ok1);
+    v2 = sgk_tstat_try<2 * W>(A2, A2q, B2, B2q, ok2);
+#endif
+}
+
 template <int W>
 SGK_TM float sgk_tstat_fast(double A, double A2, double B, double B2) {
     bool ok;
