@@ -476,12 +476,18 @@ struct Lead16<int16_t> {
         const float shifted = (float)v + sc.offf;
         return shifted * sc.unit;
     }
+    template <int U>
+    __device__ __forceinline__ int16_t raw() const {
+        return (int16_t)((U & 1) ? (w[U / 2] >> 16) : (w[U / 2] & 0xffffu));
+    }
 };
 template <>
 struct Lead16<float> {
     float w[16];
     template <int U>
     __device__ __forceinline__ float get(const Scale &) const { return w[U]; }
+    template <int U>
+    __device__ __forceinline__ float raw() const { return w[U]; }
 };
 typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -833,10 +839,10 @@ struct FastPassL {
         for (int k = 0; k < NV; ++k) v[k] = src[k];
         __builtin_memcpy(dst.w, v, sizeof(dst.w));
     }
-    __device__ __forceinline__ float hist(int pos) const {  // x[pos], pos within the resident window
-        const T v = *reinterpret_cast<const T *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
-        return to_pa(v, sc);
+    __device__ __forceinline__ T raw_hist(int pos) const {  // stored sample at pos (within the resident window)
+        return *reinterpret_cast<const T *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
     }
+    __device__ __forceinline__ float hist(int pos) const { return to_pa(raw_hist(pos), sc); }
     __device__ __forceinline__ void store_group(const Lead16<T> &g, int pos) {  // x[pos..pos+16), pos-W2 multiple of 16
         uint32_t *dst = reinterpret_cast<uint32_t *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
         constexpr int ND = 16 * (int)sizeof(T) / 4;
@@ -850,21 +856,24 @@ struct FastPassL {
     __device__ __forceinline__ void tstep() {
         const int i = ib + U;
         bool ok1, ok2;
-        const float v1 = sgk_tstat_try<W1>(A1, A1q, B1, B1q, ok1);
-        const float v2 = sgk_tstat_try<W2>(A2, A2q, B2, B2q, ok2);
+        float v1, v2;
+        sgk_tstat_try_pair<W1>(A1, A1q, B1, B1q, A2, A2q, B2, B2q, v1, v2, ok1, ok2);
         const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
         t1[U & 3] = in1 ? v1 : 0.0f;
         t2[U & 3] = in2 ? v2 : 0.0f;
         bad1 |= (in1 && !ok1) ? (1u << (U & 3)) : 0u;
         bad2 |= (in2 && !ok2) ? (1u << (U & 3)) : 0u;
-        // slide the four windows from index i to i+1 (exact in double)
-        const float xp2 = cur.template get<U>(sc);  // x[i + 2*W1]
-        const float xm2 = hist(i - W2), xm1 = hist(i - W1), x0 = hist(i), xp1 = hist(i + W1);
+        // slide the four windows from index i to i+1 (exact in double); pA conversion and squares of
+        // the five samples involved on packed pairs
+        const f32x2 xm = to_pa2(raw_hist(i - W2), raw_hist(i - W1), sc);        // x[i-2W1], x[i-W1]
+        const f32x2 xp = to_pa2(raw_hist(i + W1), cur.template raw<U>(), sc);   // x[i+W1], x[i+2W1]
+        const float x0 = to_pa(raw_hist(i), sc);
+        const f32x2 xmq = xm * xm, xpq = xp * xp;
         const double d0 = (double)x0, d0q = (double)(x0 * x0);
-        A1 = (A1 + d0) - (double)xm1;  A1q = (A1q + d0q) - (double)(xm1 * xm1);
-        A2 = (A2 + d0) - (double)xm2;  A2q = (A2q + d0q) - (double)(xm2 * xm2);
-        B1 = (B1 + (double)xp1) - d0;  B1q = (B1q + (double)(xp1 * xp1)) - d0q;
-        B2 = (B2 + (double)xp2) - d0;  B2q = (B2q + (double)(xp2 * xp2)) - d0q;
+        A1 = (A1 + d0) - (double)xm.y;  A1q = (A1q + d0q) - (double)xmq.y;
+        A2 = (A2 + d0) - (double)xm.x;  A2q = (A2q + d0q) - (double)xmq.x;
+        B1 = (B1 + (double)xp.x) - d0;  B1q = (B1q + (double)xpq.x) - d0q;
+        B2 = (B2 + (double)xp.y) - d0;  B2q = (B2q + (double)xpq.y) - d0q;
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int U>

@@ -122,6 +122,16 @@ __device__ inline float to_pa(int16_t raw, const Scale &s) {
     return shifted * s.unit;
 }
 __device__ inline float to_pa(float pa, const Scale &) { return pa; }
+// two samples at once: the add and the multiply map onto v_pk_add_f32 / v_pk_mul_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 to_pa2(int16_t r0, int16_t r1, const Scale &s) {
+    const f32x2 raw = {(float)r0, (float)r1};
+    const f32x2 off = {s.offf, s.offf};
+    const f32x2 unit = {s.unit, s.unit};
+    const f32x2 shifted = raw + off;
+    return shifted * unit;
+}
+__device__ inline f32x2 to_pa2(float p0, float p1, const Scale &) { return f32x2{p0, p1}; }
 
 #endif  // __HIPCC__
 
