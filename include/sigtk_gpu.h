@@ -65,6 +65,7 @@ extern "C" {
 #define SGK_ERR_CAPACITY (-5)   /* an output arena slot range was too small             */
 #define SGK_ERR_ALIGN (-6)      /* samples buffer not 16-byte aligned                   */
 #define SGK_ERR_NOMEM (-7)      /* host allocation failed                               */
+#define SGK_ERR_FORMAT (-8)     /* malformed compressed signal (svb-zd blob)            */
 
 const char *sgk_strerror(int code);
 const char *sgk_version(void);
@@ -237,6 +238,66 @@ int sgk_jnn_host(const sgk_host_batch_t *batch, int rna, sgk_segs_host_t *out);
 void sgk_segs_host_free(sgk_segs_host_t *s);
 
 int sgk_prefix_host(const sgk_host_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out /* host, n_reads */);
+
+/* ---- pipelined host jobs (the batched, overlapped replacement of the ------
+ *      reference's one-record-at-a-time loop, src/cmain.c:118-120) ---------------------
+ * A job owns pinned host staging, device buffers, a private stream and pinned result buffers
+ * for one batch; all of them only grow, so recycled jobs stop allocating.  Typical use, with
+ * several jobs in flight so that reading/inflating, PCIe, kernels and formatting overlap:
+ *     sgk_job_begin(job, n, lengths, SGK_SIGNAL_SVBZD, blob_bytes, &in);
+ *     ... reader threads copy blob r to in.blobs + in.blob_offsets[r], fill in.digitisation[r] ...
+ *     sgk_job_submit(job, SGK_TOOL_EVENT, rna, pore, 0);       // returns at once
+ *     ... (another thread) sgk_job_wait(job); sgk_job_output(job, &out); format rows ...
+ * begin/submit/wait may be called from different threads, one at a time per job. */
+typedef struct sgk_job sgk_job_t;
+
+#define SGK_TOOL_PA 0
+#define SGK_TOOL_EVENT 1
+#define SGK_TOOL_STAT 2
+#define SGK_TOOL_JNN 3
+#define SGK_TOOL_PREFIX 4
+
+#define SGK_SIGNAL_INT16 0 /* caller stages decoded int16 samples                        */
+#define SGK_SIGNAL_SVBZD 1 /* caller stages svb-zd blobs; decoded on the GPU (8f-1)      */
+
+#define SGK_JOB_EVENTS_COMPACT 1 /* submit flag: only event start/length are copied back (event -c) */
+
+typedef struct sgk_job_input {
+    int16_t *samples;             /* pinned host (SGK_SIGNAL_INT16): read r at samples + offsets[r] */
+    uint8_t *blobs;               /* pinned host (SGK_SIGNAL_SVBZD): blob r at blobs + blob_offsets[r] */
+    const uint64_t *offsets;      /* n_reads: sample offset of every read (also indexes the pa output) */
+    const uint64_t *blob_offsets; /* n_reads */
+    double *digitisation, *offset, *range; /* pinned host, n_reads: filled by the caller */
+    uint64_t n_samples;           /* length of the sample arena */
+} sgk_job_input_t;
+
+typedef struct sgk_job_output {
+    uint32_t n_reads;
+    const uint64_t *offsets;        /* as in sgk_job_input_t */
+    const uint32_t *lengths;
+    const uint32_t *decode_status;  /* svb-zd input: per-read status of sgk_svbzd_decode, else NULL */
+    const float *pa;                /* pa: pa[offsets[r] + i] */
+    const uint64_t *slots;          /* event / jnn: arena slot of read r's first item (n_reads+1) */
+    const uint32_t *counts;         /* event / jnn: items of read r */
+    const uint32_t *ev_start, *ev_length;
+    const float *ev_mean, *ev_stdv; /* NULL with SGK_JOB_EVENTS_COMPACT */
+    const int32_t *seg_x, *seg_y;
+    const sgk_stat_rec_t *stat;
+    const sgk_prefix_rec_t *prefix;
+    sgk_event_status_t event_status;
+} sgk_job_output_t;
+
+int sgk_job_create(int device, sgk_job_t **out);
+void sgk_job_destroy(sgk_job_t *job);
+int sgk_job_device(const sgk_job_t *job);
+/* lengths[r]: samples of read r; blob_bytes[r] (SGK_SIGNAL_SVBZD only): byte length of its blob */
+int sgk_job_begin(sgk_job_t *job, uint32_t n_reads, const uint32_t *lengths, int signal_format,
+                  const uint32_t *blob_bytes, sgk_job_input_t *in);
+int sgk_job_submit(sgk_job_t *job, int tool, int rna, int pore, int flags);
+/* SGK_ERR_FORMAT if a blob did not decode, SGK_ERR_CAPACITY on event-slot overflow */
+int sgk_job_wait(sgk_job_t *job);
+/* valid after sgk_job_wait until the job's next sgk_job_begin */
+int sgk_job_output(const sgk_job_t *job, sgk_job_output_t *out);
 
 /* ---- per-read shims with the reference's own signatures (batch of one) ------------- */
 /* event_t / event_table exactly as src/sigtk.h:55-70 */

@@ -70,6 +70,8 @@ ABI_SYMBOLS = [
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
     "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
     "sgk_segs_host_free", "sgk_prefix_host", "sgk_signal_in_picoamps", "sgk_getevents",
+    "sgk_job_create", "sgk_job_destroy", "sgk_job_device", "sgk_job_begin", "sgk_job_submit", "sgk_job_wait",
+    "sgk_job_output",
 ]
 
 

@@ -146,6 +146,7 @@ const char *sgk_strerror(int code) {
         case SGK_ERR_CAPACITY: return "output arena slot range too small";
         case SGK_ERR_ALIGN: return "buffer not sufficiently aligned";
         case SGK_ERR_NOMEM: return "host allocation failed";
+        case SGK_ERR_FORMAT: return "malformed compressed signal";
         default: return "unknown sgk error";
     }
 }

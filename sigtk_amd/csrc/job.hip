@@ -1,0 +1,369 @@
+// job.hip -- pipelined host jobs (sgk_job_*): the host-side runtime the CLI drives.
+//
+// A job owns everything one batch needs on its way through a GPU: pinned host staging for the
+// signal (raw int16 or svb-zd blobs exactly as they sit in the BLOW5 records), the device
+// buffers, a private HIP stream, and pinned host buffers for the results.  All buffers only ever
+// grow, so a job that is recycled batch after batch stops allocating after the first few batches.
+//
+//   sgk_job_begin   lays the batch out (64-sample aligned reads, head/tail room for the event fast
+//                   path) and hands the caller the pinned staging pointers; reader threads
+//                   inflate/copy records straight into them
+//   sgk_job_submit  enqueues H2D -> (svb-zd decode) -> subtool kernels -> D2H on the job's stream
+//                   and returns immediately
+//   sgk_job_wait    synchronises the stream and validates decode/event status
+//
+// Several jobs in flight (on one or several GPUs) overlap reading/inflating, PCIe transfers,
+// kernels and output formatting; the reference does all of this strictly one record at a time
+// (src/cmain.c:118-120).
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "sgk_common.h"
+
+namespace sgk {
+
+struct GrowDev {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~GrowDev() {
+        if (p) (void)hipFree(p);
+    }
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SGK_OK;
+        if (p) SGK_HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = round_up(bytes + bytes / 8, 4096);  // some slack: batches vary a little
+        SGK_HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return SGK_OK;
+    }
+    template <typename T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+struct GrowPin {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~GrowPin() {
+        if (p) (void)hipHostFree(p);
+    }
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SGK_OK;
+        if (p) SGK_HIP_TRY(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = round_up(bytes + bytes / 8, 4096);
+        SGK_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return SGK_OK;
+    }
+    template <typename T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+}  // namespace sgk
+
+using namespace sgk;
+
+struct sgk_job {
+    int device = 0;
+    hipStream_t st = nullptr;
+    // batch geometry
+    uint32_t n_reads = 0, max_len = 0;
+    uint64_t n_samples = 0, blob_bytes = 0;
+    int fmt = SGK_SIGNAL_INT16;
+    // input staging (pinned) and device mirrors
+    GrowPin h_samples, h_blobs, h_offsets, h_lengths, h_boffs, h_blens, h_dig, h_off, h_rng, h_slots;
+    GrowDev d_samples, d_blobs, d_offsets, d_lengths, d_boffs, d_blens, d_dig, d_off, d_rng, d_slots, d_ws, d_dstat;
+    // outputs: four generic arrays (start/length/mean/stdv | seg x/y | pa | records) + per-read counts
+    GrowDev d_out[4], d_cnt;
+    GrowPin h_out[4], h_cnt, h_dstat;
+    size_t ws_bytes = 0;
+    int tool = -1, flags = 0;
+    bool begun = false, submitted = false;
+    sgk_event_status_t ev_status;
+};
+
+extern "C" {
+
+int sgk_job_create(int device, sgk_job_t **out) {
+    if (!out) return SGK_ERR_ARG;
+    *out = nullptr;
+    const int nd = sgk_device_count();
+    if (nd <= 0) return SGK_ERR_NODEVICE;
+    if (device < 0 || device >= nd) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(device));
+    sgk_job *j = new (std::nothrow) sgk_job();
+    if (!j) return SGK_ERR_NOMEM;
+    j->device = device;
+    memset(&j->ev_status, 0, sizeof j->ev_status);
+    const hipError_t e = hipStreamCreateWithFlags(&j->st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_hip_error(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+        delete j;
+        return SGK_ERR_HIP;
+    }
+    *out = j;
+    return SGK_OK;
+}
+
+void sgk_job_destroy(sgk_job_t *j) {
+    if (!j) return;
+    (void)hipSetDevice(j->device);
+    if (j->st) {
+        (void)hipStreamSynchronize(j->st);
+        (void)hipStreamDestroy(j->st);
+    }
+    delete j;
+}
+
+int sgk_job_device(const sgk_job_t *j) { return j ? j->device : -1; }
+
+int sgk_job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int signal_format,
+                  const uint32_t *blob_bytes, sgk_job_input_t *in) {
+    if (!j || !in || (n_reads && !lengths)) return SGK_ERR_ARG;
+    if (signal_format != SGK_SIGNAL_INT16 && signal_format != SGK_SIGNAL_SVBZD) return SGK_ERR_ARG;
+    if (signal_format == SGK_SIGNAL_SVBZD && n_reads && !blob_bytes) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(j->device));
+    if (j->submitted) return SGK_ERR_ARG;  // previous batch still in flight: sgk_job_wait first
+    const size_t nr = n_reads, nr1 = nr ? nr : 1;
+    int rc;
+    if ((rc = j->h_offsets.ensure(nr1 * 8)) != SGK_OK) return rc;
+    if ((rc = j->h_lengths.ensure(nr1 * 4)) != SGK_OK) return rc;
+    if ((rc = j->h_dig.ensure(nr1 * 8)) != SGK_OK) return rc;
+    if ((rc = j->h_off.ensure(nr1 * 8)) != SGK_OK) return rc;
+    if ((rc = j->h_rng.ensure(nr1 * 8)) != SGK_OK) return rc;
+    uint64_t *offs = j->h_offsets.as<uint64_t>();
+    uint32_t *lens = j->h_lengths.as<uint32_t>();
+    // every read starts on a 64-sample (128-byte) boundary; 256 samples of head room and 64 of tail
+    // room so that the event fast path never has to decline a read (sigtk_gpu.h, "layout")
+    uint64_t o = 256;
+    uint32_t mx = 0;
+    for (size_t r = 0; r < nr; ++r) {
+        if (lengths[r] > 0x7fffffffu) return SGK_ERR_ARG;  // nsample is int32 in the reference (misc.c:20)
+        offs[r] = o;
+        lens[r] = lengths[r];
+        if (lengths[r] > mx) mx = lengths[r];
+        o += round_up(lengths[r], 64);
+    }
+    j->n_reads = n_reads;
+    j->max_len = mx;
+    j->n_samples = o + 64;
+    j->fmt = signal_format;
+    j->blob_bytes = 0;
+    memset(in, 0, sizeof *in);
+    if (signal_format == SGK_SIGNAL_SVBZD) {
+        if ((rc = j->h_boffs.ensure(nr1 * 8)) != SGK_OK) return rc;
+        if ((rc = j->h_blens.ensure(nr1 * 4)) != SGK_OK) return rc;
+        uint64_t *bo = j->h_boffs.as<uint64_t>();
+        uint32_t *bl = j->h_blens.as<uint32_t>();
+        uint64_t b = 0;
+        for (size_t r = 0; r < nr; ++r) {
+            bo[r] = b;
+            bl[r] = blob_bytes[r];
+            b += round_up(blob_bytes[r], 8);
+        }
+        j->blob_bytes = b + 16;  // the decoder reads whole aligned dwords
+        if ((rc = j->h_blobs.ensure(j->blob_bytes)) != SGK_OK) return rc;
+        in->blobs = j->h_blobs.as<uint8_t>();
+        in->blob_offsets = bo;
+    } else {
+        if ((rc = j->h_samples.ensure(j->n_samples * sizeof(int16_t))) != SGK_OK) return rc;
+        in->samples = j->h_samples.as<int16_t>();
+    }
+    in->offsets = offs;
+    in->digitisation = j->h_dig.as<double>();
+    in->offset = j->h_off.as<double>();
+    in->range = j->h_rng.as<double>();
+    in->n_samples = j->n_samples;
+    j->begun = true;
+    return SGK_OK;
+}
+
+static int h2d(GrowDev &d, const GrowPin &h, size_t bytes, hipStream_t st) {
+    int rc = d.ensure(bytes ? bytes : 64);
+    if (rc != SGK_OK) return rc;
+    if (bytes) SGK_HIP_TRY(hipMemcpyAsync(d.p, h.p, bytes, hipMemcpyHostToDevice, st));
+    return SGK_OK;
+}
+static int d2h(GrowPin &h, const GrowDev &d, size_t bytes, hipStream_t st) {
+    int rc = h.ensure(bytes ? bytes : 64);
+    if (rc != SGK_OK) return rc;
+    if (bytes) SGK_HIP_TRY(hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, st));
+    return SGK_OK;
+}
+
+int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
+    if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
+    if (tool < SGK_TOOL_PA || tool > SGK_TOOL_PREFIX) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(j->device));
+    j->tool = tool;
+    j->flags = flags;
+    const size_t nr = j->n_reads;
+    hipStream_t st = j->st;
+    int rc;
+    if (nr == 0) {
+        j->submitted = true;
+        return SGK_OK;
+    }
+    // ---- inputs
+    if ((rc = h2d(j->d_offsets, j->h_offsets, nr * 8, st)) != SGK_OK) return rc;
+    if ((rc = h2d(j->d_lengths, j->h_lengths, nr * 4, st)) != SGK_OK) return rc;
+    if ((rc = h2d(j->d_dig, j->h_dig, nr * 8, st)) != SGK_OK) return rc;
+    if ((rc = h2d(j->d_off, j->h_off, nr * 8, st)) != SGK_OK) return rc;
+    if ((rc = h2d(j->d_rng, j->h_rng, nr * 8, st)) != SGK_OK) return rc;
+    if (j->fmt == SGK_SIGNAL_SVBZD) {
+        if ((rc = j->d_samples.ensure(j->n_samples * sizeof(int16_t))) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_blobs, j->h_blobs, j->blob_bytes, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_boffs, j->h_boffs, nr * 8, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_blens, j->h_blens, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = j->d_dstat.ensure(nr * 4)) != SGK_OK) return rc;
+        rc = sgk_svbzd_decode(j->d_blobs.as<uint8_t>(), j->d_boffs.as<uint64_t>(), j->d_blens.as<uint32_t>(),
+                              j->n_reads, j->d_samples.as<int16_t>(), j->d_offsets.as<uint64_t>(),
+                              j->d_lengths.as<uint32_t>(), j->d_dstat.as<uint32_t>(), st);
+        if (rc != SGK_OK) return rc;
+        if ((rc = d2h(j->h_dstat, j->d_dstat, nr * 4, st)) != SGK_OK) return rc;
+    } else {
+        if ((rc = h2d(j->d_samples, j->h_samples, j->n_samples * sizeof(int16_t), st)) != SGK_OK) return rc;
+    }
+    sgk_batch_t view;
+    view.samples = j->d_samples.as<int16_t>();
+    view.offsets = j->d_offsets.as<uint64_t>();
+    view.lengths = j->d_lengths.as<uint32_t>();
+    view.digitisation = j->d_dig.as<double>();
+    view.offset = j->d_off.as<double>();
+    view.range = j->d_rng.as<double>();
+    view.n_reads = j->n_reads;
+    view.max_read_len = j->max_len;
+    view.n_samples = j->n_samples;
+    const uint32_t *lens = j->h_lengths.as<uint32_t>();
+    // ---- kernels + results
+    switch (tool) {
+        case SGK_TOOL_PA: {
+            const size_t bytes = j->n_samples * sizeof(float);
+            if ((rc = j->d_out[0].ensure(bytes)) != SGK_OK) return rc;
+            if ((rc = sgk_pa(&view, j->d_out[0].as<float>(), st)) != SGK_OK) return rc;
+            if ((rc = d2h(j->h_out[0], j->d_out[0], bytes, st)) != SGK_OK) return rc;
+            break;
+        }
+        case SGK_TOOL_EVENT:
+        case SGK_TOOL_JNN: {
+            const bool ev = tool == SGK_TOOL_EVENT;
+            if ((rc = j->h_slots.ensure((nr + 1) * 8)) != SGK_OK) return rc;
+            uint64_t *slots = j->h_slots.as<uint64_t>();
+            uint64_t s = 0;
+            for (size_t r = 0; r < nr; ++r) {
+                slots[r] = s;
+                s += ev ? sgk_event_slots_for(lens[r]) : sgk_jnn_slots_for(lens[r]);
+            }
+            slots[nr] = s;
+            if ((rc = h2d(j->d_slots, j->h_slots, (nr + 1) * 8, st)) != SGK_OK) return rc;
+            const int narr = ev ? 4 : 2;
+            for (int k = 0; k < narr; ++k)
+                if ((rc = j->d_out[k].ensure(s * 4)) != SGK_OK) return rc;
+            if ((rc = j->d_cnt.ensure(nr * 4)) != SGK_OK) return rc;
+            j->ws_bytes = ev ? sgk_event_workspace_bytes(j->n_reads, j->n_samples, j->max_len)
+                             : sgk_jnn_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
+            if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
+            if (ev)
+                rc = sgk_event(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<uint32_t>(),
+                               j->d_out[1].as<uint32_t>(), j->d_out[2].as<float>(), j->d_out[3].as<float>(),
+                               j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
+            else
+                rc = sgk_jnn(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<int32_t>(),
+                             j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
+            if (rc != SGK_OK) return rc;
+            if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
+            const int ncopy = (ev && (flags & SGK_JOB_EVENTS_COMPACT)) ? 2 : narr;
+            for (int k = 0; k < ncopy; ++k)
+                if ((rc = d2h(j->h_out[k], j->d_out[k], s * 4, st)) != SGK_OK) return rc;
+            break;
+        }
+        case SGK_TOOL_STAT: {
+            if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
+            j->ws_bytes = sgk_stat_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
+            if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
+            rc = sgk_stat(&view, j->d_out[0].as<sgk_stat_rec_t>(), j->d_ws.p, j->d_ws.cap, st);
+            if (rc != SGK_OK) return rc;
+            if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_stat_rec_t), st)) != SGK_OK) return rc;
+            break;
+        }
+        case SGK_TOOL_PREFIX: {
+            if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
+            j->ws_bytes = sgk_prefix_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
+            if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
+            rc = sgk_prefix(&view, rna, pore, j->d_out[0].as<sgk_prefix_rec_t>(), j->d_ws.p, j->d_ws.cap, st);
+            if (rc != SGK_OK) return rc;
+            if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_prefix_rec_t), st)) != SGK_OK) return rc;
+            break;
+        }
+    }
+    j->submitted = true;
+    return SGK_OK;
+}
+
+int sgk_job_wait(sgk_job_t *j) {
+    if (!j || !j->submitted) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(j->device));
+    j->submitted = false;
+    j->begun = false;
+    memset(&j->ev_status, 0, sizeof j->ev_status);
+    SGK_HIP_TRY(hipStreamSynchronize(j->st));
+    if (j->n_reads == 0) return SGK_OK;
+    if (j->fmt == SGK_SIGNAL_SVBZD) {
+        const uint32_t *ds = j->h_dstat.as<uint32_t>();
+        for (uint32_t r = 0; r < j->n_reads; ++r)
+            if (ds[r] != 0) return SGK_ERR_FORMAT;
+    }
+    if (j->tool == SGK_TOOL_EVENT) return sgk_event_status(j->d_ws.p, &j->ev_status, j->st);
+    return SGK_OK;
+}
+
+int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
+    if (!j || !out) return SGK_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->n_reads = j->n_reads;
+    out->offsets = j->h_offsets.as<uint64_t>();
+    out->lengths = j->h_lengths.as<uint32_t>();
+    out->decode_status = j->fmt == SGK_SIGNAL_SVBZD ? j->h_dstat.as<uint32_t>() : nullptr;
+    switch (j->tool) {
+        case SGK_TOOL_PA:
+            out->pa = j->h_out[0].as<float>();
+            break;
+        case SGK_TOOL_EVENT:
+            out->slots = j->h_slots.as<uint64_t>();
+            out->counts = j->h_cnt.as<uint32_t>();
+            out->ev_start = j->h_out[0].as<uint32_t>();
+            out->ev_length = j->h_out[1].as<uint32_t>();
+            if (!(j->flags & SGK_JOB_EVENTS_COMPACT)) {
+                out->ev_mean = j->h_out[2].as<float>();
+                out->ev_stdv = j->h_out[3].as<float>();
+            }
+            out->event_status = j->ev_status;
+            break;
+        case SGK_TOOL_JNN:
+            out->slots = j->h_slots.as<uint64_t>();
+            out->counts = j->h_cnt.as<uint32_t>();
+            out->seg_x = j->h_out[0].as<int32_t>();
+            out->seg_y = j->h_out[1].as<int32_t>();
+            break;
+        case SGK_TOOL_STAT:
+            out->stat = j->h_out[0].as<sgk_stat_rec_t>();
+            break;
+        case SGK_TOOL_PREFIX:
+            out->prefix = j->h_out[0].as<sgk_prefix_rec_t>();
+            break;
+        default:
+            return SGK_ERR_ARG;
+    }
+    return SGK_OK;
+}
+
+}  // extern "C"

@@ -250,3 +250,109 @@ void b5_rec_free(b5_rec_t *rec) {
     free(rec->zbuf);
     memset(rec, 0, sizeof *rec);
 }
+
+/* ------------------------------------------------------------------ split API (pipelined reader) */
+
+static int read_raw_here(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size) {
+    uint8_t szb[8];
+    const size_t got = fread(szb, 1, 8, f->fp);
+    if (got >= 5 && memcmp(szb, B5_EOF_MARK, 5) == 0) return got == 5 ? B5_EOF : B5_ERR_FORMAT;
+    if (got != 8) return B5_ERR_IO;
+    uint64_t sz;
+    memcpy(&sz, szb, 8);
+    if (sz == 0 || sz > (1ull << 36)) return B5_ERR_FORMAT;
+    const int rc = grow(buf, cap, *len + sz);
+    if (rc) return rc;
+    if (fread(*buf + *len, 1, sz, f->fp) != sz) return B5_ERR_IO;
+    *len += sz;
+    *size = sz;
+    return 0;
+}
+
+int b5_next_raw(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size) {
+    return read_raw_here(f, buf, len, cap, size);
+}
+
+int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size) {
+    if (!f->idx) {
+        const int rc = b5_index(f);
+        if (rc) return rc;
+    }
+    b5_idx_entry_t key;
+    key.id = (char *)read_id;
+    key.offset = 0;
+    const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
+    if (!e) return B5_ERR_NOTFOUND;
+    if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
+    return read_raw_here(f, buf, len, cap, size);
+}
+
+int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,
+                 b5_view_t *out) {
+    const uint8_t *p = raw;
+    uint64_t n = size;
+    if (f->record_press == 1) {
+        uint64_t want = *scratch_cap ? *scratch_cap : size * 4 + 4096;
+        for (;;) {
+            const int rc = grow(scratch, scratch_cap, want);
+            if (rc) return rc;
+            uLongf outlen = *scratch_cap;
+            const int z = uncompress(*scratch, &outlen, raw, size);
+            if (z == Z_OK) { n = outlen; break; }
+            if (z != Z_BUF_ERROR) return B5_ERR_PRESS;
+            want = *scratch_cap * 2;
+        }
+        p = *scratch;
+    }
+    if (n < 2) return B5_ERR_FORMAT;
+    uint16_t idl;
+    memcpy(&idl, p, 2);
+    if (2 + (uint64_t)idl + 44 > n) return B5_ERR_FORMAT;
+    out->read_id = (const char *)(p + 2);
+    out->id_len = idl;
+    const uint8_t *q = p + 2 + idl;
+    memcpy(&out->read_group, q, 4);
+    memcpy(&out->digitisation, q + 4, 8);
+    memcpy(&out->offset, q + 12, 8);
+    memcpy(&out->range, q + 20, 8);
+    memcpy(&out->sampling_rate, q + 28, 8);
+    uint64_t ln;
+    memcpy(&ln, q + 36, 8);
+    q += 44;
+    const uint64_t left = n - (uint64_t)(q - p);
+    out->signal = q;
+    if (f->signal_press == 1) {
+        if (ln > left || ln < 4 || ln > 0xffffffffull) return B5_ERR_FORMAT;
+        uint32_t count;
+        memcpy(&count, q, 4);
+        if (count > 0x7fffffffu) return B5_ERR_FORMAT;
+        out->signal_bytes = ln;
+        out->n_samples = count;
+    } else {
+        if (ln > 0x7fffffffull || ln * 2 > left) return B5_ERR_FORMAT;
+        out->signal_bytes = ln * 2;
+        out->n_samples = (uint32_t)ln;
+    }
+    return 0;
+}
+
+int b5_svb_zd_decode(const uint8_t *blob, uint64_t nbytes, int16_t *dst, uint32_t count) {
+    if (nbytes < 4) return B5_ERR_PRESS;
+    uint32_t c;
+    memcpy(&c, blob, 4);
+    if (c != count) return B5_ERR_PRESS;
+    const uint64_t nkeys = ((uint64_t)count + 3) / 4;
+    if (4 + nkeys > nbytes) return B5_ERR_PRESS;
+    const uint8_t *keys = blob + 4, *data = keys + nkeys, *end = blob + nbytes;
+    int32_t prev = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const unsigned code = (keys[i >> 2] >> ((i & 3) * 2)) & 3u;
+        if (data + code + 1 > end) return B5_ERR_PRESS;
+        uint32_t v = 0;
+        memcpy(&v, data, code + 1);
+        data += code + 1;
+        prev += (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+        dst[i] = (int16_t)prev;
+    }
+    return data == end ? 0 : B5_ERR_PRESS;
+}

@@ -60,4 +60,29 @@ int b5_index(b5_file_t *f);
 int b5_get(b5_file_t *f, const char *read_id, b5_rec_t *rec);
 void b5_rec_free(b5_rec_t *rec);
 
+/* ---- split API for the pipelined reader --------------------------------------
+ * One thread pulls the records' bytes off the file in order (b5_next_raw / b5_get_raw); any number
+ * of threads then inflate + parse them (b5_parse_raw, re-entrant) -- the split slow5lib's compiled-out
+ * batch API makes between slow5_get_next_mem and slow5_rec_depress_parse (slow5_mt.c:252-317). */
+typedef struct {
+    const char *read_id;  /* NOT NUL-terminated: id_len bytes inside the parsed record */
+    uint16_t id_len;
+    uint32_t read_group;
+    double digitisation, offset, range, sampling_rate;
+    const uint8_t *signal; /* svb-zd blob (signal_press 1) or little-endian int16 samples */
+    uint64_t signal_bytes;
+    uint32_t n_samples;    /* from the blob's count word, or signal_bytes / 2 */
+} b5_view_t;
+
+/* appends the next record's on-disk bytes (without the u64 size) to *buf at *len (realloc'd as needed);
+ * *size receives their length.  0 ok, B5_EOF, or an error. */
+int b5_next_raw(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size);
+int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size);
+/* inflates (if the file uses zlib records) into *scratch (realloc'd as needed) and parses; the view points
+ * into *scratch or into raw.  Re-entrant: touches no state of f besides its compression settings. */
+int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,
+                 b5_view_t *out);
+/* scalar streamvbyte + zigzag-delta decode of one blob into dst[count] (host-decode fallback path) */
+int b5_svb_zd_decode(const uint8_t *blob, uint64_t nbytes, int16_t *dst, uint32_t count);
+
 #endif

@@ -6,10 +6,13 @@
  *   src/cmain.c:40-156  options (-h -V -n -c --print-stat, ignored -o/--verbose), DNA/RNA and pore
  *                       detection from read-group 0, sequential or read-id mode
  *   src/cfunc.c         the TSV grammar of every subtool (byte-identical output)
- * What differs by design: records are not processed one at a time.  The reader fills a batch
- * (structure of arrays), the batch is split across the selected GPUs by cumulative sample count
- * (one host thread per GPU, no collective), and rows are printed in file order.
- * Extra options: --gpus N (default 1), --batch-samples M (default 64M samples per batch).
+ * What differs by design: records are not processed one at a time.  A loader pulls the records'
+ * bytes off the file in order and a pool of threads inflates/parses them into the pinned staging of a
+ * job (sgk_job_*, include/sigtk_gpu.h); svb-zd signals are handed to the GPU still compressed and
+ * decoded there.  Several batches are in flight (one per GPU plus two), a writer thread formats the
+ * rows of finished batches on a pool of threads (exact fast number formatting, fmt.h) and emits them
+ * in file order.  Whole batches are the multi-GPU sharding unit: no collective.
+ * Extra options: --gpus N, --batch-samples M, -t/--threads T, --host-decode.
  */
 #include <getopt.h>
 #include <pthread.h>
@@ -20,7 +23,10 @@
 #include <sys/resource.h>
 #include <sys/time.h>
 
+#include <unistd.h>
+
 #include "blow5.h"
+#include "fmt.h"
 #include "sigtk_gpu.h"
 
 #define SIGTK_VERSION "0.2.0" /* the reference version whose CLI this mirrors (src/sigtk.h:11) */
@@ -118,254 +124,472 @@ static int8_t pore_detect(const b5_file_t *f) {
     return pore;
 }
 
-/* ------------------------------------------------------------------ batch */
-
-typedef struct {
-    char **ids;
-    uint64_t *offsets; /* n+1 (CSR into samples) */
-    double *dig, *off, *rng;
-    int16_t *samples;
-    uint32_t n, cap_reads;
-    uint64_t cap_samples;
-} batch_t;
+/* ------------------------------------------------------------------ small utilities */
 
 static void die_mem(void) {
     ERROR("main", "%s", "out of memory");
     exit(EXIT_FAILURE);
 }
 
-static void batch_push(batch_t *b, const b5_rec_t *rec) {
-    if (b->n == b->cap_reads) {
-        b->cap_reads = b->cap_reads ? b->cap_reads * 2 : 1024;
-        b->ids = (char **)realloc(b->ids, sizeof(char *) * b->cap_reads);
-        b->offsets = (uint64_t *)realloc(b->offsets, sizeof(uint64_t) * ((size_t)b->cap_reads + 1));
-        b->dig = (double *)realloc(b->dig, sizeof(double) * b->cap_reads);
-        b->off = (double *)realloc(b->off, sizeof(double) * b->cap_reads);
-        b->rng = (double *)realloc(b->rng, sizeof(double) * b->cap_reads);
-        if (!b->ids || !b->offsets || !b->dig || !b->off || !b->rng) die_mem();
-        if (b->n == 0) b->offsets[0] = 0;
-    }
-    const uint64_t o = b->offsets[b->n], n = rec->len_raw_signal;
-    if (o + n > b->cap_samples) {
-        uint64_t c = b->cap_samples ? b->cap_samples : (1u << 20);
-        while (c < o + n) c *= 2;
-        b->samples = (int16_t *)realloc(b->samples, sizeof(int16_t) * c);
-        if (!b->samples) die_mem();
-        b->cap_samples = c;
-    }
-    if (n) memcpy(b->samples + o, rec->raw_signal, sizeof(int16_t) * n); /* the record buffer is reused */
-    b->ids[b->n] = strdup(rec->read_id);
-    b->dig[b->n] = rec->digitisation;
-    b->off[b->n] = rec->offset;
-    b->rng[b->n] = rec->range;
-    b->offsets[b->n + 1] = o + n;
-    b->n++;
-}
-
-static void batch_clear(batch_t *b) {
-    for (uint32_t i = 0; i < b->n; i++) free(b->ids[i]);
-    b->n = 0;
-    if (b->offsets) b->offsets[0] = 0;
-}
-
-static void batch_free(batch_t *b) {
-    batch_clear(b);
-    free(b->ids); free(b->offsets); free(b->dig); free(b->off); free(b->rng); free(b->samples);
-    memset(b, 0, sizeof *b);
-}
-
-/* ------------------------------------------------------------------ per-GPU shard work */
-
+/* growable output buffer */
 typedef struct {
-    int mode, device, rc;
-    opt_t opt;
-    const batch_t *b;
-    uint32_t lo, hi; /* reads [lo, hi) of the batch */
-    sgk_events_host_t ev;
-    sgk_segs_host_t segs;
-    sgk_stat_rec_t *stat;
-    sgk_prefix_rec_t *prefix;
-    float *pa;
-} shard_t;
+    char *p;
+    size_t n, cap;
+} sbuf_t;
 
-static void *shard_run(void *arg) {
-    shard_t *s = (shard_t *)arg;
-    const batch_t *b = s->b;
-    s->rc = sgk_set_device(s->device);
-    if (s->rc != SGK_OK) return NULL;
-    sgk_host_batch_t hb;
-    hb.samples = b->samples;
-    hb.offsets = b->offsets + s->lo;
-    hb.digitisation = b->dig + s->lo;
-    hb.offset = b->off + s->lo;
-    hb.range = b->rng + s->lo;
-    hb.n_reads = s->hi - s->lo;
-    const uint32_t n = hb.n_reads;
-    switch (s->mode) {
-        case MODE_EVENT:
-            s->rc = sgk_event_host(&hb, s->opt.rna, &s->ev);
-            break;
-        case MODE_STAT:
-            s->stat = (sgk_stat_rec_t *)calloc(n ? n : 1, sizeof(sgk_stat_rec_t));
-            s->rc = s->stat ? sgk_stat_host(&hb, s->stat) : SGK_ERR_NOMEM;
-            break;
-        case MODE_PREFIX:
-            s->prefix = (sgk_prefix_rec_t *)calloc(n ? n : 1, sizeof(sgk_prefix_rec_t));
-            s->rc = s->prefix ? sgk_prefix_host(&hb, s->opt.rna, s->opt.pore, s->prefix) : SGK_ERR_NOMEM;
-            break;
-        case MODE_JNN:
-            s->rc = sgk_jnn_host(&hb, s->opt.rna, &s->segs);
-            break;
-        case MODE_PA: {
-            const uint64_t tot = b->offsets[s->hi]; /* sgk_pa_host indexes its output with the CSR offsets */
-            s->pa = (float *)malloc(sizeof(float) * (tot ? tot : 1));
-            s->rc = s->pa ? sgk_pa_host(&hb, s->pa) : SGK_ERR_NOMEM;
-            break;
-        }
+static inline char *sbuf_room(sbuf_t *b, size_t need) {
+    if (b->n + need > b->cap) {
+        size_t c = b->cap ? b->cap : (1u << 16);
+        while (c < b->n + need) c *= 2;
+        b->p = (char *)realloc(b->p, c);
+        if (!b->p) die_mem();
+        b->cap = c;
+    }
+    return b->p + b->n;
+}
+static inline void sbuf_str(sbuf_t *b, const char *s, size_t len) {
+    memcpy(sbuf_room(b, len), s, len);
+    b->n += len;
+}
+
+/* parallel for with dynamic scheduling: fn(ctx, i, tid) for i in [0, n) on up to nthreads threads */
+typedef void (*pfor_fn)(void *ctx, uint32_t i, int tid);
+typedef struct {
+    pfor_fn fn;
+    void *ctx;
+    uint32_t n;
+    uint32_t *next;
+    int tid;
+} pfor_arg_t;
+static void *pfor_main(void *a_) {
+    pfor_arg_t *a = (pfor_arg_t *)a_;
+    for (;;) {
+        const uint32_t i = __atomic_fetch_add(a->next, 1u, __ATOMIC_RELAXED);
+        if (i >= a->n) break;
+        a->fn(a->ctx, i, a->tid);
     }
     return NULL;
 }
+static void pfor(int nthreads, uint32_t n, pfor_fn fn, void *ctx) {
+    if (n == 0) return;
+    if ((uint32_t)nthreads > n) nthreads = (int)n;
+    if (nthreads < 1) nthreads = 1;
+    uint32_t next = 0;
+    pfor_arg_t *args = (pfor_arg_t *)calloc((size_t)nthreads, sizeof *args);
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
+    if (!args || !th) die_mem();
+    for (int t = 0; t < nthreads; t++) {
+        args[t].fn = fn; args[t].ctx = ctx; args[t].n = n; args[t].next = &next; args[t].tid = t;
+        if (t > 0 && pthread_create(&th[t], NULL, pfor_main, &args[t]) != 0) {
+            ERROR("pfor", "%s", "cannot create thread");
+            exit(EXIT_FAILURE);
+        }
+    }
+    pfor_main(&args[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(args);
+    free(th);
+}
 
-/* ------------------------------------------------------------------ printers (src/cfunc.c) */
+/* ------------------------------------------------------------------ batches and the pipeline
+ *
+ *   loader (main thread)                                  writer thread
+ *   --------------------                                  -------------
+ *   take a free batch                                     take the oldest submitted batch
+ *   read the records' bytes off the file, in order        sgk_job_wait
+ *   N threads: inflate + parse                            N threads: format rows into chunk buffers
+ *   sgk_job_begin (layout, pinned staging)                fwrite the chunks in order
+ *   N threads: copy svb-zd blobs / samples into staging   return the batch to the free list
+ *   sgk_job_submit (async H2D, decode, kernels, D2H)
+ *
+ * n_gpus + 2 batches circulate; batch k runs on GPU k mod n_gpus (whole batches are the sharding unit:
+ * every output row depends on one record only, src/cmain.c:118-120, so there is no collective). */
+
+typedef struct {
+    uint64_t raw_off, raw_size; /* the record's on-disk bytes inside batch_t.raw */
+    uint8_t *scratch;           /* inflated record (kept per slot; grows only) */
+    uint64_t scratch_cap;
+    b5_view_t v;
+    int err;
+} lrec_t;
+
+typedef struct batch {
+    sgk_job_t *job;
+    sgk_job_input_t in;
+    lrec_t *recs;
+    uint32_t n, cap;
+    uint8_t *raw;
+    uint64_t raw_len, raw_cap;
+    uint32_t *lengths, *blob_bytes;
+    int svb;        /* signal staged as svb-zd blobs (GPU decode) */
+    int last;       /* sentinel: no more batches */
+    struct batch *next;
+} batch_t;
+
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    batch_t *head, *tail;
+} queue_t;
+
+static void q_init(queue_t *q) {
+    pthread_mutex_init(&q->mu, NULL);
+    pthread_cond_init(&q->cv, NULL);
+    q->head = q->tail = NULL;
+}
+static void q_push(queue_t *q, batch_t *b) {
+    pthread_mutex_lock(&q->mu);
+    b->next = NULL;
+    if (q->tail) q->tail->next = b;
+    else q->head = b;
+    q->tail = b;
+    pthread_cond_signal(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+}
+static batch_t *q_pop(queue_t *q) {
+    pthread_mutex_lock(&q->mu);
+    while (!q->head) pthread_cond_wait(&q->cv, &q->mu);
+    batch_t *b = q->head;
+    q->head = b->next;
+    if (!q->head) q->tail = NULL;
+    pthread_mutex_unlock(&q->mu);
+    return b;
+}
+
+typedef struct {
+    b5_file_t *f;
+    int mode, nthreads, host_decode;
+    opt_t opt;
+    queue_t free_q, ready_q;
+    double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
+    uint64_t n_reads, n_samples;
+} pipe_t;
+
+static void gpu_fail(const char *what, int rc) {
+    ERROR(what, "%s %s", sgk_strerror(rc), sgk_last_hip_error());
+    exit(EXIT_FAILURE);
+}
+
+static void batch_add_record(batch_t *b, uint64_t size) {
+    if (b->n == b->cap) {
+        const uint32_t nc = b->cap ? b->cap * 2 : 1024;
+        b->recs = (lrec_t *)realloc(b->recs, sizeof(lrec_t) * nc);
+        b->lengths = (uint32_t *)realloc(b->lengths, sizeof(uint32_t) * nc);
+        b->blob_bytes = (uint32_t *)realloc(b->blob_bytes, sizeof(uint32_t) * nc);
+        if (!b->recs || !b->lengths || !b->blob_bytes) die_mem();
+        memset(b->recs + b->cap, 0, sizeof(lrec_t) * (nc - b->cap));
+        b->cap = nc;
+    }
+    b->recs[b->n].raw_off = b->raw_len - size;
+    b->recs[b->n].raw_size = size;
+    b->n++;
+}
+
+/* phase 1 (parallel): inflate + parse record i */
+typedef struct {
+    pipe_t *P;
+    batch_t *b;
+} lctx_t;
+static void load_parse(void *ctx_, uint32_t i, int tid) {
+    (void)tid;
+    lctx_t *c = (lctx_t *)ctx_;
+    lrec_t *r = &c->b->recs[i];
+    r->err = b5_parse_raw(c->P->f, c->b->raw + r->raw_off, r->raw_size, &r->scratch, &r->scratch_cap, &r->v);
+}
+/* phase 2 (parallel): stage record i's signal and scaling into the job's pinned buffers */
+static void load_stage(void *ctx_, uint32_t i, int tid) {
+    (void)tid;
+    lctx_t *c = (lctx_t *)ctx_;
+    batch_t *b = c->b;
+    lrec_t *r = &b->recs[i];
+    b->in.digitisation[i] = r->v.digitisation;
+    b->in.offset[i] = r->v.offset;
+    b->in.range[i] = r->v.range;
+    if (b->svb) {
+        memcpy(b->in.blobs + b->in.blob_offsets[i], r->v.signal, r->v.signal_bytes);
+    } else if (c->P->f->signal_press == 1) {
+        r->err = b5_svb_zd_decode(r->v.signal, r->v.signal_bytes, b->in.samples + b->in.offsets[i], r->v.n_samples);
+    } else {
+        memcpy(b->in.samples + b->in.offsets[i], r->v.signal, r->v.signal_bytes);
+    }
+}
+
+/* parse + stage + submit the records gathered in b */
+static void batch_launch(pipe_t *P, batch_t *b) {
+    lctx_t c = {P, b};
+    double t0 = realtime();
+    pfor(P->nthreads, b->n, load_parse, &c);
+    for (uint32_t i = 0; i < b->n; i++) {
+        if (b->recs[i].err) {
+            fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
+            exit(EXIT_FAILURE);
+        }
+        b->lengths[i] = b->recs[i].v.n_samples;
+        b->blob_bytes[i] = (uint32_t)b->recs[i].v.signal_bytes;
+        P->n_samples += b->recs[i].v.n_samples;
+    }
+    P->n_reads += b->n;
+    double t1 = realtime();
+    P->t_parse += t1 - t0;
+    b->svb = P->f->signal_press == 1 && !P->host_decode;
+    int rc = sgk_job_begin(b->job, b->n, b->lengths, b->svb ? SGK_SIGNAL_SVBZD : SGK_SIGNAL_INT16, b->blob_bytes,
+                           &b->in);
+    if (rc != SGK_OK) gpu_fail("sgk_job_begin", rc);
+    pfor(P->nthreads, b->n, load_stage, &c);
+    for (uint32_t i = 0; i < b->n; i++) {
+        if (b->recs[i].err) {
+            fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
+            exit(EXIT_FAILURE);
+        }
+    }
+    int tool = SGK_TOOL_PA, flags = 0;
+    switch (P->mode) {
+        case MODE_EVENT: tool = SGK_TOOL_EVENT; flags = P->opt.compact ? SGK_JOB_EVENTS_COMPACT : 0; break;
+        case MODE_STAT: tool = SGK_TOOL_STAT; break;
+        case MODE_PREFIX: tool = SGK_TOOL_PREFIX; break;
+        case MODE_JNN: tool = SGK_TOOL_JNN; break;
+        default: break;
+    }
+    rc = sgk_job_submit(b->job, tool, P->opt.rna, P->opt.pore, flags);
+    if (rc != SGK_OK) gpu_fail("sgk_job_submit", rc);
+    P->t_stage += realtime() - t1;
+    q_push(&P->ready_q, b);
+}
+
+/* ------------------------------------------------------------------ row formatters (src/cfunc.c)
+ * Byte-for-byte the reference's printf output; numbers go through fmt.h. */
+
+#define ID_OF(b, r) (b)->recs[r].v.read_id, (b)->recs[r].v.id_len
+
+static inline void put_id_len(sbuf_t *o, const batch_t *b, uint32_t r) {
+    char *p = sbuf_room(o, (size_t)b->recs[r].v.id_len + 32);
+    memcpy(p, b->recs[r].v.read_id, b->recs[r].v.id_len);
+    p += b->recs[r].v.id_len;
+    *p++ = '\t';
+    p = fmt_u64(p, b->lengths[r]);
+    *p++ = '\t';
+    o->n = (size_t)(p - o->p);
+}
 
 /* print_events, cfunc.c:16-61 */
-static void print_events(const char *rid, uint64_t len, const sgk_events_host_t *ev, uint32_t r, opt_t opt) {
-    const uint64_t a = ev->ev_offsets[r], n = ev->ev_offsets[r + 1] - a;
+static void row_events(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r, opt_t opt) {
+    const uint64_t a = out->slots[r], n = out->counts[r];
+    const uint32_t *st = out->ev_start + a, *ln = out->ev_length + a;
     if (opt.compact) {
-        printf("%s\t%ld\t", rid, (long)len);
+        put_id_len(o, b, r);
         if (n) {
-            printf("%ld\t%ld\t", (long)ev->start[a], (long)(ev->start[a + n - 1] + ev->length[a + n - 1]));
-            printf("%ld\t", (long)n);
+            char *p = sbuf_room(o, 96 + n * 12);
+            p = fmt_u64(p, st[0]); *p++ = '\t';
+            p = fmt_u64(p, (uint64_t)st[n - 1] + ln[n - 1]); *p++ = '\t';
+            p = fmt_u64(p, n); *p++ = '\t';
             for (uint64_t j = 0; j < n; j++) {
-                const int mi = (int)ev->length[a + j];
+                const int mi = (int)ln[j];
                 if (mi) {
-                    if (j < n - 1) printf("%d,", mi);
-                    else printf("%d", mi);
+                    p = fmt_i64(p, mi);
+                    if (j < n - 1) *p++ = ',';
                 }
             }
+            o->n = (size_t)(p - o->p);
         } else {
-            printf(".\t.\t.\t.");
+            sbuf_str(o, ".\t.\t.\t.", 7);
         }
-        printf("\n");
+        sbuf_str(o, "\n", 1);
     } else {
-        for (uint64_t j = 0; j < n; j++)
-            printf("%s\t%d\t%ld\t%ld\t%f\t%f\n", rid, (int)j, (long)ev->start[a + j],
-                   (long)(ev->start[a + j] + ev->length[a + j]), ev->mean[a + j], ev->stdv[a + j]);
-        printf("\n"); /* cfunc.c:58 */
+        const float *mean = out->ev_mean + a, *sd = out->ev_stdv + a;
+        const size_t idl = b->recs[r].v.id_len;
+        char *p = sbuf_room(o, n * (idl + 160) + 8);
+        for (uint64_t j = 0; j < n; j++) {
+            memcpy(p, b->recs[r].v.read_id, idl);
+            p += idl;
+            *p++ = '\t';
+            p = fmt_i64(p, (int)j); *p++ = '\t';
+            p = fmt_u64(p, st[j]); *p++ = '\t';
+            p = fmt_u64(p, (uint64_t)st[j] + ln[j]); *p++ = '\t';
+            p = fmt_f6(p, mean[j]); *p++ = '\t';
+            p = fmt_f6(p, sd[j]); *p++ = '\n';
+        }
+        *p++ = '\n'; /* cfunc.c:58 */
+        o->n = (size_t)(p - o->p);
     }
 }
 
 /* jnn_print, jnn.c:309-350 */
-static void print_jnn(const char *rid, uint64_t len, const sgk_segs_host_t *sg, uint32_t r, opt_t opt) {
-    printf("%s\t", rid);
-    printf("%ld\t", (long)len);
+static void row_jnn(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r, opt_t opt) {
+    put_id_len(o, b, r);
+    const uint64_t len = b->lengths[r];
     if (len > 0) {
-        const uint64_t a = sg->seg_offsets[r], n = sg->seg_offsets[r + 1] - a;
-        printf("%d\t", (int)n);
+        const uint64_t a = out->slots[r], n = out->counts[r];
+        const int32_t *x = out->seg_x + a, *y = out->seg_y + a;
+        char *p = sbuf_room(o, 32 + n * 48);
+        p = fmt_i64(p, (int)n); *p++ = '\t';
         if (opt.compact) {
             uint64_t ci = 0, mi = 0;
             for (uint64_t i = 0; i < n; i++) {
-                ci += (mi = (uint64_t)sg->x[a + i] - ci);
-                if (mi) printf("%dH", (int)mi);
-                ci += (mi = (uint64_t)sg->y[a + i] - ci);
-                if (mi) printf("%d,", (int)mi);
+                ci += (mi = (uint64_t)x[i] - ci);
+                if (mi) { p = fmt_i64(p, (int)mi); *p++ = 'H'; }
+                ci += (mi = (uint64_t)y[i] - ci);
+                if (mi) { p = fmt_i64(p, (int)mi); *p++ = ','; }
             }
         } else {
-            for (uint64_t i = 0; i < n; i++) printf("%ld,%ld;", (long)sg->x[a + i], (long)sg->y[a + i]);
+            for (uint64_t i = 0; i < n; i++) {
+                p = fmt_i64(p, x[i]); *p++ = ',';
+                p = fmt_i64(p, y[i]); *p++ = ';';
+            }
         }
-        if (n == 0) printf(".");
+        if (n == 0) *p++ = '.';
+        o->n = (size_t)(p - o->p);
     }
-    printf("\n");
+    sbuf_str(o, "\n", 1);
 }
 
 /* stat_func, cfunc.c:126-159 */
-static void print_stat(const char *rid, uint64_t len, const sgk_stat_rec_t *s) {
-    printf("%s\t", rid);
-    printf("%ld\t", (long)len);
-    printf("%f\t%f\t%f\t%f\t%d\t%f\t", s->raw_mean, s->pa_mean, s->raw_std, s->pa_std, (int)(int16_t)s->raw_median,
-           s->pa_median);
-    printf("\n");
+static void row_stat(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r) {
+    put_id_len(o, b, r);
+    const sgk_stat_rec_t *s = &out->stat[r];
+    char *p = sbuf_room(o, 6 * 52);
+    p = fmt_f6(p, s->raw_mean); *p++ = '\t';
+    p = fmt_f6(p, s->pa_mean); *p++ = '\t';
+    p = fmt_f6(p, s->raw_std); *p++ = '\t';
+    p = fmt_f6(p, s->pa_std); *p++ = '\t';
+    p = fmt_i64(p, (int)(int16_t)s->raw_median); *p++ = '\t';
+    p = fmt_f6(p, s->pa_median); *p++ = '\t';
+    *p++ = '\n';
+    o->n = (size_t)(p - o->p);
 }
 
 /* prefix_func, cfunc.c:169-234 */
-static void print_prefix(const char *rid, uint64_t len, const sgk_prefix_rec_t *p, opt_t opt) {
-    printf("%s\t%ld\t", rid, (long)len);
-    if (p->adapt_y > 0) {
-        printf("%ld\t%ld\t", (long)p->adapt_x, (long)p->adapt_y);
-        if (p->polya_y > 0) printf("%ld\t%ld", (long)p->polya_x + p->adapt_y, (long)p->polya_y + p->adapt_y);
-        else printf(".\t.");
+static void row_prefix(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r, opt_t opt) {
+    put_id_len(o, b, r);
+    const sgk_prefix_rec_t *q = &out->prefix[r];
+    char *p = sbuf_room(o, 512);
+    if (q->adapt_y > 0) {
+        p = fmt_i64(p, q->adapt_x); *p++ = '\t';
+        p = fmt_i64(p, q->adapt_y); *p++ = '\t';
+        if (q->polya_y > 0) {
+            p = fmt_i64(p, (int64_t)q->polya_x + q->adapt_y); *p++ = '\t';
+            p = fmt_i64(p, (int64_t)q->polya_y + q->adapt_y);
+        } else {
+            memcpy(p, ".\t.", 3); p += 3;
+        }
         if (opt.p_stat) {
-            printf("\t%f\t%f\t%f\t", p->adapt_mean, p->adapt_std, p->adapt_median);
-            if (p->polya_y > 0) printf("\t%f\t%f\t%f\t", p->polya_mean, p->polya_std, p->polya_median);
-            else printf("\t.\t.\t.");
+            *p++ = '\t';
+            p = fmt_f6(p, q->adapt_mean); *p++ = '\t';
+            p = fmt_f6(p, q->adapt_std); *p++ = '\t';
+            p = fmt_f6(p, q->adapt_median); *p++ = '\t';
+            if (q->polya_y > 0) {
+                *p++ = '\t';
+                p = fmt_f6(p, q->polya_mean); *p++ = '\t';
+                p = fmt_f6(p, q->polya_std); *p++ = '\t';
+                p = fmt_f6(p, q->polya_median); *p++ = '\t';
+            } else {
+                memcpy(p, "\t.\t.\t.", 6); p += 6;
+            }
         }
     } else {
-        printf(".\t.\t.\t.");
+        memcpy(p, ".\t.\t.\t.", 7); p += 7;
     }
-    printf("\n");
+    *p++ = '\n';
+    o->n = (size_t)(p - o->p);
 }
 
 /* pa_func, cfunc.c:85-102 */
-static void print_pa(const char *rid, uint64_t len, const float *pa) {
-    printf("%s\t%ld\t", rid, (long)len);
+static void row_pa(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r) {
+    put_id_len(o, b, r);
+    const uint64_t len = b->lengths[r];
+    const float *pa = out->pa + out->offsets[r];
+    char *p = sbuf_room(o, len * 50 + 8);
     for (uint64_t i = 0; i < len; i++) {
-        if (i == len - 1) printf("%f", pa[i]);
-        else printf("%f,", pa[i]);
+        p = fmt_f6(p, pa[i]);
+        if (i != len - 1) *p++ = ',';
     }
-    printf("\n");
+    *p++ = '\n';
+    o->n = (size_t)(p - o->p);
 }
 
-/* ------------------------------------------------------------------ batch processing */
+/* ------------------------------------------------------------------ writer */
 
-static void process_batch(const batch_t *b, int mode, opt_t opt, int n_gpus) {
-    if (b->n == 0) return;
-    shard_t *sh = (shard_t *)calloc((size_t)n_gpus, sizeof(shard_t));
-    pthread_t *th = (pthread_t *)calloc((size_t)n_gpus, sizeof(pthread_t));
-    if (!sh || !th) die_mem();
-    /* contiguous read ranges balanced by cumulative sample count (lengths vary widely in real data) */
-    const uint64_t total = b->offsets[b->n];
-    uint32_t lo = 0;
-    int used = 0;
-    for (int g = 0; g < n_gpus && lo < b->n; g++) {
-        uint32_t hi = b->n;
-        if (g < n_gpus - 1) {
-            const uint64_t target = total / (uint64_t)n_gpus * (uint64_t)(g + 1);
-            hi = lo;
-            while (hi < b->n && b->offsets[hi + 1] <= target) hi++;
-            if (hi == lo) hi = lo + 1;
-        }
-        sh[used].mode = mode; sh[used].device = g; sh[used].opt = opt; sh[used].b = b;
-        sh[used].lo = lo; sh[used].hi = hi;
-        lo = hi;
-        used++;
-    }
-    for (int g = 1; g < used; g++) pthread_create(&th[g], NULL, shard_run, &sh[g]);
-    shard_run(&sh[0]);
-    for (int g = 1; g < used; g++) pthread_join(th[g], NULL);
-    for (int g = 0; g < used; g++) {
-        if (sh[g].rc != SGK_OK) {
-            ERROR("process_batch", "GPU %d: %s %s", sh[g].device, sgk_strerror(sh[g].rc), sgk_last_hip_error());
-            exit(EXIT_FAILURE);
+typedef struct {
+    pipe_t *P;
+    batch_t *b;
+    sgk_job_output_t out;
+    sbuf_t *chunk;          /* one buffer per chunk of reads */
+    uint32_t *chunk_lo;     /* n_chunks + 1 */
+} wctx_t;
+
+static void write_chunk(void *ctx_, uint32_t k, int tid) {
+    (void)tid;
+    wctx_t *c = (wctx_t *)ctx_;
+    sbuf_t *o = &c->chunk[k];
+    o->n = 0;
+    const opt_t opt = c->P->opt;
+    for (uint32_t r = c->chunk_lo[k]; r < c->chunk_lo[k + 1]; r++) {
+        switch (c->P->mode) {
+            case MODE_EVENT: row_events(o, c->b, &c->out, r, opt); break;
+            case MODE_JNN: row_jnn(o, c->b, &c->out, r, opt); break;
+            case MODE_STAT: row_stat(o, c->b, &c->out, r); break;
+            case MODE_PREFIX: row_prefix(o, c->b, &c->out, r, opt); break;
+            default: row_pa(o, c->b, &c->out, r); break;
         }
     }
-    for (int g = 0; g < used; g++) {
-        for (uint32_t r = sh[g].lo; r < sh[g].hi; r++) {
-            const uint32_t k = r - sh[g].lo;
-            const uint64_t len = b->offsets[r + 1] - b->offsets[r];
-            switch (mode) {
-                case MODE_EVENT: print_events(b->ids[r], len, &sh[g].ev, k, opt); break;
-                case MODE_JNN: print_jnn(b->ids[r], len, &sh[g].segs, k, opt); break;
-                case MODE_STAT: print_stat(b->ids[r], len, &sh[g].stat[k]); break;
-                case MODE_PREFIX: print_prefix(b->ids[r], len, &sh[g].prefix[k], opt); break;
-                case MODE_PA: print_pa(b->ids[r], len, sh[g].pa + b->offsets[r]); break;
+}
+
+static void *writer_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    sbuf_t *chunk = NULL;
+    uint32_t *chunk_lo = NULL;
+    uint32_t chunk_cap = 0;
+    for (;;) {
+        batch_t *b = q_pop(&P->ready_q);
+        if (b->last) break;
+        double t0 = realtime();
+        int rc = sgk_job_wait(b->job);
+        if (rc != SGK_OK) gpu_fail("sgk_job_wait", rc);
+        wctx_t c;
+        c.P = P;
+        c.b = b;
+        rc = sgk_job_output(b->job, &c.out);
+        if (rc != SGK_OK) gpu_fail("sgk_job_output", rc);
+        double t1 = realtime();
+        P->t_wait += t1 - t0;
+        /* contiguous chunks of reads with about equal sample counts; a few per thread for balance */
+        uint32_t nchunks = (uint32_t)P->nthreads * 4;
+        if (nchunks > b->n) nchunks = b->n;
+        if (nchunks > chunk_cap) {
+            chunk = (sbuf_t *)realloc(chunk, sizeof(sbuf_t) * nchunks);
+            chunk_lo = (uint32_t *)realloc(chunk_lo, sizeof(uint32_t) * ((size_t)nchunks + 1));
+            if (!chunk || !chunk_lo) die_mem();
+            memset(chunk + chunk_cap, 0, sizeof(sbuf_t) * (nchunks - chunk_cap));
+            chunk_cap = nchunks;
+        }
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < b->n; r++) total += b->lengths[r] + 64;
+        uint64_t acc = 0;
+        uint32_t k = 0;
+        chunk_lo[0] = 0;
+        for (uint32_t r = 0; r < b->n && k + 1 < nchunks; r++) {
+            acc += b->lengths[r] + 64;
+            if (acc * nchunks >= total * (uint64_t)(k + 1)) chunk_lo[++k] = r + 1;
+        }
+        while (k < nchunks) chunk_lo[++k] = b->n;
+        c.chunk = chunk;
+        c.chunk_lo = chunk_lo;
+        pfor(P->nthreads, nchunks, write_chunk, &c);
+        double t2 = realtime();
+        P->t_format += t2 - t1;
+        for (uint32_t i = 0; i < nchunks; i++)
+            if (chunk[i].n && fwrite(chunk[i].p, 1, chunk[i].n, stdout) != chunk[i].n) {
+                ERROR("writer", "%s", "write to stdout failed");
+                exit(EXIT_FAILURE);
             }
-        }
-        sgk_events_host_free(&sh[g].ev);
-        sgk_segs_host_free(&sh[g].segs);
-        free(sh[g].stat); free(sh[g].prefix); free(sh[g].pa);
+        P->t_write += realtime() - t2;
+        b->n = 0;
+        b->raw_len = 0;
+        q_push(&P->free_q, b);
     }
-    free(th);
-    free(sh);
+    for (uint32_t i = 0; i < chunk_cap; i++) free(chunk[i].p);
+    free(chunk);
+    free(chunk_lo);
+    return NULL;
 }
 
 /* ------------------------------------------------------------------ cmain (src/cmain.c:40-156) */
@@ -374,15 +598,15 @@ static struct option long_options[] = {
     {"verbose", required_argument, 0, 'v'}, {"help", no_argument, 0, 'h'},       {"version", no_argument, 0, 'V'},
     {"output", required_argument, 0, 'o'},  {"print-stat", no_argument, 0, 0},   {"no-header", no_argument, 0, 'n'},
     {"compact", no_argument, 0, 'c'},       {"gpus", required_argument, 0, 0},   {"batch-samples", required_argument, 0, 0},
-    {0, 0, 0, 0}};
+    {"threads", required_argument, 0, 't'}, {"host-decode", no_argument, 0, 0},  {0, 0, 0, 0}};
 
 static int cmain(int argc, char *argv[], const char *mode_s) {
-    const char *optstring = "o:hVnc";
+    const char *optstring = "o:hVnct:";
     int longindex = 0, c;
     FILE *fp_help = stderr;
     int8_t hdr = 1;
     opt_t opt = {0, 0, 0, 0};
-    int n_gpus = 1;
+    int n_gpus = 1, nthreads = 0, host_decode = 0;
     uint64_t batch_samples = 64ull << 20;
 
     while ((c = getopt_long(argc, argv, optstring, long_options, &longindex)) >= 0) {
@@ -395,12 +619,16 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
             hdr = 0;
         } else if (c == 'c') {
             opt.compact = 1;
+        } else if (c == 't') {
+            nthreads = atoi(optarg);
         } else if (c == 0 && longindex == 4) {
             opt.p_stat = 1;
         } else if (c == 0 && longindex == 7) {
             n_gpus = atoi(optarg);
         } else if (c == 0 && longindex == 8) {
             batch_samples = strtoull(optarg, NULL, 10);
+        } else if (c == 0 && longindex == 10) {
+            host_decode = 1;
         }
     }
     if (argc - optind < 1 || fp_help == stdout) {
@@ -411,8 +639,10 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         fprintf(fp_help, "   -n                         suppress header\n");
         fprintf(fp_help, "   -c                         compact output\n");
         fprintf(fp_help, "   --version                  print version\n");
-        fprintf(fp_help, "   --gpus INT                 number of GPUs to shard reads across [1]\n");
-        fprintf(fp_help, "   --batch-samples INT        raw samples per GPU batch [67108864]\n");
+        fprintf(fp_help, "   --gpus INT                 number of GPUs; whole batches go round-robin [1]\n");
+        fprintf(fp_help, "   --batch-samples INT        approximate raw samples per batch [67108864]\n");
+        fprintf(fp_help, "   -t, --threads INT          host threads for inflating records / formatting rows [auto]\n");
+        fprintf(fp_help, "   --host-decode              decode svb-zd signals on the host instead of the GPU\n");
         exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
     }
 
@@ -459,19 +689,51 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         WARNING("cmain", "--gpus %d requested but %d visible; using %d", n_gpus, ndev, ndev);
         n_gpus = ndev;
     }
+    if (nthreads <= 0) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        nthreads = nc > 1 ? (int)(nc / 2) : 1;
+        if (nthreads > 32) nthreads = 32;
+    }
 
-    b5_rec_t rec;
-    memset(&rec, 0, sizeof rec);
-    batch_t b;
-    memset(&b, 0, sizeof b);
-    const uint64_t limit = batch_samples * (uint64_t)n_gpus;
+    pipe_t P;
+    memset(&P, 0, sizeof P);
+    P.f = f;
+    P.mode = mode;
+    P.nthreads = nthreads;
+    P.host_decode = host_decode;
+    P.opt = opt;
+    q_init(&P.free_q);
+    q_init(&P.ready_q);
+    const int nbatch = n_gpus + 2;
+    batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
+    if (!pool) die_mem();
+    for (int i = 0; i < nbatch; i++) {
+        const int rc = sgk_job_create(i % n_gpus, &pool[i].job);
+        if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
+        q_push(&P.free_q, &pool[i]);
+    }
+    pthread_t wth;
+    if (pthread_create(&wth, NULL, writer_main, &P) != 0) {
+        ERROR("cmain", "%s", "cannot create the writer thread");
+        exit(EXIT_FAILURE);
+    }
+
+    /* on-disk bytes per sample: ~0.85 (zlib over svb-zd), ~1.3 (svb-zd only), 2 (raw); the batch limit is
+     * applied to the bytes read, which is all the loader knows before the records are inflated */
+    const uint64_t limit_bytes = batch_samples;
     int ret = 0;
+    batch_t *b = q_pop(&P.free_q);
     if (argc - optind == 1) {
-        while ((ret = b5_next(f, &rec)) >= 0) {
-            batch_push(&b, &rec);
-            if (b.offsets[b.n] >= limit) {
-                process_batch(&b, mode, opt, n_gpus);
-                batch_clear(&b);
+        for (;;) {
+            uint64_t size = 0;
+            const double t0 = realtime();
+            ret = b5_next_raw(f, &b->raw, &b->raw_len, &b->raw_cap, &size);
+            P.t_read += realtime() - t0;
+            if (ret < 0) break;
+            batch_add_record(b, size);
+            if (b->raw_len >= limit_bytes) {
+                batch_launch(&P, b);
+                b = q_pop(&P.free_q);
             }
         }
         if (ret != B5_EOF) {
@@ -485,20 +747,35 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         }
         for (int i = optind + 1; i < argc; i++) {
             fprintf(stderr, "Read ID %s\n", argv[i]);
-            if (b5_get(f, argv[i], &rec) < 0) {
+            uint64_t size = 0;
+            if (b5_get_raw(f, argv[i], &b->raw, &b->raw_len, &b->raw_cap, &size) < 0) {
                 ERROR("cmain", "%s", "Error when fetching the read");
                 exit(EXIT_FAILURE);
             }
-            batch_push(&b, &rec);
-            if (b.offsets[b.n] >= limit) {
-                process_batch(&b, mode, opt, n_gpus);
-                batch_clear(&b);
+            batch_add_record(b, size);
+            if (b->raw_len >= limit_bytes) {
+                batch_launch(&P, b);
+                b = q_pop(&P.free_q);
             }
         }
     }
-    process_batch(&b, mode, opt, n_gpus);
-    batch_free(&b);
-    b5_rec_free(&rec);
+    if (b->n) batch_launch(&P, b);
+    pool[nbatch].last = 1;
+    q_push(&P.ready_q, &pool[nbatch]);
+    pthread_join(wth, NULL);
+    fflush(stdout);
+    if (getenv("SGK_CLI_TIMING"))
+        fprintf(stderr,
+                "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
+                "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s\n",
+                (unsigned long)P.n_reads, (unsigned long)P.n_samples, nthreads, n_gpus, P.t_read, P.t_parse, P.t_stage,
+                P.t_wait, P.t_format, P.t_write);
+    for (int i = 0; i < nbatch; i++) {
+        sgk_job_destroy(pool[i].job);
+        for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
+        free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+    }
+    free(pool);
     b5_close(f);
     return 0;
 }
@@ -529,6 +806,44 @@ static int dumpmain(int argc, char *argv[]) {
     return ret == B5_EOF ? 0 : 1;
 }
 
+/* hidden helper for tests: fmt_f6 / fmt_i64 against snprintf on every stride-th float bit pattern */
+static int fmtcheckmain(int argc, char *argv[]) {
+    const uint32_t stride = argc > 1 ? (uint32_t)strtoul(argv[1], NULL, 10) : 9973u;
+    uint64_t bad = 0, n = 0;
+    char a[512], b[512];
+    for (uint64_t u = 0; u <= 0xffffffffull; u += stride ? stride : 1) {
+        const uint32_t w = (uint32_t)u;
+        float f;
+        memcpy(&f, &w, 4);
+        *fmt_f6(a, f) = '\0';
+        snprintf(b, sizeof b, "%f", f);
+        n++;
+        if (strcmp(a, b) != 0 && bad++ < 10) printf("MISMATCH %08x: %s vs %s\n", w, a, b);
+    }
+    /* ties and carries: k / 2^m around the 6th decimal, values just below integers */
+    for (int m = 1; m <= 30; m++)
+        for (int k = 1; k < 4000; k += 2) {
+            const float f = (float)k / (float)(1u << m);
+            const float g[4] = {f, -f, f + 123456.0f, 999999.0f + f};
+            for (int t = 0; t < 4; t++) {
+                *fmt_f6(a, g[t]) = '\0';
+                snprintf(b, sizeof b, "%f", g[t]);
+                n++;
+                if (strcmp(a, b) != 0 && bad++ < 10) printf("MISMATCH %a: %s vs %s\n", g[t], a, b);
+            }
+        }
+    const int64_t iv[] = {0, 1, -1, 9, 10, 99, 100, 12345, -98765, 2147483647LL, -2147483648LL, 4294967295LL,
+                          9223372036854775807LL, (-9223372036854775807LL - 1)};
+    for (size_t i = 0; i < sizeof iv / sizeof iv[0]; i++) {
+        *fmt_i64(a, iv[i]) = '\0';
+        snprintf(b, sizeof b, "%ld", (long)iv[i]);
+        n++;
+        if (strcmp(a, b) != 0 && bad++ < 10) printf("MISMATCH int: %s vs %s\n", a, b);
+    }
+    printf("checked %lu values, %lu mismatches\n", (unsigned long)n, (unsigned long)bad);
+    return bad ? 1 : 0;
+}
+
 /* ------------------------------------------------------------------ main (src/main.c:49-123) */
 
 static void print_usage(FILE *fp) {
@@ -553,6 +868,8 @@ int main(int argc, char *argv[]) {
         ret = cmain(argc - 1, argv + 1, argv[1]);
     } else if (strcmp(argv[1], "_dump") == 0) {
         return dumpmain(argc - 1, argv + 1);
+    } else if (strcmp(argv[1], "_fmtcheck") == 0) {
+        return fmtcheckmain(argc - 1, argv + 1);
     } else if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "-V") == 0) {
         fprintf(stdout, "sigtk %s\n", SIGTK_VERSION);
         exit(EXIT_SUCCESS);

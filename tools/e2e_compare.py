@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reads", type=int, default=500)
     ap.add_argument("--read-len", type=int, default=100000)
     ap.add_argument("--kind", type=int, default=0)
+    ap.add_argument("--cli-args", default="", help="extra options for sigtk-amd, e.g. '--host-decode -t 8'")
     a = ap.parse_args()
     reads, dig, off, rng = api.synth_reads_host(a.reads, a.read_len, 77, a.kind)
     recs = [blow5.Read("synth-%08d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
@@ -33,10 +34,13 @@ def main():
         out = {"reads": a.reads, "samples": a.reads * a.read_len, "file_mb": round(os.path.getsize(f) / 1e6, 1)}
         for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"]):
             name = " ".join(tool)
-            t0 = time.perf_counter(); g = subprocess.run([build.CLI, *tool, f], capture_output=True); tg = time.perf_counter() - t0
+            env = dict(os.environ, SGK_CLI_TIMING="1")
+            t0 = time.perf_counter(); g = subprocess.run([build.CLI, *tool, *a.cli_args.split(), f], capture_output=True, env=env); tg = time.perf_counter() - t0
+            stages = [ln for ln in g.stderr.decode(errors="replace").splitlines() if ln.startswith("[sigtk-amd]")]
             t0 = time.perf_counter(); r = subprocess.run([REF_BIN, *tool, f], capture_output=True, cwd=tmp); tr = time.perf_counter() - t0
             out[name] = {"identical": g.stdout == r.stdout and g.returncode == 0, "sigtk_amd_s": round(tg, 3),
-                         "reference_s": round(tr, 3), "stdout_mb": round(len(r.stdout) / 1e6, 1)}
+                         "reference_s": round(tr, 3), "stdout_mb": round(len(r.stdout) / 1e6, 1),
+                         "stages": stages[0] if stages else None}
         print(json.dumps(out))
 
 
