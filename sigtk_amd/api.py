@@ -54,6 +54,28 @@ class SegsHost(C.Structure):
                 ("x", C.POINTER(C.c_int32)), ("y", C.POINTER(C.c_int32))]
 
 
+class JobInput(C.Structure):
+    """sgk_job_input_t"""
+    _fields_ = [("samples", C.c_void_p), ("blobs", C.c_void_p), ("offsets", C.POINTER(C.c_uint64)),
+                ("blob_offsets", C.POINTER(C.c_uint64)), ("digitisation", C.POINTER(C.c_double)),
+                ("offset", C.POINTER(C.c_double)), ("range", C.POINTER(C.c_double)), ("n_samples", C.c_uint64)]
+
+
+class JobOutput(C.Structure):
+    """sgk_job_output_t"""
+    _fields_ = [("n_reads", C.c_uint32), ("offsets", C.POINTER(C.c_uint64)), ("lengths", C.POINTER(C.c_uint32)),
+                ("decode_status", C.POINTER(C.c_uint32)), ("pa", C.POINTER(C.c_float)),
+                ("slots", C.POINTER(C.c_uint64)), ("counts", C.POINTER(C.c_uint32)),
+                ("ev_start", C.POINTER(C.c_uint32)), ("ev_length", C.POINTER(C.c_uint32)),
+                ("ev_mean", C.POINTER(C.c_float)), ("ev_stdv", C.POINTER(C.c_float)),
+                ("seg_x", C.POINTER(C.c_int32)), ("seg_y", C.POINTER(C.c_int32)),
+                ("stat", C.c_void_p), ("prefix", C.c_void_p), ("event_status", EventStatus)]
+
+
+TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX = range(5)
+SIGNAL_INT16, SIGNAL_SVBZD = 0, 1
+JOB_EVENTS_COMPACT = 1
+
 STAT_DTYPE = np.dtype([("raw_mean", "<f4"), ("pa_mean", "<f4"), ("raw_std", "<f4"), ("pa_std", "<f4"),
                        ("raw_median", "<i4"), ("pa_median", "<f4"), ("n", "<u4"), ("reserved", "<u4")])
 PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i4"), ("polya_y", "<i4"),
@@ -118,6 +140,14 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_synth_reads_host.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
     L.sgk_synth_reads_host.restype = None
     L.sgk_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]
+    L.sgk_job_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sgk_job_destroy.argtypes = [C.c_void_p]
+    L.sgk_job_destroy.restype = None
+    L.sgk_job_device.argtypes = [C.c_void_p]
+    L.sgk_job_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(JobInput)]
+    L.sgk_job_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sgk_job_wait.argtypes = [C.c_void_p]
+    L.sgk_job_output.argtypes = [C.c_void_p, C.POINTER(JobOutput)]
     L.sgk_event_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.POINTER(EventsHost)]
     L.sgk_events_host_free.argtypes = [C.POINTER(EventsHost)]
     L.sgk_events_host_free.restype = None
@@ -265,3 +295,72 @@ def profile_read():
     calls = (C.c_uint32 * cap)()
     k = L.sgk_profile_read(names, ms, calls, cap)
     return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}
+
+
+class Job:
+    """A pipelined host job (sgk_job_*): pinned staging + device buffers + stream for one batch at a time.
+
+    `signals` is a list of int16 arrays (SIGNAL_INT16) or of svb-zd blobs as bytes (SIGNAL_SVBZD, with
+    `counts` = samples per read); results come back as numpy copies."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        check(self.L.sgk_job_create(device, C.byref(self.h)), "sgk_job_create")
+
+    def close(self):
+        if self.h:
+            self.L.sgk_job_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def submit(self, tool: int, signals, dig, off, rng, rna: int = 0, pore: int = 0, flags: int = 0, counts=None):
+        n = len(signals)
+        svb = counts is not None
+        lengths = np.asarray(counts if svb else [len(x) for x in signals], dtype=np.uint32)
+        blens = np.asarray([len(b) for b in signals], dtype=np.uint32) if svb else None
+        jin = JobInput()
+        check(self.L.sgk_job_begin(self.h, n, lengths.ctypes.data, SIGNAL_SVBZD if svb else SIGNAL_INT16,
+                                   blens.ctypes.data if svb else None, C.byref(jin)), "sgk_job_begin")
+        for r in range(n):
+            jin.digitisation[r] = float(dig[r]); jin.offset[r] = float(off[r]); jin.range[r] = float(rng[r])
+            if svb:
+                C.memmove(jin.blobs + jin.blob_offsets[r], signals[r], len(signals[r]))
+            elif lengths[r]:
+                x = np.ascontiguousarray(signals[r], dtype=np.int16)
+                C.memmove(jin.samples + 2 * jin.offsets[r], x.ctypes.data, x.nbytes)
+        self._tool = tool
+        check(self.L.sgk_job_submit(self.h, tool, rna, pore, flags), "sgk_job_submit")
+
+    def wait(self):
+        """-> dict of numpy results (per read lists for the variable-length outputs)"""
+        check(self.L.sgk_job_wait(self.h), "sgk_job_wait")
+        o = JobOutput()
+        check(self.L.sgk_job_output(self.h, C.byref(o)), "sgk_job_output")
+        n = o.n_reads
+        res = {"n_reads": n, "lengths": _np_from(o.lengths, n, np.uint32).copy()}
+        if self._tool == TOOL_PA:
+            res["pa"] = [_np_from(C.cast(C.addressof(o.pa.contents) + 4 * o.offsets[r], C.POINTER(C.c_float)),
+                                  int(o.lengths[r]), np.float32).copy() if o.lengths[r] else np.zeros(0, np.float32)
+                         for r in range(n)]
+        elif self._tool in (TOOL_EVENT, TOOL_JNN):
+            def seg(ptr, dtype, r):
+                k = int(o.counts[r])
+                if not k or not ptr:
+                    return np.zeros(0, dtype)
+                base = C.addressof(ptr.contents) + 4 * o.slots[r]
+                return _np_from(C.cast(base, C.POINTER(C.c_uint32)), k, np.uint32).view(dtype).copy()
+            if self._tool == TOOL_EVENT:
+                res["events"] = [Events(seg(o.ev_start, np.uint32, r), seg(o.ev_length, np.uint32, r),
+                                        seg(o.ev_mean, np.float32, r), seg(o.ev_stdv, np.float32, r))
+                                 for r in range(n)]
+                res["status"] = o.event_status
+            else:
+                res["segs"] = [(seg(o.seg_x, np.int32, r), seg(o.seg_y, np.int32, r)) for r in range(n)]
+        elif self._tool == TOOL_STAT:
+            res["stat"] = np.frombuffer(C.string_at(o.stat, n * STAT_DTYPE.itemsize), dtype=STAT_DTYPE).copy()
+        elif self._tool == TOOL_PREFIX:
+            res["prefix"] = np.frombuffer(C.string_at(o.prefix, n * PREFIX_DTYPE.itemsize), dtype=PREFIX_DTYPE).copy()
+        return res

@@ -780,28 +780,63 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     return 0;
 }
 
-/* hidden helper for tests: dump id, length, scaling and a checksum of every record */
+/* hidden helper for tests: dump id, length, scaling and a checksum of every record.  `--split` goes
+ * through the pipelined reader's split API (b5_next_raw + b5_parse_raw + b5_svb_zd_decode). */
+static uint64_t fnv_i16(const int16_t *x, uint64_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t i = 0; i < n; i++) {
+        h ^= (uint16_t)x[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
 static int dumpmain(int argc, char *argv[]) {
-    if (argc < 2) return 1;
-    b5_file_t *f = b5_open(argv[1]);
+    int split = 0;
+    const char *path = NULL;
+    for (int i = 1; i < argc; i++) {
+        if (strcmp(argv[i], "--split") == 0) split = 1;
+        else path = argv[i];
+    }
+    if (!path) return 1;
+    b5_file_t *f = b5_open(path);
     if (!f) {
-        ERROR("dumpmain", "cannot open %s. ", argv[1]);
+        ERROR("dumpmain", "cannot open %s. ", path);
         return 1;
     }
-    b5_rec_t rec;
-    memset(&rec, 0, sizeof rec);
     int ret;
     printf("#press\t%d\t%d\tgroups\t%u\n", f->record_press, f->signal_press, f->num_read_groups);
-    while ((ret = b5_next(f, &rec)) >= 0) {
-        uint64_t h = 1469598103934665603ull;
-        for (uint64_t i = 0; i < rec.len_raw_signal; i++) {
-            h ^= (uint16_t)rec.raw_signal[i];
-            h *= 1099511628211ull;
+    if (split) {
+        uint8_t *raw = NULL, *scratch = NULL;
+        uint64_t raw_len = 0, raw_cap = 0, scratch_cap = 0, size = 0, sig_cap = 0;
+        int16_t *sig = NULL;
+        while ((ret = b5_next_raw(f, &raw, &raw_len, &raw_cap, &size)) >= 0) {
+            b5_view_t v;
+            ret = b5_parse_raw(f, raw + raw_len - size, size, &scratch, &scratch_cap, &v);
+            if (ret < 0) break;
+            raw_len = 0;
+            if (v.n_samples > sig_cap) {
+                sig = (int16_t *)realloc(sig, sizeof(int16_t) * ((size_t)v.n_samples + 1));
+                if (!sig) die_mem();
+                sig_cap = v.n_samples;
+            }
+            if (f->signal_press == 1) {
+                ret = b5_svb_zd_decode(v.signal, v.signal_bytes, sig, v.n_samples);
+                if (ret < 0) break;
+            } else if (v.n_samples) {
+                memcpy(sig, v.signal, v.signal_bytes);
+            }
+            printf("%.*s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", (int)v.id_len, v.read_id, (unsigned long)v.n_samples,
+                   v.digitisation, v.offset, v.range, (unsigned long)fnv_i16(sig, v.n_samples));
         }
-        printf("%s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", rec.read_id, (unsigned long)rec.len_raw_signal,
-               rec.digitisation, rec.offset, rec.range, (unsigned long)h);
+        free(raw); free(scratch); free(sig);
+    } else {
+        b5_rec_t rec;
+        memset(&rec, 0, sizeof rec);
+        while ((ret = b5_next(f, &rec)) >= 0)
+            printf("%s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", rec.read_id, (unsigned long)rec.len_raw_signal,
+                   rec.digitisation, rec.offset, rec.range, (unsigned long)fnv_i16(rec.raw_signal, rec.len_raw_signal));
+        b5_rec_free(&rec);
     }
-    b5_rec_free(&rec);
     b5_close(f);
     return ret == B5_EOF ? 0 : 1;
 }

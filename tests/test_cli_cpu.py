@@ -54,6 +54,9 @@ def test_version_and_usage(cli):
 def _check_dump(cli, path, reads):
     p = run(cli, "_dump", path)
     assert p.returncode == 0, p.stderr
+    # the pipelined reader's split API (next_raw + parse_raw + svb decode) sees the same records
+    q = run(cli, "_dump", "--split", path)
+    assert q.returncode == 0 and q.stdout == p.stdout
     rows = [ln.split("\t") for ln in p.stdout.strip().split("\n")[1:]]
     assert len(rows) == len(reads)
     for row, r in zip(rows, reads):
@@ -91,3 +94,19 @@ def test_no_gpu_is_a_loud_error(cli):
     p = run(cli, "event", "-c", os.path.join(GOLDEN, "sp1_dna.blow5"))
     assert p.returncode == 1 and "no usable GPU" in p.stderr
     assert "DNA data detected" in p.stderr and "R9 data detected" in p.stderr
+
+
+def test_exact_fast_formatter_matches_printf(cli):
+    """fmt.h: "%f" of floats and "%ld" of integers, against snprintf on every 9973rd
+    float bit pattern plus ties/carries (dyadic fractions around the 6th decimal)."""
+    p = run(cli, "_fmtcheck", "9973")
+    assert p.returncode == 0 and p.stdout.strip().endswith("0 mismatches"), p.stdout
+
+
+def test_truncated_file_is_an_error(cli, tmp_path):
+    data = open(os.path.join(GOLDEN, "sp1_dna.blow5"), "rb").read()
+    path = str(tmp_path / "cut.blow5")
+    open(path, "wb").write(data[: len(data) // 2])
+    for extra in ([], ["--split"]):
+        p = run(cli, "_dump", *extra, path)
+        assert p.returncode == 1

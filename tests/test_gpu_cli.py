@@ -84,6 +84,42 @@ def test_no_header_and_small_batches(cli):
     assert out(cli, "stat", "--batch-samples", "5000", SP1) == gold("sp1_dna.stat.tsv")
 
 
+def test_pipeline_options_do_not_change_the_output(cli, synth_files):
+    """host svb-zd decode vs GPU decode, 1 vs many host threads, tiny batches (many jobs in flight)"""
+    for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["pa"]):
+        for f in (SP1, synth_files["synth_rna"] if "synth_rna" in synth_files else SP1):
+            if tool == ["pa"] and f != SP1:
+                continue
+            base = out(cli, *tool, f)
+            assert out(cli, *tool, "--host-decode", f) == base
+            assert out(cli, *tool, "-t", "1", f) == base
+            assert out(cli, *tool, "--threads", "7", "--batch-samples", "30000", f) == base
+
+
+@pytest.mark.parametrize("rp,sp", [(0, 0), (1, 0), (0, 1)])
+def test_other_compression_layouts(cli, tmp_path, sp1, rp, sp):
+    """record compression none/zlib x signal compression none/svb-zd (sp1_dna.blow5 itself is zlib + svb-zd)"""
+    path = str(tmp_path / "x.blow5")
+    blow5.write_blow5(path, sp1.reads, {"experiment_type": "genomic_dna", "sequencing_kit": "sqk-lsk109"}, rp, sp)
+    assert out(cli, "event", "-c", path) == gold("sp1_dna.event_c.tsv")
+    assert out(cli, "stat", path) == gold("sp1_dna.stat.tsv")
+
+
+def test_corrupt_signal_blob_fails_like_a_read_error(cli, tmp_path, sp1):
+    recs = [blow5.Read(r.read_id, 0, r.digitisation, r.offset, r.range, r.sampling_rate, r.raw) for r in sp1.reads[:3]]
+    path = str(tmp_path / "bad.blow5")
+    blow5.write_blow5(path, recs, {"experiment_type": "genomic_dna", "sequencing_kit": "sqk-lsk109"}, 0, 1)
+    data = bytearray(open(path, "rb").read())
+    # flip the count word of the last record's blob: the GPU decoder must flag it and the CLI must fail
+    blob = blow5.svb_zd_encode(recs[2].raw)
+    at = bytes(data).rfind(blob[:64])
+    assert at > 0
+    data[at] ^= 0x55
+    open(path, "wb").write(bytes(data))
+    p = subprocess.run([cli, "stat", path], capture_output=True)
+    assert p.returncode != 0
+
+
 def test_more_gpus_requested_than_present(cli):
     p = subprocess.run([cli, "stat", "--gpus", "64", SP1], capture_output=True)
     assert p.returncode == 0 and p.stdout == gold("sp1_dna.stat.tsv")

@@ -1,0 +1,118 @@
+"""GPU: the pipelined host jobs (sgk_job_*, include/sigtk_gpu.h) -- every subtool through a job, fed with
+int16 samples and with svb-zd blobs (decoded on the device), against the oracle; jobs are recycled
+across batches of different sizes and several jobs are in flight at once."""
+import numpy as np
+import pytest
+
+from sigtk_amd import blow5
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_events(got, exp, what):
+    assert got.start.size == exp.start.size, "%s: %d events, oracle %d" % (what, got.start.size, exp.start.size)
+    assert np.array_equal(got.start.astype(np.uint64), exp.start.astype(np.uint64)), what
+    assert np.array_equal(got.length.astype(np.uint64), exp.length.astype(np.uint64)), what
+    assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32)), what
+    assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32)), what
+
+
+def _batch(gpu, lens, seed, kind):
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=seed, kind=kind)
+    return reads, dig, off, rng
+
+
+@pytest.mark.parametrize("svb", [False, True])
+def test_all_subtools_through_a_recycled_job(gpu, oracle, svb):
+    job = gpu.Job(0)
+    # three batches of different geometry through the SAME job: buffers grow, then are reused
+    for b, lens in enumerate(([5000, 100000, 333, 70001], [100000] * 6 + [0, 1, 250], [64, 4096])):
+        kind = b % 2
+        reads, dig, off, rng = _batch(gpu, lens, 20 + b, kind)
+        sig = [blow5.svb_zd_encode(r) for r in reads] if svb else reads
+        counts = [r.size for r in reads] if svb else None
+
+        job.submit(gpu.TOOL_EVENT, sig, dig, off, rng, rna=kind, counts=counts)
+        res = job.wait()
+        for r, raw in enumerate(reads):
+            if raw.size == 0:
+                assert res["events"][r].start.size == 0
+                continue
+            _same_events(res["events"][r], oracle.event_raw(raw, dig[r], off[r], rng[r], kind), "event read %d" % r)
+
+        job.submit(gpu.TOOL_EVENT, sig, dig, off, rng, rna=kind, flags=gpu.JOB_EVENTS_COMPACT, counts=counts)
+        res = job.wait()
+        for r, raw in enumerate(reads):
+            if raw.size:
+                exp = oracle.event_raw(raw, dig[r], off[r], rng[r], kind)
+                assert np.array_equal(res["events"][r].length.astype(np.uint64), exp.length.astype(np.uint64))
+                assert res["events"][r].mean.size == 0   # not copied back in compact mode
+
+        job.submit(gpu.TOOL_STAT, sig, dig, off, rng, counts=counts)
+        st = job.wait()["stat"]
+        for r, raw in enumerate(reads):
+            if raw.size == 0:
+                continue
+            e = oracle.stat(raw, dig[r], off[r], rng[r])
+            assert int(st[r]["raw_median"]) == e[4]
+            for name, ev in (("raw_mean", e[0]), ("pa_mean", e[1]), ("raw_std", e[2]), ("pa_std", e[3]), ("pa_median", e[5])):
+                assert np.float32(st[r][name]).view(np.uint32) == np.float32(ev).view(np.uint32), (r, name)
+
+        job.submit(gpu.TOOL_JNN, sig, dig, off, rng, rna=kind, counts=counts)
+        segs = job.wait()["segs"]
+        for r, raw in enumerate(reads):
+            ex, ey = oracle.jnn_raw(raw, kind)
+            assert np.array_equal(segs[r][0].astype(np.int64), ex) and np.array_equal(segs[r][1].astype(np.int64), ey)
+
+        job.submit(gpu.TOOL_PA, sig, dig, off, rng, counts=counts)
+        pa = job.wait()["pa"]
+        for r, raw in enumerate(reads):
+            assert np.array_equal(pa[r].view(np.uint32), oracle.pa(raw, dig[r], off[r], rng[r]).view(np.uint32))
+
+        job.submit(gpu.TOOL_PREFIX, sig, dig, off, rng, rna=kind, pore=0, counts=counts)
+        pf = job.wait()["prefix"]
+        for r, raw in enumerate(reads):
+            if raw.size == 0:
+                continue
+            e = oracle.prefix(raw, dig[r], off[r], rng[r], kind, 0)
+            assert (int(pf[r]["adapt_x"]), int(pf[r]["adapt_y"])) == (e.adapt_x, e.adapt_y), r
+            assert (int(pf[r]["polya_x"]), int(pf[r]["polya_y"])) == (e.polya_x, e.polya_y), r
+            if e.adapt_y > 0:
+                assert np.float32(pf[r]["adapt_mean"]).view(np.uint32) == np.float32(e.adapt_mean).view(np.uint32)
+    job.close()
+
+
+def test_jobs_in_flight_concurrently(gpu, oracle):
+    jobs = [gpu.Job(0) for _ in range(3)]
+    batches = [_batch(gpu, [30000 + 1000 * k] * 4, 40 + k, 0) for k in range(3)]
+    for j, (reads, dig, off, rng) in zip(jobs, batches):
+        j.submit(gpu.TOOL_EVENT, reads, dig, off, rng)        # all three enqueued before any wait
+    for j, (reads, dig, off, rng) in zip(jobs, batches):
+        res = j.wait()
+        for r, raw in enumerate(reads):
+            _same_events(res["events"][r], oracle.event_raw(raw, dig[r], off[r], rng[r], 0), "read %d" % r)
+    for j in jobs:
+        j.close()
+
+
+def test_malformed_blob_is_reported(gpu):
+    reads, dig, off, rng = _batch(gpu, [5000, 5000], 7, 0)
+    blobs = [blow5.svb_zd_encode(r) for r in reads]
+    blobs[1] = blobs[1][:-10]                                  # truncated data bytes
+    job = gpu.Job(0)
+    job.submit(gpu.TOOL_STAT, blobs, dig, off, rng, counts=[5000, 5000])
+    with pytest.raises(Exception, match="malformed compressed signal"):
+        job.wait()
+    # the job stays usable
+    job.submit(gpu.TOOL_STAT, reads, dig, off, rng)
+    assert job.wait()["stat"].size == 2
+    job.close()
+
+
+def test_empty_batch_and_misuse(gpu):
+    job = gpu.Job(0)
+    job.submit(gpu.TOOL_STAT, [], [], [], [])
+    assert job.wait()["n_reads"] == 0
+    with pytest.raises(Exception):
+        job.wait()                                             # nothing submitted
+    job.close()
