@@ -1,6 +1,6 @@
 // oracle/verify_math.cpp -- TEST INFRASTRUCTURE ONLY.
 // Checks the fast arithmetic of sigtk_amd/csrc/tstat_math.h against plain IEEE division / sqrt:
-//   1. sgk_div_f32<W>  == a / (float)W   EXHAUSTIVELY over all finite floats with |a| >= 2^-100 (W = 3, 6, 7, 14)
+//   1. sgk_div_f32<W>  == a / (float)W   EXHAUSTIVELY over all finite floats with |a| >= 2^-100 (W = 3, 6, 7, 14, and 2000 for the jnnv2 rolling mean)
 //   2. sgk_div_f64<W>  == a / (double)W  on random and structured doubles
 //   3. sgk_tstat_tail  == (float)(fabs((double)d)/sqrt((double)v)) with the hardware rsqrt modelled
 //      as 1/sqrt(v) perturbed by up to 2^-22 relative (robustness of the run-time certificate)
@@ -143,6 +143,7 @@ int main(int argc, char **argv) {
     b = check_div32<6>(step);  printf("div_f32<6>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div32<7>(step);  printf("div_f32<7>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div32<14>(step); printf("div_f32<14>  mismatches: %llu\n", (unsigned long long)b); bad += b;
+    b = check_div32<2000>(step); printf("div_f32<2000> mismatches: %llu\n", (unsigned long long)b); bad += b;  // jnnv2 rolling mean
     b = check_div64<3>(n64);   printf("div_f64<3>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div64<6>(n64);   printf("div_f64<6>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div64<7>(n64);   printf("div_f64<7>   mismatches: %llu\n", (unsigned long long)b); bad += b;

@@ -15,6 +15,7 @@
 #include "row_stream.h"
 #include "sgk_common.h"
 #include "stat_args.h"
+#include "tstat_math.h"
 
 namespace sgk {
 
@@ -269,31 +270,43 @@ struct JnnAuto {
         first_min = (float)window_ * stall_len;
         open = 0; err = 0; run_err = 0; c = 0; w = corrector; start = 0; nseg = 0; last_x = 0; last_y = 0;
     }
-    // emit(k, x, y) is called when segment k can no longer change
+    // emit(k, x, y) is called when segment k can no longer change.  The per-sample bookkeeping is written
+    // with selects (the lanes of a wave run different reads, so every branch taken by any lane costs the
+    // whole wave); only closing a segment -- rare -- branches.
     template <typename E>
-    __device__ void step(int i, float v, E emit) {
-        if (v < top && v > bot) {
-            if (!open) { start = i; open = 1; }
-            ++c; ++w;
-            run_err = 0;
-            if (c >= window && c >= w && (c % w) == 0) --err;
-        } else if (open && err < error) {
-            ++c; ++err; ++run_err;
-            if (c >= window && c >= w && (c % w) == 0) --err;
-        } else if (open && (c >= window || (nseg == 0 && (float)c >= first_min))) {
-            const int end = i - run_err;
-            open = 0;
-            if (nseg > 0 && start - last_y < seg_dist) {
-                last_y = end;
-            } else {
-                if (nseg > 0) emit(nseg - 1, last_x, last_y);
-                last_x = start; last_y = end;
-                ++nseg;
-            }
-            c = 0; err = 0; run_err = 0;
-        } else if (open) {
-            open = 0; c = 0; err = 0; run_err = 0;
+    __device__ __forceinline__ void step(int i, float v, E emit) {
+        const bool in = (v < top) & (v > bot);
+        const bool opn = open != 0;
+        const bool tol = !in & opn & (err < error);                 // tolerated out-of-range sample
+        const bool rest = !in & opn & !tol;
+        const bool cnt = in | tol;
+        start = (in & !opn) ? i : start;
+        const int c1 = c + (cnt ? 1 : 0);
+        const int w1 = w + (in ? 1 : 0);
+        int err1 = err + (tol ? 1 : 0);
+        // "if (c >= window && c >= w && c % w == 0) err--" (jnn.c:228, 238): c >= w needs more tolerated
+        // samples in the segment than in-range samples before it -- rare, so the modulo sits behind a branch
+        if (cnt & (c1 >= window) & (c1 >= w1)) {
+            if ((c1 % w1) == 0) --err1;
         }
+        run_err = in ? 0 : (tol ? run_err + 1 : run_err);
+        if (rest) {
+            if (c >= window || (nseg == 0 && (float)c >= first_min)) {
+                const int end = i - run_err;
+                if (nseg > 0 && start - last_y < seg_dist) {
+                    last_y = end;
+                } else {
+                    if (nseg > 0) emit(nseg - 1, last_x, last_y);
+                    last_x = start; last_y = end;
+                    ++nseg;
+                }
+            }
+            open = 0; c = 0; err = 0; run_err = 0;
+        } else {
+            open = in ? 1 : open;
+            c = c1; err = err1;
+        }
+        w = w1;
     }
     template <typename E>
     __device__ void finish(E emit) {
@@ -374,27 +387,31 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
 // rolling window mean (jnn.c:20-56) of the clamped raw signal, its sequential float mean/std,
 // then the below-threshold run finder with merging; first run with lo <= length <= hi.
 struct RunFinder {
-    float bot;
+    int t_lt, t_gt;  // tot < t_lt  <=>  t < bot;   tot >= t_gt  <=>  t > bot   (see roll_threshold)
     int seg_dist, lo, hi;
     int in_run, start, end, nseg, last_x, last_y, ans_x, ans_y, found;
-    __device__ void init(float bot_, int seg_dist_, int lo_, int hi_) {
-        bot = bot_; seg_dist = seg_dist_; lo = lo_; hi = hi_;
+    __device__ void init(int t_lt_, int t_gt_, int seg_dist_, int lo_, int hi_) {
+        t_lt = t_lt_; t_gt = t_gt_; seg_dist = seg_dist_; lo = lo_; hi = hi_;
         in_run = 0; start = 0; end = 0; nseg = 0; last_x = 0; last_y = 0; ans_x = 0; ans_y = 0; found = 0;
     }
     __device__ void settle() {  // the last segment can no longer change
         const int len = last_y - last_x;
         if (!found && !(len > hi) && !(len < lo)) { found = 1; ans_x = last_x; ans_y = last_y; }
     }
-    __device__ void step(int j, float v) {
-        if (v < bot && !in_run) { start = j; in_run = 1; }
-        else if (v < bot) { end = j; }
-        else if (v > bot && in_run) {
+    __device__ __forceinline__ void step(int j, int tot) {
+        const bool below = tot < t_lt, above = tot >= t_gt;
+        // selects for the per-sample updates; only the (rare) end of a run branches
+        start = (below & !in_run) ? j : start;
+        end = (below & (in_run != 0)) ? j : end;
+        if (above & (in_run != 0)) {
             if (nseg > 0 && start - last_y < seg_dist) last_y = end;
             else {
                 if (nseg > 0) settle();
                 last_x = start; last_y = end; ++nseg;
             }
             start = 0; end = 0; in_run = 0;
+        } else {
+            in_run = below ? 1 : in_run;
         }
     }
     __device__ void finish() { if (nseg > 0) settle(); }
@@ -402,38 +419,43 @@ struct RunFinder {
 
 constexpr int ADW = 2000;  // jnnv2 window (both presets, src/jnn.h:84-98)
 
-// One rolling-window sweep: calls f(i, t_i) for i = 0..m-1 (m = n - ADW) in order.  The trailing
-// edge is a second row stream whose base is shifted by 16 samples, so that its tiles line up with
-// the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
+__device__ inline int clampi_raw(int16_t v) {  // rm_outlier as an integer (the float it yields is that integer)
+    return v > 1200 ? 1200 : (v < 0 ? 0 : (int)v);
+}
+// rolling_window's t_i = tt / w (src/jnn.c:20-56).  tt is a float holding an exact integer (< 2000*1200 < 2^24),
+// so it is carried as an int here; the division by the constant 2000 is the correctly rounded three-operation
+// form of tstat_math.h (verified exhaustively for every float >= 2^-100 by oracle/verify_math.cpp).
+__device__ __forceinline__ float roll_mean(int tot) { return sgk_div_f32<ADW>((float)tot); }
+
+// One rolling-window sweep: calls f(i, tot_i) for i = 0..m-1 (m = n - ADW) in order, tot_i = sum of the clamped
+// samples x[i .. i+ADW).  The trailing edge is a second row stream whose base is shifted by 16 samples, so that
+// its tiles line up with the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
 template <int K, typename F>
 __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int64_t il0,
-                                              int64_t n, float &tot, F &f) {
+                                              int64_t n, int &tot, F &f) {
     if constexpr (K < TILE) {
         const int64_t il = il0 + K;  // lead index
         if (il >= 0 && il < n) {
-            const float cl = clampf_raw(RowPrefetch::sample<K>(wl));
+            const int cl = clampi_raw(RowPrefetch::sample<K>(wl));
             if (il < ADW) {
                 tot = tot + cl;
-                if (il == ADW - 1) f((int64_t)0, tot / (float)ADW);
+                if (il == ADW - 1) f((int64_t)0, tot);
             } else {
-                const float ct = clampf_raw(RowPrefetch::sample<K>(wt));
+                const int ct = clampi_raw(RowPrefetch::sample<K>(wt));
                 tot = tot - ct;
                 tot = tot + cl;
-                f(il - ADW + 1, tot / (float)ADW);
+                f(il - ADW + 1, tot);
             }
         }
         rolling_elems<K + 1>(wl, wt, il0, n, tot, f);
     }
 }
 template <int K, typename F>
-__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int il0, float &tot,
+__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int il0, int &tot,
                                              F &f) {
     if constexpr (K < TILE) {
-        const float cl = clampf_raw(RowPrefetch::sample<K>(wl));
-        const float ct = clampf_raw(RowPrefetch::sample<K>(wt));
-        tot = tot - ct;
-        tot = tot + cl;
-        f((int64_t)(il0 + K - ADW + 1), tot / (float)ADW);
+        tot += clampi_raw(RowPrefetch::sample<K>(wl)) - clampi_raw(RowPrefetch::sample<K>(wt));
+        f((int64_t)(il0 + K - ADW + 1), tot);
         rolling_full<K + 1>(wl, wt, il0, tot, f);
     }
 }
@@ -443,7 +465,7 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
     const int ntiles = (maxq + TILE - 1) / TILE;
     if (ntiles == 0) return;
     constexpr int LAG = 31;  // tiles between the two streams
-    float tot = 0.0f;
+    int tot = 0;
     lead.issue(0);
     lead.commit(0);
     for (int t = 0; t < ntiles; ++t) {
@@ -464,6 +486,21 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
     }
 }
 
+// smallest integer total whose rolling mean is >= x (resp. > x): roll_mean is non-decreasing in tot, so
+// the run finder's float comparisons t < bot / t > bot (src/jnn.c:139-163) become integer comparisons
+// tot < T_lt / tot >= T_gt.  Binary search over [0, 2000*1200].
+__device__ inline int roll_threshold(float x, bool strict) {
+    if (x != x) return strict ? 0x7fffffff : 0;  // NaN threshold: no t is < or > it
+    int lo = 0, hi = ADW * 1200 + 1;  // answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float t = roll_mean(mid);
+        const bool ok = strict ? (t > x) : (t >= x);   // NaN x: never ok -> hi stays -> nothing is >= / > x
+        if (ok) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
     __shared__ __attribute__((aligned(16))) char lds[2 * Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
@@ -480,17 +517,18 @@ __global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
     const int64_t m = n - ADW;
     const float mf = (float)(int)m;
     float s = 0.0f;
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) { if (i < m) s = s + t; });
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) { if (i < m) s = s + roll_mean(tot); });
     const float mn = s / mf;
     float q = 0.0f;
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) {
-        if (i < m) { const float d = t - mn; q = q + d * d; }
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) {
+        if (i < m) { const float d = roll_mean(tot) - mn; q = q + d * d; }
     });
     const float sd = sqrtf(q / mf);
     const float std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
     RunFinder F;
-    F.init(mn - sd * std_scale, 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, float t) { if (i < m) F.step((int)i, t); });
+    const float bot = mn - sd * std_scale;
+    F.init(roll_threshold(bot, false), roll_threshold(bot, true), 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
+    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) { if (i < m) F.step((int)i, tot); });
     F.finish();
     if (!valid) return;
     sgk_prefix_rec_t *o = a.prefix + r;
