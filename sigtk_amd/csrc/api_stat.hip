@@ -35,11 +35,16 @@ int sgk_stat(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_byte
 }
 
 int sgk_stat_pa(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream) {
-    int rc = sgk_stat(b, out, ws, ws_bytes, stream);
+    (void)ws; (void)ws_bytes;
+    const int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
-    if (!pa_out) return SGK_ERR_ARG;
-    return launch_pa(b, pa_out, static_cast<hipStream_t>(stream));
+    if (!out || !pa_out) return SGK_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(pa_out) & 15u) return SGK_ERR_ALIGN;
+    StatArgs a = make_args(b);
+    a.stat = out;
+    a.pa_out = pa_out;  // the median pass streams every sample anyway: it writes the pA values as it goes
+    return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
 int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,

@@ -966,19 +966,16 @@ __device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_l
         f.A2 = f.A2 + (double)x; f.A2q = f.A2q + (double)xq;
         if (k <= W1) { f.A1 = f.A1 + (double)x; f.A1q = f.A1q + (double)xq; }
     }
-    {
-        // B windows need x[i_begin .. i_begin+W2): not in the ring yet (that is the cur group's range
-        // shifted by W2), so take them from memory directly (clamped like every other load)
+    // B windows: x[i_begin .. i_begin+W2) is the tail of the three groups just stored.  They MUST come from
+    // the ring as well: a group that load_lead had to redirect (chunk 0 of a read with exactly `lead` samples
+    // of head room) holds shifted samples, and every value has to leave a window sum as the same number it
+    // entered with -- the running sums never reset, so one mismatch would stay in them for the whole chunk.
 #pragma unroll
-        for (int k = 0; k < W2; ++k) {
-            int p = i_begin + k;
-            p = p > f.hi - 1 ? f.hi - 1 : p;
-            p = p < f.lo ? f.lo : p;
-            const float x = to_pa(f.base[p], f.sc);
-            const float xq = x * x;
-            f.B2 = f.B2 + (double)x; f.B2q = f.B2q + (double)xq;
-            if (k < W1) { f.B1 = f.B1 + (double)x; f.B1q = f.B1q + (double)xq; }
-        }
+    for (int k = 0; k < W2; ++k) {
+        const float x = f.hist(i_begin + k);
+        const float xq = x * x;
+        f.B2 = f.B2 + (double)x; f.B2q = f.B2q + (double)xq;
+        if (k < W1) { f.B1 = f.B1 + (double)x; f.B1q = f.B1q + (double)xq; }
     }
 
     f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : snap->st0[lane_id()];

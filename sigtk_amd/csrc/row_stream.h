@@ -71,33 +71,49 @@ namespace sgk {
 
 // Prefetching variant for int16 rows, used by the lane-per-read kernels (stat / jnn / prefix):
 //   issue(t)   every lane starts its eight 16-byte global loads of tile t (no wait),
-//   commit(t)  waits for them and writes them into LDS slot t&1,
-//   row(t, w)  copies this lane's 64-sample row of tile t from LDS into 32 registers.
-// A sweep issues tile t+1, consumes tile t out of registers (pure arithmetic, no memory op on the
-// serial float chain), then commits t+1.  Rows must start on a multiple of 8 samples (callers align
-// the row base down and skip the leading samples) and the buffer base must be 16-byte aligned.
+//   commit(t)  waits for them and writes them into the wave's LDS tile,
+//   row(w)     copies this lane's 64-sample row of the resident tile from LDS into 32 registers.
+// A sweep issues tile t+1, copies tile t into registers, consumes it (pure arithmetic, no memory op on
+// the serial float chain), then commits t+1 over the same LDS tile: one tile per stream is resident
+// (8.4 KB per wave), so LDS never limits the number of waves per CU.  Rows must start on a multiple of 8
+// samples (callers align the row base down and skip the leading samples) and the buffer base must be
+// 16-byte aligned.  The bases of the eight rows a lane fetches pieces of are kept as 32-bit offsets
+// (units of 8 samples) from the wave's first row.
 struct RowPrefetch {
-    static constexpr int ROW_BYTES = 2 * TILE * 2 + 4;
+    static constexpr int ROW_BYTES = TILE * 2 + 4;
     static constexpr int LDS_BYTES = 64 * ROW_BYTES;
     char *lds;
     const int16_t *base;
     int64_t hi;   // readable samples in [0, hi), hi a multiple of 8
     int64_t rb;   // this lane's row base (multiple of 8)
+    int64_t rb0;  // wave-uniform: the smallest row base of the wave
+    int shift8;   // added to every row base, in units of 8 samples (a second stream over the same rows)
     uint4 pf[8];
-    int64_t rb_of[8];  // row bases of the eight rows this lane fetches pieces of
+    uint32_t rb_of[8];  // (row base - rb0) / 8 of the eight rows this lane fetches pieces of
     unsigned long long rowmask;
 
     __device__ void init(char *lds_, const int16_t *base_, int64_t hi_, int64_t rb_, unsigned long long rowmask_) {
-        lds = lds_; base = base_; hi = hi_; rb = rb_; rowmask = rowmask_;
+        lds = lds_; base = base_; hi = hi_; rb = rb_; rowmask = rowmask_; shift8 = 0;
         const int l = lane_id();
+        const bool wanted = (rowmask_ >> l) & 1ull;
+        long long m = wanted ? (long long)rb_ : 0x7fffffffffffffffll;  // rows nobody wants do not move the base
 #pragma unroll
-        for (int it = 0; it < 8; ++it) rb_of[it] = (int64_t)__shfl((long long)rb, it * 8 + l / 8, 64);
+        for (int d = 32; d >= 1; d >>= 1) {
+            const long long o = __shfl_xor(m, d, 64);
+            m = o < m ? o : m;
+        }
+        rb0 = (m == 0x7fffffffffffffffll) ? 0 : m;
+        const uint32_t mine = wanted ? (uint32_t)((rb_ - rb0) >> 3) : 0u;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rb_of[it] = (uint32_t)__shfl((int)mine, it * 8 + l / 8, 64);
+    }
+    __device__ __forceinline__ int64_t piece_pos(int it, int tile) const {
+        return rb0 + (((int64_t)rb_of[it] + shift8) << 3) + (int64_t)tile * TILE + (lane_id() & 7) * 8;
     }
     __device__ __forceinline__ void issue(int tile) {
-        const int v = lane_id() & 7;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            int64_t p0 = rb_of[it] + (int64_t)tile * TILE + v * 8;
+            int64_t p0 = piece_pos(it, tile);
             p0 = p0 > hi - 8 ? hi - 8 : p0;
             p0 = p0 < 0 ? 0 : p0;
             pf[it] = *reinterpret_cast<const uint4 *>(base + p0);
@@ -106,25 +122,35 @@ struct RowPrefetch {
     __device__ __forceinline__ void commit(int tile) {
         const int l = lane_id();
         const int v = l & 7;
-        __syncthreads();
+        __syncthreads();  // every lane has copied the previous tile into registers
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + l / 8;
-            const int64_t p0 = rb_of[it] + (int64_t)tile * TILE + v * 8;
+            const int64_t p0 = piece_pos(it, tile);
             uint4 q = pf[it];
             if (p0 < 0 || p0 > hi - 8) q = make_uint4(0u, 0u, 0u, 0u);  // outside the buffer: zeros
-            uint32_t *dst = reinterpret_cast<uint32_t *>(lds + row * ROW_BYTES + (tile & 1) * TILE * 2 + v * 16);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(lds + row * ROW_BYTES + v * 16);
             dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
         }
         __syncthreads();
     }
-    __device__ __forceinline__ void row(int tile, uint32_t (&w)[32]) const {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES + (tile & 1) * TILE * 2);
+    __device__ __forceinline__ void row(uint32_t (&w)[32]) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES);
 #pragma unroll
         for (int k = 0; k < 32; ++k) w[k] = src[k];
     }
     template <int K>
     static __device__ __forceinline__ int16_t sample(const uint32_t (&w)[32]) {
+        return (K & 1) ? (int16_t)(w[K / 2] >> 16) : (int16_t)(w[K / 2] & 0xffffu);
+    }
+    // half rows (32 samples, 16 registers) for kernels that hold two streams at once
+    __device__ __forceinline__ void row_half(int h, uint32_t (&w)[16]) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES) + h * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = src[k];
+    }
+    template <int K>
+    static __device__ __forceinline__ int16_t sample_half(const uint32_t (&w)[16]) {
         return (K & 1) ? (int16_t)(w[K / 2] >> 16) : (int16_t)(w[K / 2] & 0xffffu);
     }
 };

@@ -14,11 +14,12 @@ struct StatArgs {
     int32_t *seg_x, *seg_y;
     uint32_t *n_segs;
     uint32_t *err_count;         // workspace: number of reads whose segments overflowed their slots
+    float *pa_out;               // stat+pa fused: pA of every sample, written by the median pass (or null)
 };
 
 int check_batch(const sgk_batch_t *b);
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
-int launch_stat(const StatArgs &a, hipStream_t st);
+int launch_stat(const StatArgs &a, hipStream_t st);  // a.pa_out != null: fused stat + pa
 int launch_jnn(const StatArgs &a, int rna, hipStream_t st);
 int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st);
 

@@ -91,7 +91,7 @@ __device__ inline void sweep_rows(RowPrefetch &rs, int skip, int64_t len, F f) {
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) rs.issue(t + 1);
         uint32_t w[32];
-        rs.row(t, w);
+        rs.row(w);
         const int64_t j0 = (int64_t)t * TILE - skip;
         // common case: the whole tile lies inside every lane's row -> no per-sample predicates
         if (__all(j0 >= 0 && j0 + TILE <= len)) sweep_tile_full<0>(w, (int)j0, f);
@@ -154,17 +154,26 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
 
 // ---------------------------------------------------------------- median (src/stat.h:56-73)
 // Visit every key of x[0..n) with a 256-thread workgroup: 16-byte vector loads over the aligned
-// middle (four in flight per thread), scalar loads for the unaligned head and tail.
-template <typename F>
-__device__ __forceinline__ void visit_keys(const int16_t *x, int64_t n, F f) {
+// middle (four in flight per thread), scalar loads for the unaligned head and tail.  With PA, pa[i] =
+// signal_in_picoamps(x[i]) is written on the way (two 16-byte stores per vector): the fused stat + pa of
+// BASELINE config 4 costs no extra pass over the samples.
+template <bool PA, typename F>
+__device__ __forceinline__ void visit_keys(const int16_t *x, int64_t n, F f, float *pa = nullptr,
+                                           Scale sc = Scale{0.0f, 1.0f}) {
     const int t = threadIdx.x;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
     int64_t head = (int64_t)(((16 - (addr & 15)) & 15) / 2);
     if (head > n) head = n;
     const int64_t nvec = (n - head) / 8;
     const int64_t tail0 = head + nvec * 8;
-    if (t < head) f((uint32_t)((int)x[t] + 32768));
-    if (tail0 + t < n && t < 8) f((uint32_t)((int)x[tail0 + t] + 32768));
+    if (t < head) {
+        f((uint32_t)((int)x[t] + 32768));
+        if (PA) pa[t] = to_pa(x[t], sc);
+    }
+    if (tail0 + t < n && t < 8) {
+        f((uint32_t)((int)x[tail0 + t] + 32768));
+        if (PA) pa[tail0 + t] = to_pa(x[tail0 + t], sc);
+    }
     const uint4 *v = reinterpret_cast<const uint4 *>(x + head);
     for (int64_t i = t; i < nvec; i += 256 * 4) {
         uint4 q[4];
@@ -175,12 +184,21 @@ __device__ __forceinline__ void visit_keys(const int16_t *x, int64_t n, F f) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i + (int64_t)u * 256 < nvec) {
+            const int64_t k = i + (int64_t)u * 256;
+            if (k < nvec) {
                 const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                float o[8];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    f((uint32_t)((int)(int16_t)(w[d] & 0xffffu) + 32768));
-                    f((uint32_t)((int)(int16_t)(w[d] >> 16) + 32768));
+                    const int16_t s0 = (int16_t)(w[d] & 0xffffu), s1 = (int16_t)(w[d] >> 16);
+                    f((uint32_t)((int)s0 + 32768));
+                    f((uint32_t)((int)s1 + 32768));
+                    if (PA) { o[2 * d] = to_pa(s0, sc); o[2 * d + 1] = to_pa(s1, sc); }
+                }
+                if (PA) {
+                    float4 *dst = reinterpret_cast<float4 *>(pa + head + k * 8);  // x + head is 16-byte aligned
+                    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
                 }
             }
         }
@@ -188,11 +206,13 @@ __device__ __forceinline__ void visit_keys(const int16_t *x, int64_t n, F f) {
 }
 
 // rank-k order statistic of the int16 keys of a region, by a 256-thread workgroup
-__device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t *hist /*4096*/, uint32_t *part /*256+2*/) {
+template <bool PA = false>
+__device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t *hist /*4096*/, uint32_t *part /*256+2*/,
+                            float *pa = nullptr, Scale sc = Scale{0.0f, 1.0f}) {
     const int t = threadIdx.x;
     for (int i = t; i < 4096; i += 256) hist[i] = 0;
     __syncthreads();
-    visit_keys(x, n, [&](uint32_t key) { atomicAdd(&hist[key >> 4], 1u); });
+    visit_keys<PA>(x, n, [&](uint32_t key) { atomicAdd(&hist[key >> 4], 1u); }, pa, sc);
     __syncthreads();
     uint32_t s = 0;
 #pragma unroll
@@ -218,7 +238,7 @@ __device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t 
     __syncthreads();
     if (t < 16) hist[t] = 0;
     __syncthreads();
-    visit_keys(x, n, [&](uint32_t key) {
+    visit_keys<false>(x, n, [&](uint32_t key) {
         if ((key >> 4) == bin) atomicAdd(&hist[key & 15u], 1u);
     });
     __syncthreads();
@@ -236,25 +256,91 @@ __device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t 
     return res;
 }
 
-template <int MODE>
+// Order statistics of ranks k1 and k2 from ONE pass: an LDS histogram with one bin per raw value over the window
+// [lo, lo + RANGE_BINS) (centred on the read's mean, which k_moments has already written); values outside are
+// clipped into the two edge bins.  A rank that lands in an edge bin is not trusted (ok = false -> the caller
+// falls back to the two-level select).  Nanopore raw signals span a few hundred ADC codes, so this is the path taken.
+constexpr int RANGE_BINS = 8192;
+template <bool PA>
+__device__ bool block_select_range(const int16_t *x, int64_t n, int64_t k1, int64_t k2, int lo,
+                                   uint32_t *hist /*RANGE_BINS*/, uint32_t *part /*256+4*/, int &r1, int &r2,
+                                   float *pa, Scale sc) {
+    const int t = threadIdx.x;
+    constexpr int nb = RANGE_BINS, per = RANGE_BINS / 256;
+    for (int i = t; i < nb; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int base = lo + 32768;
+    visit_keys<PA>(x, n, [&](uint32_t key) {
+        int b = (int)key - base;
+        b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
+        atomicAdd(&hist[b], 1u);
+    }, pa, sc);
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < per; ++k) s += hist[t * per + k];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
+    }
+    __syncthreads();
+    const uint32_t before = part[t];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int64_t rank = w ? k2 : k1;
+        if ((uint64_t)rank >= before && (uint64_t)rank < (uint64_t)before + s) {
+            uint32_t acc = before;
+            for (int k = 0; k < per; ++k) {
+                const uint32_t h = hist[t * per + k];
+                if ((uint64_t)rank < (uint64_t)acc + h) { part[256 + w] = (uint32_t)(t * per + k); break; }
+                acc += h;
+            }
+        }
+    }
+    __syncthreads();
+    const int b1 = (int)part[256], b2 = (int)part[257];
+    __syncthreads();
+    r1 = lo + b1;
+    r2 = lo + b2;
+    return b1 > 0 && b1 < nb - 1 && b2 > 0 && b2 < nb - 1;
+}
+
+template <int MODE, bool PA = false>
 __global__ __launch_bounds__(256) void k_median(StatArgs a) {
-    __shared__ uint32_t hist[4096];
-    __shared__ uint32_t part[258];
+    __shared__ uint32_t hist[MODE == REG_WHOLE ? RANGE_BINS : 4096];
+    __shared__ uint32_t part[260];
     const uint32_t r = blockIdx.x;
     const Region g = get_region(MODE, a.b, a.prefix, r);
     if (g.len <= 0) {
-        if (threadIdx.x == 0 && MODE == REG_WHOLE) { a.stat[r].raw_median = 0; a.stat[r].pa_median = 0.0f; }
+        if (threadIdx.x == 0 && MODE == REG_WHOLE) { a.stat[r].raw_median = 0; a.stat[r].pa_median = 0.0f; a.stat[r].reserved = 0; }
         return;
     }
     const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
     const int16_t *x = a.b.samples + g.start;
+    float *pa = PA ? a.pa_out + g.start : nullptr;
     const int64_t k = g.len / 2;
-    const int med = block_select(x, g.len, k, hist, part);
-    int med_for_pa = med;
-    if (sc.unit < 0.0f && g.len - 1 - k != k) med_for_pa = block_select(x, g.len, g.len - 1 - k, hist, part);
+    const bool mirrored = sc.unit < 0.0f && g.len - 1 - k != k;  // pA order is the reverse of the raw order
+    int med, med_for_pa;
+    bool done = false;
+    if (MODE == REG_WHOLE) {
+        // window centred on the read's raw mean (written by k_moments, which runs before this kernel)
+        const float m = a.stat[r].raw_mean;
+        int c = (m == m) ? (int)fminf(fmaxf(m, -32768.0f), 32767.0f) : 0;
+        int lo = c - RANGE_BINS / 2;
+        lo = lo < -32768 ? -32768 : (lo > 32768 - RANGE_BINS ? 32768 - RANGE_BINS : lo);
+        done = block_select_range<PA>(x, g.len, k, mirrored ? g.len - 1 - k : k, lo, hist, part, med, med_for_pa, pa, sc);
+        pa = nullptr;  // already written
+    }
+    if (!done) {
+        if (PA && pa) med = block_select<true>(x, g.len, k, hist, part, pa, sc);
+        else med = block_select<false>(x, g.len, k, hist, part);
+        med_for_pa = mirrored ? block_select<false>(x, g.len, g.len - 1 - k, hist, part) : med;
+    }
     if (threadIdx.x == 0) {
         const float pm = to_pa((int16_t)med_for_pa, sc);
-        if (MODE == REG_WHOLE) { a.stat[r].raw_median = med; a.stat[r].pa_median = pm; }
+        if (MODE == REG_WHOLE) { a.stat[r].raw_median = med; a.stat[r].pa_median = pm; a.stat[r].reserved = 0; }
         else if (MODE == REG_ADAPT) a.prefix[r].adapt_median = pm;
         else a.prefix[r].polya_median = pm;
     }
@@ -430,18 +516,19 @@ __device__ __forceinline__ float roll_mean(int tot) { return sgk_div_f32<ADW>((f
 // One rolling-window sweep: calls f(i, tot_i) for i = 0..m-1 (m = n - ADW) in order, tot_i = sum of the clamped
 // samples x[i .. i+ADW).  The trailing edge is a second row stream whose base is shifted by 16 samples, so that
 // its tiles line up with the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
+constexpr int HALF = TILE / 2;
 template <int K, typename F>
-__device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int64_t il0,
+__device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[16], const uint32_t (&wt)[16], int64_t il0,
                                               int64_t n, int &tot, F &f) {
-    if constexpr (K < TILE) {
+    if constexpr (K < HALF) {
         const int64_t il = il0 + K;  // lead index
         if (il >= 0 && il < n) {
-            const int cl = clampi_raw(RowPrefetch::sample<K>(wl));
+            const int cl = clampi_raw(RowPrefetch::sample_half<K>(wl));
             if (il < ADW) {
                 tot = tot + cl;
                 if (il == ADW - 1) f((int64_t)0, tot);
             } else {
-                const int ct = clampi_raw(RowPrefetch::sample<K>(wt));
+                const int ct = clampi_raw(RowPrefetch::sample_half<K>(wt));
                 tot = tot - ct;
                 tot = tot + cl;
                 f(il - ADW + 1, tot);
@@ -451,11 +538,13 @@ __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[32], const ui
     }
 }
 template <int K, typename F>
-__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[32], const uint32_t (&wt)[32], int il0, int &tot,
+__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[16], const uint32_t (&wt)[16], int il0, int &tot,
                                              F &f) {
-    if constexpr (K < TILE) {
-        tot += clampi_raw(RowPrefetch::sample<K>(wl)) - clampi_raw(RowPrefetch::sample<K>(wt));
+    if constexpr (K < HALF) {
+        tot += clampi_raw(RowPrefetch::sample_half<K>(wl)) - clampi_raw(RowPrefetch::sample_half<K>(wt));
         f((int64_t)(il0 + K - ADW + 1), tot);
+        // keep the scheduler from hoisting every extraction of the half tile (register pressure)
+        if constexpr ((K & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         rolling_full<K + 1>(wl, wt, il0, tot, f);
     }
 }
@@ -471,16 +560,20 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) lead.issue(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.issue(t + 1 - LAG);
-        uint32_t wl[32], wt[32];
-        lead.row(t, wl);
-        if (t >= LAG) trail.row(t - LAG, wt);
-        else {
+        // half a tile at a time: two streams of 32 registers each would not leave room for a second wave
 #pragma unroll
-            for (int k = 0; k < 32; ++k) wt[k] = 0u;
+        for (int h = 0; h < 2; ++h) {
+            uint32_t wl[16], wt[16];
+            lead.row_half(h, wl);
+            if (t >= LAG) trail.row_half(h, wt);
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wt[k] = 0u;
+            }
+            const int64_t il0 = (int64_t)t * TILE + h * HALF - skip;
+            if (__all(il0 >= ADW && il0 + HALF <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
+            else if (n > ADW) rolling_elems<0>(wl, wt, il0, n, tot, f);
         }
-        const int64_t il0 = (int64_t)t * TILE - skip;
-        if (__all(il0 >= ADW && il0 + TILE <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
-        else if (n > ADW) rolling_elems<0>(wl, wt, il0, n, tot, f);
         if (t + 1 < ntiles) lead.commit(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.commit(t + 1 - LAG);
     }
@@ -501,7 +594,10 @@ __device__ inline int roll_threshold(float x, bool strict) {
     return lo;
 }
 
-__global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
+// OCC = waves per SIMD the register allocation is held to.  The kernel wants ~300 registers: with up to one wave
+// per SIMD in the launch (<= 65536 reads) it may have them; beyond that two resident waves with some spills win.
+template <int OCC>
+__global__ __launch_bounds__(64, OCC) void k_adaptor(StatArgs a, int pore) {
     __shared__ __attribute__((aligned(16))) char lds[2 * Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
     const bool valid = r < a.b.n_reads;
@@ -512,8 +608,10 @@ __global__ __launch_bounds__(64) void k_adaptor(StatArgs a, int pore) {
     int skip;
     Stream1 lead = make_stream(lds, a.b, g.start, run, skip);
     Stream1 trail;
-    // trail position = lead position - 2000 = (row base - 16) + (q - 31*64)
-    trail.init(lds + Stream1::LDS_BYTES, a.b.samples, (int64_t)a.b.n_samples, lead.rb - 16, lead.rowmask);
+    // trail position = lead position - 2000 = (row base - 16) + (q - 31*64): the same rows, shifted
+    trail = lead;
+    trail.lds = lds + Stream1::LDS_BYTES;
+    trail.shift8 = -2;
     const int64_t m = n - ADW;
     const float mf = (float)(int)m;
     float s = 0.0f;
@@ -554,7 +652,8 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
     SGK_HIP_TRY(hipGetLastError());
-    SGK_LAUNCH("k_median", (k_median<REG_WHOLE>), nr, 256, a);
+    if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
+    else SGK_LAUNCH("k_median", (k_median<REG_WHOLE, false>), nr, 256, a);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -572,7 +671,8 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, pore);
+    if (nr > 65536u) SGK_LAUNCH("k_adaptor", k_adaptor<2>, (nr + 63) / 64, 64, a, pore);
+    else SGK_LAUNCH("k_adaptor", k_adaptor<1>, gw, 64, a, pore);
     SGK_HIP_TRY(hipGetLastError());
     SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
     SGK_HIP_TRY(hipGetLastError());

@@ -55,7 +55,7 @@ def alloc_reads(lengths: np.ndarray, device: torch.device, align: int = 64) -> D
     offsets = np.full(n, 256, dtype=np.int64)
     if n > 1:
         offsets[1:] += np.cumsum(padded[:-1])
-    n_samples = (int(padded.sum()) if n else 0) + 320
+    n_samples = ((int(padded.sum()) if n else 0) + 320 + 7) // 8 * 8   # the ABI wants a multiple of 8
     return DeviceReads(
         samples=torch.zeros(n_samples, dtype=torch.int16, device=device),
         offsets=torch.from_numpy(offsets).to(device),
@@ -146,6 +146,18 @@ def stat(b: DeviceReads) -> torch.Tensor:
     view = b.view()
     api.check(L.sgk_stat(C.byref(view), _ptr(out), None, 0, _stream_ptr()), "sgk_stat")
     return out
+
+
+def stat_pa(b: DeviceReads, pa_out: Optional[torch.Tensor] = None):
+    """sgk_stat_pa (BASELINE config 4): stat records + pA of every sample in one launch sequence; the pA values
+    are written by the median pass.  -> (stat record bytes, pa tensor laid out like b.samples)"""
+    L = api.load_library()
+    out = torch.zeros(max(b.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
+    if pa_out is None:
+        pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=b.samples.device)
+    view = b.view()
+    api.check(L.sgk_stat_pa(C.byref(view), _ptr(out), _ptr(pa_out), None, 0, _stream_ptr()), "sgk_stat_pa")
+    return out, pa_out
 
 
 def prefix(b: DeviceReads, rna: int, pore: int) -> torch.Tensor:

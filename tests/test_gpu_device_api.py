@@ -14,13 +14,21 @@ def _torch():
     return torch
 
 
-def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n: n // 3 + 2):
+# what recycled device memory looked like in the gaps of a job's sample arena when this was found: pointer-like
+# words, i.e. a few huge values between runs of zeros
+STALE = np.array([4096, 961, 31966, 0, -8192, -12610, 31957, 0, 16, 0, 0, 0, 0, 0, 16, 0, -8176, -12610, 31957, 0, 512,
+                  0, 512, 0, 9, 0, 13, 0, 0, -26880, 31957, 0] + [0] * 32, dtype=np.int16)
+
+
+def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n: n // 3 + 2, gap_fill=None):
     """Place reads at the given sample offsets of one buffer and run sgk_event through the device API."""
     torch = _torch()
     from sigtk_amd import device
     dev = torch.device("cuda", 0)
     host = np.zeros(n_samples, dtype=np.int16)
     host[:] = 777  # gap samples are arbitrary data, not zeros
+    if gap_fill is not None:
+        host[:] = np.resize(gap_fill, n_samples)
     lens = np.array([len(r) for r in reads], dtype=np.int64)
     for r, o in zip(reads, offsets):
         host[o:o + len(r)] = r
@@ -146,3 +154,33 @@ def test_getevents_shim_matches_reference_signature(gpu, oracle, sp1):
         assert np.array_equal(got[:, 1].astype(np.float32), exp.length)
         assert np.array_equal(got[:, 2].astype(np.float32).view(np.uint32), exp.mean.view(np.uint32))
         libc.free(t.event)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("fill", ["stale", "random", "extremes"])
+def test_gap_content_never_matters(gpu, oracle, kind, fill):
+    """The fast path reads up to 64 (DNA) / 256 (RNA) samples before a read and 16 after it without bounds
+    checks; whatever sits there must not change a single event.  Regression: with EXACTLY 256 samples of head
+    room the RNA pass had to redirect its first history groups, and initial window sums taken from memory
+    disagreed with the redirected copies that later left the windows (only visible with non-constant gaps)."""
+    lens = [100000, 5000, 70001, 300]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=21, kind=kind)
+    rs = np.random.RandomState(4)
+    gap = {"stale": STALE, "random": rs.randint(-32768, 32767, size=4099).astype(np.int16),
+           "extremes": np.where(rs.rand(997) < 0.5, -32768, 32767).astype(np.int16)}[fill]
+    for head in (256, 64 if kind == 0 else 256, 320):
+        offsets, o = [], head
+        for n in lens:
+            offsets.append(o)
+            o += (n + 63) // 64 * 64
+        n_samples = o + 64
+        b, arena = _run_layout(gpu, oracle, reads, offsets, n_samples, kind, gap_fill=gap)
+        st = arena.status()
+        assert st.n_fallback_reads == 0          # all of them took the fast path
+        for r, raw in enumerate(reads):
+            exp = oracle.event_raw(raw, 8192.0, 7.0, 1402.882324, kind)
+            got = arena.read_events(r)
+            assert got.start.size == exp.start.size, "head %d read %d: %d events, oracle %d" % (head, r, got.start.size, exp.start.size)
+            assert np.array_equal(got.start.astype(np.uint64), exp.start)
+            assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+            assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))

@@ -109,3 +109,37 @@ def test_prefix_synthetic_rna(gpu, oracle, pore):
     _check_prefix(oracle, reads, dig, off, rng, 1, pore, got)
     assert (int(got[0]["adapt_x"]), int(got[0]["adapt_y"])) == (-1, -1)   # too short (jnn.c:173-177)
     assert any(int(g["adapt_y"]) > 0 and int(g["polya_y"]) > 0 for g in got)  # the structure is found
+
+
+def test_fused_stat_pa_matches_stat_and_pa(gpu, oracle):
+    """sgk_stat_pa (BASELINE config 4): same records as sgk_stat, pA bit-identical to sgk_pa / the oracle;
+    ragged lengths exercise the unaligned head/tail of the vectorised median pass; one read spans more than
+    8192 distinct raw values (two-level select path), one has a negative range (mirrored pA median)."""
+    import torch
+    from sigtk_amd import device
+    lens = [1, 7, 8, 9, 63, 64, 65, 1000, 4097, 30000, 70001]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=11, kind=0)
+    rs = np.random.RandomState(3)
+    reads[8] = rs.randint(-32768, 32767, size=4097).astype(np.int16)
+    rng = rng.copy(); rng[9] = -rng[9]
+    dev = torch.device("cuda", 0)
+    b = device.alloc_reads(np.asarray(lens, dtype=np.int64), dev, align=1)   # reads start at odd offsets too
+    host = np.zeros(b.n_samples, dtype=np.int16)
+    for r, raw in enumerate(reads):
+        o = int(b.offsets_host[r]); host[o:o + raw.size] = raw
+    b.samples.copy_(torch.from_numpy(host).to(dev))
+    b.dig.copy_(torch.from_numpy(np.asarray(dig, dtype=np.float64)).to(dev))
+    b.off.copy_(torch.from_numpy(np.asarray(off, dtype=np.float64)).to(dev))
+    b.rng.copy_(torch.from_numpy(np.asarray(rng, dtype=np.float64)).to(dev))
+    rec, pa = device.stat_pa(b)
+    rec2 = device.stat(b)
+    torch.cuda.synchronize()
+    got = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
+    got2 = np.frombuffer(rec2.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
+    assert got.tobytes() == got2.tobytes()
+    _check_stat(oracle, reads, dig, off, rng, got)
+    pa_h = pa.cpu().numpy()
+    for r, raw in enumerate(reads):
+        o = int(b.offsets_host[r])
+        exp = oracle.pa(raw, dig[r], off[r], rng[r])
+        assert np.array_equal(pa_h[o:o + raw.size].view(np.uint32), exp.view(np.uint32)), "read %d pA" % r

@@ -47,6 +47,7 @@ def main():
 
     run("pa", lambda: device.pa(b, pa_out), 6 * S)
     run("stat", lambda: device.stat(b), 2 * S + 32 * R)
+    run("stat+pa", lambda: device.stat_pa(b, pa_out), 6 * S + 32 * R)   # BASELINE config 4 (fused)
     run("jnn", lambda: device.jnn(b, segs, args.rna), 2 * S)
     run("prefix", lambda: device.prefix(b, args.rna, 0), 2 * S + 48 * R)
 
