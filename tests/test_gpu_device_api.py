@@ -46,6 +46,9 @@ def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n:
         np.cumsum([slots_for(int(n)) for n in lens], out=slots[1:])
         arena.slots_host = slots
         arena.slots = torch.from_numpy(slots).to(dev)
+    if gap_fill is not None:  # nothing may depend on what the workspace or the output arena held before
+        arena.ws.fill_(0xA5)
+        arena.start.fill_(-1); arena.length.fill_(-1); arena.n_events.fill_(-1)
     device.event(b, arena, rna)
     torch.cuda.synchronize()
     return b, arena
