@@ -177,6 +177,13 @@ class Oracle:
                                 C.c_int(pore), _p(xy, C.c_int64))
         return int(xy[0]), int(xy[1])
 
+    def ent(self, raw):
+        """-> (raw_ent, delta_ent, byte_ent) as float64, src/ent.c"""
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        out = np.zeros(3, dtype=np.float64)
+        self.lib.orc_ent(_p(raw, C.c_int16), C.c_int64(raw.size), _p(out, C.c_double))
+        return out
+
     def prefix(self, raw, dig, off, rng, rna, pore):
         raw = np.ascontiguousarray(raw, dtype=np.int16)
         out = _PrefixT()

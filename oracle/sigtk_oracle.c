@@ -541,3 +541,49 @@ void orc_prefix(const int16_t *raw, int64_t n, double digitisation, double offse
     }
     free(pa);
 }
+
+/* ---- ent: the three entropies of `sigtk ent` (src/ent.c:25-50 entropy(), :107-164 entmain loop) ----
+ * entropy(x, len): 65536-bin histogram of the samples reinterpreted as uint16 (:32-35); for every non-empty bin
+ * in increasing bin order p = count/len (doubles), ent -= p*log2(p) (:41-46).
+ *   out[0] raw:   entropy(raw, n)                                                    (:111)
+ *   out[1] delta: zigzag(raw[i] - raw[i-1]) with prev = 0 for i = 0 (:52-61, :120-126), truncated to int16
+ *                 (:130-132); entropy over the FIRST n-1 of them (:134 -- the last delta is dropped)
+ *   out[2] bytes: high bytes a/256 and low bytes a%256 of those n-1 values as two int16 arrays; the sum of their
+ *                 entropies (:143-152)
+ * n == 0 makes the reference index with len-1 = 2^64-1 (undefined); here it yields three zeros. */
+static double orc_entropy_u16(const uint16_t *x, uint64_t len, int64_t *counts) {
+    memset(counts, 0, 65536 * sizeof(int64_t));
+    for (uint64_t i = 0; i < len; i++) counts[x[i]]++;
+    double ent = 0;
+    for (uint64_t i = 0; i < 65536; i++) {
+        if (counts[i] > 0) {
+            double p = (double)counts[i] / (double)len;
+            ent -= p * log2(p);
+        }
+    }
+    return ent;
+}
+
+void orc_ent(const int16_t *raw, int64_t n, double *out) {
+    out[0] = out[1] = out[2] = 0.0;
+    if (n <= 0) return;
+    int64_t *counts = (int64_t *)malloc(65536 * sizeof(int64_t));
+    uint16_t *a = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n);
+    uint16_t *b = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n);
+    out[0] = orc_entropy_u16((const uint16_t *)raw, (uint64_t)n, counts);
+    int32_t prev = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t val = (int32_t)raw[i] - prev;
+        const uint32_t zz = (uint32_t)((val + val) ^ (val >> 31));
+        a[i] = (uint16_t)(int16_t)zz;
+        prev = raw[i];
+    }
+    const uint64_t m = (uint64_t)n - 1;
+    out[1] = orc_entropy_u16(a, m, counts);
+    for (uint64_t i = 0; i < m; i++) b[i] = (uint16_t)(a[i] / 256);
+    double e = orc_entropy_u16(b, m, counts);
+    for (uint64_t i = 0; i < m; i++) b[i] = (uint16_t)(a[i] % 256);
+    e = e + orc_entropy_u16(b, m, counts);
+    out[2] = e;
+    free(counts); free(a); free(b);
+}

@@ -125,3 +125,11 @@ def prefix_row(read_id: str, n: int, adapt, polya, p_stat: bool, adapt_stats=Non
         out.append(".\t.\t.\t.")
     out.append("\n")
     return "".join(out)
+
+
+# ---- ent (src/ent.c:105, :108-163): id, then "%f" of the three entropies (doubles)
+HDR_ENT = "read_id\traw_ent\tdelta_ent\tbyte_ent\n"
+
+
+def ent_row(read_id: str, raw_ent: float, delta_ent: float, byte_ent: float) -> str:
+    return "%s\t%f\t%f\t%f\n" % (read_id, raw_ent, delta_ent, byte_ent)

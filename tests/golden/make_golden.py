@@ -70,6 +70,7 @@ def main():
         save("sp1_dna.prefix.tsv", ref(tmp, "prefix", sp1))
         save("sp1_dna.prefix_stat.tsv", ref(tmp, "prefix", "--print-stat", sp1))
         save("sp1_dna.pa3.tsv", ref(tmp, "pa", sp1, *PA_READS))
+        save("sp1_dna.ent.tsv", ref(tmp, "ent", sp1))
         # long-form event output of the whole file is ~6.5 MB: keep its hash only
         manifest["sp1_dna.event.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", sp1)).hexdigest()
         for name, spec in SYNTH.items():
@@ -79,6 +80,7 @@ def main():
             save(name + ".stat.tsv", ref(tmp, "stat", f))
             save(name + ".jnn.tsv", ref(tmp, "jnn", f))
             save(name + ".prefix_stat.tsv", ref(tmp, "prefix", "--print-stat", f))
+            save(name + ".ent.tsv", ref(tmp, "ent", f))
             manifest[name + ".event.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", f)).hexdigest()
     manifest["_synth_specs"] = {k: list(v) for k, v in SYNTH.items()}
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as fh:
