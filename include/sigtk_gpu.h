@@ -174,6 +174,28 @@ size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t
 int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
                size_t workspace_bytes, void *stream);
 
+/* ---- ent: the histograms behind `sigtk ent` (src/ent.c) ----------------- */
+/* The counting runs on the GPU, the sum of -p*log2(p) over the (few thousand) non-empty bins on the host
+ * with the reference's own operations and order (sgk_ent_finish), so the printed entropies are identical.
+ * Values below the windows are counted in the record; the rare others (raw < 0 or >= 8192, zigzag delta
+ * >= 4096) are listed, unordered, in over_raw / over_delta at [offsets[r], offsets[r] + n_over_*). */
+#define SGK_ENT_RAW_WINDOW 8192
+#define SGK_ENT_DELTA_WINDOW 4096
+typedef struct sgk_ent_hist {
+    uint32_t n;            /* samples of the read */
+    uint32_t n_over_raw;   /* entries of this read in over_raw */
+    uint32_t n_over_delta; /* entries of this read in over_delta */
+    uint32_t reserved;
+    uint32_t raw[SGK_ENT_RAW_WINDOW];     /* count of samples with (uint16)raw == v, all n samples */
+    uint32_t delta[SGK_ENT_DELTA_WINDOW]; /* count of (uint16)zigzag(raw[i]-raw[i-1]) == v, i = 0..n-2, raw[-1] = 0 */
+    uint32_t hi[256], lo[256];            /* byte planes of those n-1 values */
+} sgk_ent_hist_t;
+/* over_raw / over_delta: device arrays of batch->n_samples uint16 each (same layout as the samples) */
+int sgk_ent(const sgk_batch_t *batch, sgk_ent_hist_t *out, uint16_t *over_raw, uint16_t *over_delta, void *stream);
+/* HOST function: out[0..2] = raw, delta, byte entropy of one read from host copies of its record and of its
+ * two overflow lists (which it sorts in place; may be NULL when the counts are 0) */
+void sgk_ent_finish(const sgk_ent_hist_t *hist, uint16_t *over_raw, uint16_t *over_delta, double *out);
+
 /* ---- svb-zd signal decode on the device ------------------------------- */
 /* Expands BLOW5 svb-zd signal blobs (slow5lib/src/slow5_press.c:1116-1146: u32 count, streamvbyte
  * keys + data of the zigzag deltas) into int16 samples, one wavefront per read.  The record layer
@@ -256,6 +278,7 @@ typedef struct sgk_job sgk_job_t;
 #define SGK_TOOL_STAT 2
 #define SGK_TOOL_JNN 3
 #define SGK_TOOL_PREFIX 4
+#define SGK_TOOL_ENT 5
 
 #define SGK_SIGNAL_INT16 0 /* caller stages decoded int16 samples                        */
 #define SGK_SIGNAL_SVBZD 1 /* caller stages svb-zd blobs; decoded on the GPU (8f-1)      */
@@ -285,6 +308,8 @@ typedef struct sgk_job_output {
     const sgk_stat_rec_t *stat;
     const sgk_prefix_rec_t *prefix;
     sgk_event_status_t event_status;
+    const sgk_ent_hist_t *ent;            /* ent: one record per read */
+    uint16_t *ent_over_raw, *ent_over_delta; /* ent: host copies of the overflow lists (NULL if all empty) */
 } sgk_job_output_t;
 
 int sgk_job_create(int device, sgk_job_t **out);

@@ -69,10 +69,12 @@ class JobOutput(C.Structure):
                 ("ev_start", C.POINTER(C.c_uint32)), ("ev_length", C.POINTER(C.c_uint32)),
                 ("ev_mean", C.POINTER(C.c_float)), ("ev_stdv", C.POINTER(C.c_float)),
                 ("seg_x", C.POINTER(C.c_int32)), ("seg_y", C.POINTER(C.c_int32)),
-                ("stat", C.c_void_p), ("prefix", C.c_void_p), ("event_status", EventStatus)]
+                ("stat", C.c_void_p), ("prefix", C.c_void_p), ("event_status", EventStatus),
+                ("ent", C.c_void_p), ("ent_over_raw", C.c_void_p), ("ent_over_delta", C.c_void_p)]
 
 
-TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX = range(5)
+TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX, TOOL_ENT = range(6)
+ENT_HIST_BYTES = 4 * (4 + 8192 + 4096 + 512)   # sizeof(sgk_ent_hist_t)
 SIGNAL_INT16, SIGNAL_SVBZD = 0, 1
 JOB_EVENTS_COMPACT = 1
 
@@ -88,7 +90,7 @@ ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
     "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
-    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_svbzd_decode", "sgk_synth_reads", "sgk_synth_reads_host",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode", "sgk_synth_reads", "sgk_synth_reads_host",
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
     "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
     "sgk_segs_host_free", "sgk_prefix_host", "sgk_signal_in_picoamps", "sgk_getevents",
@@ -140,6 +142,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_synth_reads_host.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
     L.sgk_synth_reads_host.restype = None
     L.sgk_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]
+    L.sgk_ent.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sgk_ent_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    L.sgk_ent_finish.restype = None
     L.sgk_job_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.sgk_job_destroy.argtypes = [C.c_void_p]
     L.sgk_job_destroy.restype = None
@@ -363,4 +368,13 @@ class Job:
             res["stat"] = np.frombuffer(C.string_at(o.stat, n * STAT_DTYPE.itemsize), dtype=STAT_DTYPE).copy()
         elif self._tool == TOOL_PREFIX:
             res["prefix"] = np.frombuffer(C.string_at(o.prefix, n * PREFIX_DTYPE.itemsize), dtype=PREFIX_DTYPE).copy()
+        elif self._tool == TOOL_ENT:
+            ent = np.zeros((n, 3), dtype=np.float64)
+            for r in range(n):
+                off = int(o.offsets[r]) * 2
+                self.L.sgk_ent_finish(o.ent + r * ENT_HIST_BYTES,
+                                      (o.ent_over_raw + off) if o.ent_over_raw else None,
+                                      (o.ent_over_delta + off) if o.ent_over_delta else None,
+                                      ent[r].ctypes.data_as(C.POINTER(C.c_double)))
+            res["ent"] = ent
         return res

@@ -87,7 +87,7 @@ struct sgk_job {
     GrowPin h_out[4], h_cnt, h_dstat;
     size_t ws_bytes = 0;
     int tool = -1, flags = 0;
-    bool begun = false, submitted = false;
+    bool begun = false, submitted = false, ent_over = false;
     sgk_event_status_t ev_status;
 };
 
@@ -202,7 +202,7 @@ static int d2h(GrowPin &h, const GrowDev &d, size_t bytes, hipStream_t st) {
 
 int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
     if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
-    if (tool < SGK_TOOL_PA || tool > SGK_TOOL_PREFIX) return SGK_ERR_ARG;
+    if (tool < SGK_TOOL_PA || tool > SGK_TOOL_ENT) return SGK_ERR_ARG;
     SGK_HIP_TRY(hipSetDevice(j->device));
     j->tool = tool;
     j->flags = flags;
@@ -295,6 +295,16 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_stat_rec_t), st)) != SGK_OK) return rc;
             break;
         }
+        case SGK_TOOL_ENT: {
+            const size_t ob = j->n_samples * sizeof(uint16_t);
+            if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_ent_hist_t))) != SGK_OK) return rc;
+            if ((rc = j->d_out[1].ensure(ob)) != SGK_OK) return rc;
+            if ((rc = j->d_out[2].ensure(ob)) != SGK_OK) return rc;
+            rc = sgk_ent(&view, j->d_out[0].as<sgk_ent_hist_t>(), j->d_out[1].as<uint16_t>(), j->d_out[2].as<uint16_t>(), st);
+            if (rc != SGK_OK) return rc;
+            if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_ent_hist_t), st)) != SGK_OK) return rc;
+            break;  // the overflow lists are fetched by sgk_job_wait only when some read has entries
+        }
         case SGK_TOOL_PREFIX: {
             if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
             j->ws_bytes = sgk_prefix_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
@@ -323,6 +333,18 @@ int sgk_job_wait(sgk_job_t *j) {
             if (ds[r] != 0) return SGK_ERR_FORMAT;
     }
     if (j->tool == SGK_TOOL_EVENT) return sgk_event_status(j->d_ws.p, &j->ev_status, j->st);
+    if (j->tool == SGK_TOOL_ENT) {
+        const sgk_ent_hist_t *rec = j->h_out[0].as<sgk_ent_hist_t>();
+        j->ent_over = false;
+        for (uint32_t r = 0; r < j->n_reads && !j->ent_over; ++r) j->ent_over = rec[r].n_over_raw || rec[r].n_over_delta;
+        if (j->ent_over) {
+            const size_t ob = j->n_samples * sizeof(uint16_t);
+            int rc;
+            if ((rc = d2h(j->h_out[1], j->d_out[1], ob, j->st)) != SGK_OK) return rc;
+            if ((rc = d2h(j->h_out[2], j->d_out[2], ob, j->st)) != SGK_OK) return rc;
+            SGK_HIP_TRY(hipStreamSynchronize(j->st));
+        }
+    }
     return SGK_OK;
 }
 
@@ -359,6 +381,11 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
             break;
         case SGK_TOOL_PREFIX:
             out->prefix = j->h_out[0].as<sgk_prefix_rec_t>();
+            break;
+        case SGK_TOOL_ENT:
+            out->ent = j->h_out[0].as<sgk_ent_hist_t>();
+            out->ent_over_raw = j->ent_over ? j->h_out[1].as<uint16_t>() : nullptr;
+            out->ent_over_delta = j->ent_over ? j->h_out[2].as<uint16_t>() : nullptr;
             break;
         default:
             return SGK_ERR_ARG;

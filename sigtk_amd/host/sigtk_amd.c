@@ -49,7 +49,7 @@ typedef struct {
     int8_t rna, compact, p_stat, pore; /* opt_t, src/sigtk.h:115-120 */
 } opt_t;
 
-enum { MODE_EVENT, MODE_STAT, MODE_PREFIX, MODE_JNN, MODE_PA };
+enum { MODE_EVENT, MODE_STAT, MODE_PREFIX, MODE_JNN, MODE_PA, MODE_ENT };
 
 static double realtime(void) {
     struct timeval tp;
@@ -348,6 +348,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
         case MODE_STAT: tool = SGK_TOOL_STAT; break;
         case MODE_PREFIX: tool = SGK_TOOL_PREFIX; break;
         case MODE_JNN: tool = SGK_TOOL_JNN; break;
+        case MODE_ENT: tool = SGK_TOOL_ENT; break;
         default: break;
     }
     rc = sgk_job_submit(b->job, tool, P->opt.rna, P->opt.pore, flags);
@@ -506,6 +507,20 @@ static void row_pa(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uin
     o->n = (size_t)(p - o->p);
 }
 
+/* entmain's row, ent.c:108-163: id, then "%f" of three doubles (the histograms come from the GPU, the sum over
+ * the non-empty bins is sgk_ent_finish: the reference's own arithmetic in the reference's order) */
+static void row_ent(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r) {
+    double e[3];
+    const uint64_t off = out->offsets[r];
+    sgk_ent_finish(&out->ent[r], out->ent_over_raw ? out->ent_over_raw + off : NULL,
+                   out->ent_over_delta ? out->ent_over_delta + off : NULL, e);
+    char *p = sbuf_room(o, (size_t)b->recs[r].v.id_len + 3 * 330 + 8);
+    memcpy(p, b->recs[r].v.read_id, b->recs[r].v.id_len);
+    p += b->recs[r].v.id_len;
+    p += sprintf(p, "\t%f\t%f\t%f\n", e[0], e[1], e[2]);
+    o->n = (size_t)(p - o->p);
+}
+
 /* ------------------------------------------------------------------ writer */
 
 typedef struct {
@@ -528,6 +543,7 @@ static void write_chunk(void *ctx_, uint32_t k, int tid) {
             case MODE_JNN: row_jnn(o, c->b, &c->out, r, opt); break;
             case MODE_STAT: row_stat(o, c->b, &c->out, r); break;
             case MODE_PREFIX: row_prefix(o, c->b, &c->out, r, opt); break;
+            case MODE_ENT: row_ent(o, c->b, &c->out, r); break;
             default: row_pa(o, c->b, &c->out, r); break;
         }
     }
@@ -601,7 +617,10 @@ static struct option long_options[] = {
     {"threads", required_argument, 0, 't'}, {"host-decode", no_argument, 0, 0},  {0, 0, 0, 0}};
 
 static int cmain(int argc, char *argv[], const char *mode_s) {
-    const char *optstring = "o:hVnct:";
+    /* `ent` has its own front end in the reference (src/ent.c:63-105): only -h/-V (and --no-header) are options,
+     * exactly one file argument, no DNA/RNA or pore detection */
+    const int is_ent = strcmp(mode_s, "ent") == 0;
+    const char *optstring = is_ent ? "hVt:" : "o:hVnct:";
     int longindex = 0, c;
     FILE *fp_help = stderr;
     int8_t hdr = 1;
@@ -631,6 +650,14 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
             host_decode = 1;
         }
     }
+    if (is_ent && (argc - optind != 1 || fp_help == stdout)) {
+        fprintf(fp_help, "Usage: sigtk ent a.blow5\n");
+        fprintf(fp_help, "\nbasic options:\n");
+        fprintf(fp_help, "   -h                         help\n");
+        fprintf(fp_help, "   -n                         suppress header\n");
+        fprintf(fp_help, "   --version                  print version\n");
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
     if (argc - optind < 1 || fp_help == stdout) {
         fprintf(fp_help, "Usage: sigtk %s reads.blow5 read_id1 read_id2 .. \n", mode_s);
         fprintf(fp_help, "       sigtk %s reads.blow5\n", mode_s);
@@ -648,11 +675,14 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
 
     b5_file_t *f = b5_open(argv[optind]);
     if (!f) {
-        ERROR("cmain", "cannot open %s. ", argv[optind]);
+        if (is_ent) fprintf(stderr, "Error in opening file\n"); /* ent.c:97-100 */
+        else ERROR("cmain", "cannot open %s. ", argv[optind]);
         exit(EXIT_FAILURE);
     }
-    opt.rna = drna_detect(f);
-    opt.pore = pore_detect(f);
+    if (!is_ent) {
+        opt.rna = drna_detect(f);
+        opt.pore = pore_detect(f);
+    }
 
     int mode;
     if (strcmp(mode_s, "event") == 0) {
@@ -674,6 +704,9 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     } else if (strcmp(mode_s, "jnn") == 0) {
         mode = MODE_JNN;
         if (hdr) printf("read_id\tlen_raw_signal\tnum_seg\tseg\n");
+    } else if (is_ent) {
+        mode = MODE_ENT;
+        if (hdr) printf("read_id\traw_ent\tdelta_ent\tbyte_ent\n");
     } else {
         mode = MODE_PA;
         if (hdr) printf("read_id\tlen_raw_signal\tpa\n");
@@ -889,7 +922,8 @@ static void print_usage(FILE *fp) {
     fprintf(fp, "         stat      print statistics of the raw signal\n");
     fprintf(fp, "         prefix    prefix segments such as adaptor and polyA\n");
     fprintf(fp, "         jnn       print segments found using JNN segmenter\n");
-    fprintf(fp, "\n(sigtk-amd: the per-read raw-signal subtools on MI355X; sref/ss/ent/qts are not part of it)\n");
+    fprintf(fp, "         ent       calculate entropies\n");
+    fprintf(fp, "\n(sigtk-amd: the per-read raw-signal subtools on MI355X; sref/ss/qts are not part of it)\n");
     exit(fp == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
 }
 
@@ -899,7 +933,7 @@ int main(int argc, char *argv[]) {
     if (argc < 2) {
         print_usage(stderr);
     } else if (strcmp(argv[1], "event") == 0 || strcmp(argv[1], "stat") == 0 || strcmp(argv[1], "prefix") == 0 ||
-               strcmp(argv[1], "pa") == 0 || strcmp(argv[1], "jnn") == 0) {
+               strcmp(argv[1], "pa") == 0 || strcmp(argv[1], "jnn") == 0 || strcmp(argv[1], "ent") == 0) {
         ret = cmain(argc - 1, argv + 1, argv[1]);
     } else if (strcmp(argv[1], "_dump") == 0) {
         return dumpmain(argc - 1, argv + 1);

@@ -55,6 +55,7 @@ def synth_files(tmp_path_factory):
     ("sp1_dna.jnn_c.tsv", ["jnn", SP1, "-c"]),          # options may follow positionals (GNU getopt)
     ("sp1_dna.prefix.tsv", ["prefix", SP1]),
     ("sp1_dna.prefix_stat.tsv", ["prefix", "--print-stat", SP1]),
+    ("sp1_dna.ent.tsv", ["ent", SP1]),
     ("sp1_dna.pa3.tsv", ["pa", SP1, "00011a60-dd92-4aad-be1d-59a33545ab1d",
                          "0448591b-036c-4cc7-a702-6c542ccc07de", "03880e3d-b79d-4bd8-aab4-15724f1331af"]),
 ])
@@ -132,4 +133,6 @@ def test_synthetic_outputs(cli, synth_files, name):
     assert out(cli, "stat", f) == gold(name + ".stat.tsv")
     assert out(cli, "jnn", f) == gold(name + ".jnn.tsv")
     assert out(cli, "prefix", "--print-stat", f) == gold(name + ".prefix_stat.tsv")
+    assert out(cli, "ent", f) == gold(name + ".ent.tsv")
+    assert out(cli, "ent", "--no-header", "--batch-samples", "50000", f) == gold(name + ".ent.tsv").split(b"\n", 1)[1]
     assert hashlib.sha256(out(cli, "event", f)).hexdigest() == MANIFEST[name + ".event.tsv.sha256"]

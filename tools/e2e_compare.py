@@ -32,7 +32,7 @@ def main():
         f = os.path.join(tmp, "e2e.blow5")
         blow5.write_blow5(f, recs, attrs)
         out = {"reads": a.reads, "samples": a.reads * a.read_len, "file_mb": round(os.path.getsize(f) / 1e6, 1)}
-        for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"]):
+        for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["ent"]):
             name = " ".join(tool)
             env = dict(os.environ, SGK_CLI_TIMING="1")
             t0 = time.perf_counter(); g = subprocess.run([build.CLI, *tool, *a.cli_args.split(), f], capture_output=True, env=env); tg = time.perf_counter() - t0
