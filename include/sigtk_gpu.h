@@ -318,6 +318,7 @@ int sgk_job_device(const sgk_job_t *job);
 /* lengths[r]: samples of read r; blob_bytes[r] (SGK_SIGNAL_SVBZD only): byte length of its blob */
 int sgk_job_begin(sgk_job_t *job, uint32_t n_reads, const uint32_t *lengths, int signal_format,
                   const uint32_t *blob_bytes, sgk_job_input_t *in);
+/* may be called again after sgk_job_wait to run another tool over the same staged batch */
 int sgk_job_submit(sgk_job_t *job, int tool, int rna, int pore, int flags);
 /* SGK_ERR_FORMAT if a blob did not decode, SGK_ERR_CAPACITY on event-slot overflow */
 int sgk_job_wait(sgk_job_t *job);

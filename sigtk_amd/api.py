@@ -321,7 +321,8 @@ class Job:
     def __del__(self):
         self.close()
 
-    def submit(self, tool: int, signals, dig, off, rng, rna: int = 0, pore: int = 0, flags: int = 0, counts=None):
+    def stage(self, signals, dig, off, rng, counts=None):
+        """sgk_job_begin + fill the pinned staging (int16 arrays, or svb-zd blobs when `counts` is given)"""
         n = len(signals)
         svb = counts is not None
         lengths = np.asarray(counts if svb else [len(x) for x in signals], dtype=np.uint32)
@@ -336,8 +337,15 @@ class Job:
             elif lengths[r]:
                 x = np.ascontiguousarray(signals[r], dtype=np.int16)
                 C.memmove(jin.samples + 2 * jin.offsets[r], x.ctypes.data, x.nbytes)
+
+    def launch(self, tool: int, rna: int = 0, pore: int = 0, flags: int = 0):
+        """sgk_job_submit on the staged batch (asynchronous; may be repeated after wait())"""
         self._tool = tool
         check(self.L.sgk_job_submit(self.h, tool, rna, pore, flags), "sgk_job_submit")
+
+    def submit(self, tool: int, signals, dig, off, rng, rna: int = 0, pore: int = 0, flags: int = 0, counts=None):
+        self.stage(signals, dig, off, rng, counts)
+        self.launch(tool, rna, pore, flags)
 
     def wait(self):
         """-> dict of numpy results (per read lists for the variable-length outputs)"""

@@ -322,8 +322,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
 int sgk_job_wait(sgk_job_t *j) {
     if (!j || !j->submitted) return SGK_ERR_ARG;
     SGK_HIP_TRY(hipSetDevice(j->device));
-    j->submitted = false;
-    j->begun = false;
+    j->submitted = false;  // the staged batch stays valid: it may be submitted again (e.g. with another tool)
     memset(&j->ev_status, 0, sizeof j->ev_status);
     SGK_HIP_TRY(hipStreamSynchronize(j->st));
     if (j->n_reads == 0) return SGK_OK;
