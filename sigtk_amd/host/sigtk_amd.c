@@ -712,7 +712,9 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         if (hdr) printf("read_id\tlen_raw_signal\tpa\n");
     }
 
+    const double t_init0 = realtime();
     const int ndev = sgk_device_count();
+    const double t_init = realtime() - t_init0;
     if (ndev <= 0) {
         ERROR("cmain", "%s", "no usable GPU: sigtk-amd has no CPU compute path");
         exit(EXIT_FAILURE);
@@ -740,11 +742,13 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     const int nbatch = n_gpus + 2;
     batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
     if (!pool) die_mem();
+    const double t_jobs0 = realtime();
     for (int i = 0; i < nbatch; i++) {
         const int rc = sgk_job_create(i % n_gpus, &pool[i].job);
         if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
         q_push(&P.free_q, &pool[i]);
     }
+    const double t_jobs = realtime() - t_jobs0;
     pthread_t wth;
     if (pthread_create(&wth, NULL, writer_main, &P) != 0) {
         ERROR("cmain", "%s", "cannot create the writer thread");
@@ -800,9 +804,10 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     if (getenv("SGK_CLI_TIMING"))
         fprintf(stderr,
                 "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
-                "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s\n",
+                "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s | HIP init %.3f s, job create %.3f s\n",
                 (unsigned long)P.n_reads, (unsigned long)P.n_samples, nthreads, n_gpus, P.t_read, P.t_parse, P.t_stage,
-                P.t_wait, P.t_format, P.t_write);
+                P.t_wait, P.t_format, P.t_write, t_init, t_jobs);
+    const double t_end0 = realtime();
     for (int i = 0; i < nbatch; i++) {
         sgk_job_destroy(pool[i].job);
         for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
@@ -810,6 +815,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     }
     free(pool);
     b5_close(f);
+    if (getenv("SGK_CLI_TIMING")) fprintf(stderr, "[sigtk-amd] teardown %.3f s\n", realtime() - t_end0);
     return 0;
 }
 

@@ -116,3 +116,34 @@ def test_empty_batch_and_misuse(gpu):
     with pytest.raises(Exception):
         job.wait()                                             # nothing submitted
     job.close()
+
+
+def test_many_tiny_reads_and_one_huge_read(gpu, oracle):
+    """shape extremes through one job: 20 000 reads of 200..260 samples (slot arithmetic, per-read overheads) and a
+    single 3 000 000-sample read (chunk length, 32-bit positions)"""
+    rs = np.random.RandomState(12)
+    lens = rs.randint(200, 261, size=20000).tolist()
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=77, kind=0)
+    job = gpu.Job(0)
+    job.submit(gpu.TOOL_EVENT, reads, dig, off, rng)
+    ev = job.wait()["events"]
+    job.launch(gpu.TOOL_STAT)
+    st = job.wait()["stat"]
+    for r in list(range(0, 20000, 997)) + [19999]:
+        _same_events(ev[r], oracle.event_raw(reads[r], dig[r], off[r], rng[r], 0), "tiny read %d" % r)
+        e = oracle.stat(reads[r], dig[r], off[r], rng[r])
+        assert int(st[r]["raw_median"]) == e[4]
+        assert np.float32(st[r]["pa_std"]).view(np.uint32) == np.float32(e[3]).view(np.uint32)
+    big, dig, off, rng = gpu.synth_reads_host(1, [3000000], seed=78, kind=1)
+    for rna in (0, 1):
+        job.submit(gpu.TOOL_EVENT, big, dig, off, rng, rna=rna)
+        _same_events(job.wait()["events"][0], oracle.event_raw(big[0], dig[0], off[0], rng[0], rna), "huge read rna=%d" % rna)
+    job.launch(gpu.TOOL_JNN, rna=1)
+    x, y = job.wait()["segs"][0]
+    ex, ey = oracle.jnn_raw(big[0], 1)
+    assert np.array_equal(x.astype(np.int64), ex) and np.array_equal(y.astype(np.int64), ey)
+    job.launch(gpu.TOOL_PREFIX, rna=1, pore=0)
+    p = job.wait()["prefix"][0]
+    e = oracle.prefix(big[0], dig[0], off[0], rng[0], 1, 0)
+    assert (int(p["adapt_x"]), int(p["adapt_y"]), int(p["polya_x"]), int(p["polya_y"])) == (e.adapt_x, e.adapt_y, e.polya_x, e.polya_y)
+    job.close()
