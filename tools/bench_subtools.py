@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=100000)
     ap.add_argument("--rna", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--pipeline", type=int, default=0, help="1: also time the config-5 pa->event->stat pipeline")
     args = ap.parse_args()
     import torch
     from sigtk_amd import api, device
@@ -48,6 +49,17 @@ def main():
     run("pa", lambda: device.pa(b, pa_out), 6 * S)
     run("stat", lambda: device.stat(b), 2 * S + 32 * R)
     run("stat+pa", lambda: device.stat_pa(b, pa_out), 6 * S + 32 * R)   # BASELINE config 4 (fused)
+    if args.pipeline:
+        # BASELINE config 5: pa -> event -> stat over the same resident batch (pA is not materialised for the
+        # event / stat kernels: they scale on the fly; the fused stat+pa pass writes it once)
+        arena = device.EventArena(b)
+        device.event(b, arena, args.rna); torch.cuda.synchronize()
+        E = int(arena.status().n_events_total)
+
+        def pipe():
+            device.stat_pa(b, pa_out)
+            device.event(b, arena, args.rna)
+        run("pa->event->stat", pipe, 2 * S + 16 * E + 72 * R)
     run("jnn", lambda: device.jnn(b, segs, args.rna), 2 * S)
     run("prefix", lambda: device.prefix(b, args.rna, 0), 2 * S + 48 * R)
 
