@@ -143,14 +143,15 @@ struct RowPrefetch {
     static __device__ __forceinline__ int16_t sample(const uint32_t (&w)[32]) {
         return (K & 1) ? (int16_t)(w[K / 2] >> 16) : (int16_t)(w[K / 2] & 0xffffu);
     }
-    // half rows (32 samples, 16 registers) for kernels that hold two streams at once
-    __device__ __forceinline__ void row_half(int h, uint32_t (&w)[16]) const {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES) + h * 16;
+    // a part of the row (N samples, N/2 registers, part index h) for kernels that hold two streams at once
+    template <int N>
+    __device__ __forceinline__ void row_part(int h, uint32_t (&w)[N / 2]) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane_id() * ROW_BYTES) + h * (N / 2);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = src[k];
+        for (int k = 0; k < N / 2; ++k) w[k] = src[k];
     }
-    template <int K>
-    static __device__ __forceinline__ int16_t sample_half(const uint32_t (&w)[16]) {
+    template <int K, int NW>
+    static __device__ __forceinline__ int16_t sample_part(const uint32_t (&w)[NW]) {
         return (K & 1) ? (int16_t)(w[K / 2] >> 16) : (int16_t)(w[K / 2] & 0xffffu);
     }
 };

@@ -100,6 +100,45 @@ __device__ inline void sweep_rows(RowPrefetch &rs, int skip, int64_t len, F f) {
     }
 }
 
+// Same contract as sweep_rows, but the tile is consumed in rolled parts of P samples (P/2 registers, a P-step
+// unrolled body): for callbacks with a lot of code or state (the jnn automaton) this keeps the kernel small and
+// out of scratch.
+template <int K, int P, typename F>
+__device__ __forceinline__ void sweep_part_elems(const uint32_t (&w)[P / 2], int64_t j0, int64_t len, F &f) {
+    if constexpr (K < P) {
+        const int64_t j = j0 + K;
+        if (j >= 0 && j < len) f(j, RowPrefetch::sample_part<K>(w));
+        sweep_part_elems<K + 1, P>(w, j0, len, f);
+    }
+}
+template <int K, int P, typename F>
+__device__ __forceinline__ void sweep_part_full(const uint32_t (&w)[P / 2], int j0, F &f) {
+    if constexpr (K < P) {
+        f((int64_t)(j0 + K), RowPrefetch::sample_part<K>(w));
+        sweep_part_full<K + 1, P>(w, j0, f);
+    }
+}
+template <int P, typename F>
+__device__ inline void sweep_rows_parts(RowPrefetch &rs, int skip, int64_t len, F f) {
+    const int maxq = wave_max_i((int)(len > 0 ? skip + len : 0));
+    const int ntiles = (maxq + TILE - 1) / TILE;
+    if (ntiles == 0) return;
+    rs.issue(0);
+    rs.commit(0);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) rs.issue(t + 1);
+#pragma unroll 1
+        for (int h = 0; h < TILE / P; ++h) {
+            uint32_t w[P / 2];
+            rs.row_part<P>(h, w);
+            const int64_t j0 = (int64_t)t * TILE + h * P - skip;
+            if (__all(j0 >= 0 && j0 + P <= len)) sweep_part_full<0, P>(w, (int)j0, f);
+            else if (j0 + P > 0 && j0 < len) sweep_part_elems<0, P>(w, j0, len, f);
+        }
+        if (t + 1 < ntiles) rs.commit(t + 1);
+    }
+}
+
 __device__ inline RowPrefetch make_stream(char *lds, const sgk_batch_t &b, int64_t start, bool wanted, int &skip) {
     RowPrefetch rs;
     const int64_t rb = start & ~(int64_t)7;
@@ -429,7 +468,7 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
         if ((uint64_t)k < cap) { a.seg_x[slot0 + k] = x; a.seg_y[slot0 + k] = y; }
         else overflow = true;
     };
-    sweep_rows(rs, skip, g.len, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
+    sweep_rows_parts<16>(rs, skip, g.len, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
     A.finish(emit);
     if (valid) a.n_segs[r] = (uint32_t)A.nseg;
     if (overflow) atomicAdd(a.err_count, 1u);
@@ -459,7 +498,7 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
         if (k == 0) { px = x; py = y; }
     };
     // (a lane whose first segment is final could stop; the sweep is wave-cooperative, so it just idles)
-    sweep_rows(rs, skip, g.len, [&](int64_t j, int16_t v) {
+    sweep_rows_parts<16>(rs, skip, g.len, [&](int64_t j, int16_t v) {
         if (py < 0 || A.nseg < 2) A.step((int)j, clampf_pa(to_pa(v, sc)), emit);
     });
     if (A.nseg == 1 || (A.nseg >= 2 && py < 0)) A.finish(emit);
@@ -516,19 +555,20 @@ __device__ __forceinline__ float roll_mean(int tot) { return sgk_div_f32<ADW>((f
 // One rolling-window sweep: calls f(i, tot_i) for i = 0..m-1 (m = n - ADW) in order, tot_i = sum of the clamped
 // samples x[i .. i+ADW).  The trailing edge is a second row stream whose base is shifted by 16 samples, so that
 // its tiles line up with the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
-constexpr int HALF = TILE / 2;
+constexpr int PART = 16;  // samples handled per (rolled) inner iteration: keeps the unrolled bodies and the
+                          // register footprint small (two streams, three sweeps, each in a full and an edge form)
 template <int K, typename F>
-__device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[16], const uint32_t (&wt)[16], int64_t il0,
-                                              int64_t n, int &tot, F &f) {
-    if constexpr (K < HALF) {
+__device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2],
+                                              int64_t il0, int64_t n, int &tot, F &f) {
+    if constexpr (K < PART) {
         const int64_t il = il0 + K;  // lead index
         if (il >= 0 && il < n) {
-            const int cl = clampi_raw(RowPrefetch::sample_half<K>(wl));
+            const int cl = clampi_raw(RowPrefetch::sample_part<K>(wl));
             if (il < ADW) {
                 tot = tot + cl;
                 if (il == ADW - 1) f((int64_t)0, tot);
             } else {
-                const int ct = clampi_raw(RowPrefetch::sample_half<K>(wt));
+                const int ct = clampi_raw(RowPrefetch::sample_part<K>(wt));
                 tot = tot - ct;
                 tot = tot + cl;
                 f(il - ADW + 1, tot);
@@ -538,13 +578,11 @@ __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[16], const ui
     }
 }
 template <int K, typename F>
-__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[16], const uint32_t (&wt)[16], int il0, int &tot,
-                                             F &f) {
-    if constexpr (K < HALF) {
-        tot += clampi_raw(RowPrefetch::sample_half<K>(wl)) - clampi_raw(RowPrefetch::sample_half<K>(wt));
+__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2], int il0,
+                                             int &tot, F &f) {
+    if constexpr (K < PART) {
+        tot += clampi_raw(RowPrefetch::sample_part<K>(wl)) - clampi_raw(RowPrefetch::sample_part<K>(wt));
         f((int64_t)(il0 + K - ADW + 1), tot);
-        // keep the scheduler from hoisting every extraction of the half tile (register pressure)
-        if constexpr ((K & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         rolling_full<K + 1>(wl, wt, il0, tot, f);
     }
 }
@@ -560,18 +598,17 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) lead.issue(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.issue(t + 1 - LAG);
-        // half a tile at a time: two streams of 32 registers each would not leave room for a second wave
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t wl[16], wt[16];
-            lead.row_half(h, wl);
-            if (t >= LAG) trail.row_half(h, wt);
+#pragma unroll 1
+        for (int h = 0; h < TILE / PART; ++h) {
+            uint32_t wl[PART / 2], wt[PART / 2];
+            lead.row_part<PART>(h, wl);
+            if (t >= LAG) trail.row_part<PART>(h, wt);
             else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) wt[k] = 0u;
+                for (int k = 0; k < PART / 2; ++k) wt[k] = 0u;
             }
-            const int64_t il0 = (int64_t)t * TILE + h * HALF - skip;
-            if (__all(il0 >= ADW && il0 + HALF <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
+            const int64_t il0 = (int64_t)t * TILE + h * PART - skip;
+            if (__all(il0 >= ADW && il0 + PART <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
             else if (n > ADW) rolling_elems<0>(wl, wt, il0, n, tot, f);
         }
         if (t + 1 < ntiles) lead.commit(t + 1);
@@ -594,10 +631,7 @@ __device__ inline int roll_threshold(float x, bool strict) {
     return lo;
 }
 
-// OCC = waves per SIMD the register allocation is held to.  The kernel wants ~300 registers: with up to one wave
-// per SIMD in the launch (<= 65536 reads) it may have them; beyond that two resident waves with some spills win.
-template <int OCC>
-__global__ __launch_bounds__(64, OCC) void k_adaptor(StatArgs a, int pore) {
+__global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
     __shared__ __attribute__((aligned(16))) char lds[2 * Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
     const bool valid = r < a.b.n_reads;
@@ -671,8 +705,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    if (nr > 65536u) SGK_LAUNCH("k_adaptor", k_adaptor<2>, (nr + 63) / 64, 64, a, pore);
-    else SGK_LAUNCH("k_adaptor", k_adaptor<1>, gw, 64, a, pore);
+    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, pore);
     SGK_HIP_TRY(hipGetLastError());
     SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
     SGK_HIP_TRY(hipGetLastError());
