@@ -22,8 +22,14 @@ def main():
     ap.add_argument("--read-len", type=int, default=100000)
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--cli-args", default="", help="extra options for sigtk-amd, e.g. '--host-decode -t 8'")
+    ap.add_argument("--ragged", type=int, default=0, help="seed: random read lengths in [300, 2*read_len] instead of a fixed one")
     a = ap.parse_args()
-    reads, dig, off, rng = api.synth_reads_host(a.reads, a.read_len, 77, a.kind)
+    lens = a.read_len
+    if a.ragged:
+        import numpy as np
+        rs = np.random.RandomState(a.ragged)
+        lens = [int(x) for x in np.exp(rs.uniform(np.log(300), np.log(2 * a.read_len), size=a.reads))]
+    reads, dig, off, rng = api.synth_reads_host(a.reads, lens, 77, a.kind)
     recs = [blow5.Read("synth-%08d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
             for i in range(a.reads)]
     attrs = {"experiment_type": "rna" if a.kind else "genomic_dna",
@@ -31,7 +37,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         f = os.path.join(tmp, "e2e.blow5")
         blow5.write_blow5(f, recs, attrs)
-        out = {"reads": a.reads, "samples": a.reads * a.read_len, "file_mb": round(os.path.getsize(f) / 1e6, 1)}
+        out = {"reads": a.reads, "samples": int(sum(len(r) for r in reads)), "file_mb": round(os.path.getsize(f) / 1e6, 1)}
         for tool in (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["ent"]):
             name = " ".join(tool)
             env = dict(os.environ, SGK_CLI_TIMING="1")
