@@ -557,6 +557,8 @@ __device__ __forceinline__ float roll_mean(int tot) { return sgk_div_f32<ADW>((f
 // its tiles line up with the leading stream's: trail tile = lead tile - 31 (ADW = 2000 = 31*64 + 16).
 constexpr int PART = 16;  // samples handled per (rolled) inner iteration: keeps the unrolled bodies and the
                           // register footprint small (two streams, three sweeps, each in a full and an edge form)
+// f(i, tot_i) is called for the window indices i = 0..m-1 only (m = n - ADW, as rolling_window's output length,
+// src/jnn.c:20-56); indices are 32-bit (reads are < 2^31 samples, misc.c:20).
 template <int K, typename F>
 __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2],
                                               int64_t il0, int64_t n, int &tot, F &f) {
@@ -566,24 +568,25 @@ __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[PART / 2], co
             const int cl = clampi_raw(RowPrefetch::sample_part<K>(wl));
             if (il < ADW) {
                 tot = tot + cl;
-                if (il == ADW - 1) f((int64_t)0, tot);
+                if (il == ADW - 1) f(0, tot);
             } else {
                 const int ct = clampi_raw(RowPrefetch::sample_part<K>(wt));
                 tot = tot - ct;
                 tot = tot + cl;
-                f(il - ADW + 1, tot);
+                if (il < n - 1) f((int)(il - ADW + 1), tot);  // the total after the last sample has no window
             }
         }
         rolling_elems<K + 1>(wl, wt, il0, n, tot, f);
     }
 }
+// all PART lead indices are in [ADW, n-1): no predicates
 template <int K, typename F>
-__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2], int il0,
+__device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2], int i0,
                                              int &tot, F &f) {
     if constexpr (K < PART) {
         tot += clampi_raw(RowPrefetch::sample_part<K>(wl)) - clampi_raw(RowPrefetch::sample_part<K>(wt));
-        f((int64_t)(il0 + K - ADW + 1), tot);
-        rolling_full<K + 1>(wl, wt, il0, tot, f);
+        f(i0 + K, tot);
+        rolling_full<K + 1>(wl, wt, i0, tot, f);
     }
 }
 template <typename F>
@@ -593,6 +596,7 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
     if (ntiles == 0) return;
     constexpr int LAG = 31;  // tiles between the two streams
     int tot = 0;
+    const int n32 = (int)n;
     lead.issue(0);
     lead.commit(0);
     for (int t = 0; t < ntiles; ++t) {
@@ -607,9 +611,9 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
 #pragma unroll
                 for (int k = 0; k < PART / 2; ++k) wt[k] = 0u;
             }
-            const int64_t il0 = (int64_t)t * TILE + h * PART - skip;
-            if (__all(il0 >= ADW && il0 + PART <= n)) rolling_full<0>(wl, wt, (int)il0, tot, f);
-            else if (n > ADW) rolling_elems<0>(wl, wt, il0, n, tot, f);
+            const int il0 = t * TILE + h * PART - skip;
+            if (__all(il0 >= ADW && il0 + PART < n32)) rolling_full<0>(wl, wt, il0 - ADW + 1, tot, f);
+            else if (n > ADW) rolling_elems<0>(wl, wt, (int64_t)il0, n, tot, f);
         }
         if (t + 1 < ntiles) lead.commit(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.commit(t + 1 - LAG);
@@ -649,18 +653,19 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
     const int64_t m = n - ADW;
     const float mf = (float)(int)m;
     float s = 0.0f;
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) { if (i < m) s = s + roll_mean(tot); });
+    sweep_rolling(lead, trail, skip, n, [&](int, int tot) { s = s + roll_mean(tot); });
     const float mn = s / mf;
     float q = 0.0f;
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) {
-        if (i < m) { const float d = roll_mean(tot) - mn; q = q + d * d; }
+    sweep_rolling(lead, trail, skip, n, [&](int, int tot) {
+        const float d = roll_mean(tot) - mn;
+        q = q + d * d;
     });
     const float sd = sqrtf(q / mf);
     const float std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
     RunFinder F;
     const float bot = mn - sd * std_scale;
     F.init(roll_threshold(bot, false), roll_threshold(bot, true), 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
-    sweep_rolling(lead, trail, skip, n, [&](int64_t i, int tot) { if (i < m) F.step((int)i, tot); });
+    sweep_rolling(lead, trail, skip, n, [&](int i, int tot) { F.step(i, tot); });
     F.finish();
     if (!valid) return;
     sgk_prefix_rec_t *o = a.prefix + r;
