@@ -59,6 +59,9 @@ __device__ inline Region get_region(int mode, const sgk_batch_t &b, const sgk_pr
 __device__ inline float clampf_raw(int16_t v) {  // rm_outlier, src/jnn.c:61-77
     return v > 1200 ? 1200.0f : (v < 0 ? 0.0f : (float)v);
 }
+__device__ inline int clampi_raw(int16_t v) {  // rm_outlier as an integer (the float it yields is that integer)
+    return v > 1200 ? 1200 : (v < 0 ? 0 : (int)v);
+}
 __device__ inline float clampf_pa(float v) {     // rm_outlierf, src/jnn.c:79-95
     return v > 1200.0f ? 1200.0f : (v < 0.0f ? 0.0f : v);
 }
@@ -389,34 +392,54 @@ __global__ __launch_bounds__(256) void k_median(StatArgs a) {
 struct JnnAuto {
     float top, bot, first_min;
     int window, error, seg_dist;
-    int open, err, run_err, c, w, start, nseg, last_x, last_y;
+    int hi_i, lo_i;  // integer form of the thresholds for integer-valued samples: in  <=>  lo_i < iv < hi_i
+    int first_min_i; // (float)c >= first_min  <=>  c >= first_min_i
+    int open_m;      // -1 while a segment is open, else 0 (all predicates are kept as 0 / -1 lane masks)
+    int err, run_err, c, w, start, nseg, last_x, last_y;
     __device__ void init(float top_, float bot_, int corrector, int seg_dist_, int window_, float stall_len, int error_) {
         top = top_; bot = bot_; window = window_; error = error_; seg_dist = seg_dist_;
         first_min = (float)window_ * stall_len;
-        open = 0; err = 0; run_err = 0; c = 0; w = corrector; start = 0; nseg = 0; last_x = 0; last_y = 0;
+        first_min_i = (int)ceilf(first_min);
+        // v < top <=> iv < ceil(top), v > bot <=> iv > floor(bot) for an integer iv in [0, 1200]; NaN thresholds
+        // compare false with everything
+        hi_i = (top_ != top_) ? -0x40000000 : (top_ > 4000.0f ? 4000 : (top_ < -4.0f ? -4 : (int)ceilf(top_)));
+        lo_i = (bot_ != bot_) ? 0x40000000 : (bot_ > 4000.0f ? 4000 : (bot_ < -4.0f ? -4 : (int)floorf(bot_)));
+        open_m = 0; err = 0; run_err = 0; c = 0; w = corrector; start = 0; nseg = 0; last_x = 0; last_y = 0;
     }
-    // emit(k, x, y) is called when segment k can no longer change.  The per-sample bookkeeping is written
-    // with selects (the lanes of a wave run different reads, so every branch taken by any lane costs the
-    // whole wave); only closing a segment -- rare -- branches.
+    // in-range test of a clamped raw sample as a lane mask (no compare -> scalar-mask -> select round trips)
+    __device__ __forceinline__ int in_mask_raw(int iv) const { return ((iv - hi_i) & (lo_i - iv)) >> 31; }
+    __device__ __forceinline__ int in_mask_f(float v) const { return ((v < top) & (v > bot)) ? -1 : 0; }
+
+    // One sample of jnn_core (src/jnn.c:213-271).  emit(k, x, y) is called when segment k can no longer change.
+    // The lanes of a wave run different reads, and a lone wave spends its time waiting on dependent
+    // compare -> SGPR -> select chains, so the per-sample bookkeeping is integer mask algebra on the vector
+    // unit (0 / -1 masks, "x - mask" adds one); one wave-level test guards the two rare events (the c % w
+    // correction and the end of a segment).
     template <typename E>
-    __device__ __forceinline__ void step(int i, float v, E emit) {
-        const bool in = (v < top) & (v > bot);
-        const bool opn = open != 0;
-        const bool tol = !in & opn & (err < error);                 // tolerated out-of-range sample
-        const bool rest = !in & opn & !tol;
-        const bool cnt = in | tol;
-        start = (in & !opn) ? i : start;
-        const int c1 = c + (cnt ? 1 : 0);
-        const int w1 = w + (in ? 1 : 0);
-        int err1 = err + (tol ? 1 : 0);
+    __device__ __forceinline__ void step(int i, int in, E emit) {
+        const int opn = open_m;
+        const int errlt = (err - error) >> 31;           // err < error
+        const int tol = ~in & opn & errlt;               // tolerated out-of-range sample
+        const int rest = ~in & opn & ~errlt;             // the segment ends (closed or abandoned)
+        const int cnt = in | tol;
+        const int opening = in & ~opn;
+        start = (opening & i) | (~opening & start);
+        const int c1 = c - cnt;
+        const int w1 = w - in;
+        int err1 = err - tol;
+        run_err = (run_err - tol) & ~in;
         // "if (c >= window && c >= w && c % w == 0) err--" (jnn.c:228, 238): c >= w needs more tolerated
-        // samples in the segment than in-range samples before it -- rare, so the modulo sits behind a branch
-        if (cnt & (c1 >= window) & (c1 >= w1)) {
-            if ((c1 % w1) == 0) --err1;
-        }
-        run_err = in ? 0 : (tol ? run_err + 1 : run_err);
-        if (rest) {
-            if (c >= window || (nseg == 0 && (float)c >= first_min)) {
+        // samples in the segment than in-range samples before it
+        const int fix = cnt & ((window - 1 - c1) >> 31) & ((w1 - 1 - c1) >> 31);
+        // a segment that ends is kept if it is long enough (jnn.c:243-262), otherwise it is just dropped; with
+        // thresholds at mean +- 0.75 std short runs are dropped every few samples, so dropping must not branch
+        const int first = (nseg - 1) >> 31;              // no segment yet
+        const int keep = rest & (((window - 1 - c) >> 31) | (first & ((first_min_i - 1 - c) >> 31)));
+        if (__any((fix | keep) != 0)) {
+            if (fix) {
+                if ((c1 % w1) == 0) --err1;
+            }
+            if (keep) {
                 const int end = i - run_err;
                 if (nseg > 0 && start - last_y < seg_dist) {
                     last_y = end;
@@ -426,11 +449,11 @@ struct JnnAuto {
                     ++nseg;
                 }
             }
-            open = 0; c = 0; err = 0; run_err = 0;
-        } else {
-            open = in ? 1 : open;
-            c = c1; err = err1;
         }
+        open_m = (open_m | in) & ~rest;
+        c = c1 & ~rest;
+        err = err1 & ~rest;
+        run_err &= ~rest;
         w = w1;
     }
     template <typename E>
@@ -468,7 +491,7 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
         if ((uint64_t)k < cap) { a.seg_x[slot0 + k] = x; a.seg_y[slot0 + k] = y; }
         else overflow = true;
     };
-    sweep_rows_parts<16>(rs, skip, g.len, [&](int64_t j, int16_t v) { A.step((int)j, clampf_raw(v), emit); });
+    sweep_rows_parts<16>(rs, skip, g.len, [&](int64_t j, int16_t v) { A.step((int)j, A.in_mask_raw(clampi_raw(v)), emit); });
     A.finish(emit);
     if (valid) a.n_segs[r] = (uint32_t)A.nseg;
     if (overflow) atomicAdd(a.err_count, 1u);
@@ -499,7 +522,7 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
     };
     // (a lane whose first segment is final could stop; the sweep is wave-cooperative, so it just idles)
     sweep_rows_parts<16>(rs, skip, g.len, [&](int64_t j, int16_t v) {
-        if (py < 0 || A.nseg < 2) A.step((int)j, clampf_pa(to_pa(v, sc)), emit);
+        if (py < 0 || A.nseg < 2) A.step((int)j, A.in_mask_f(clampf_pa(to_pa(v, sc))), emit);
     });
     if (A.nseg == 1 || (A.nseg >= 2 && py < 0)) A.finish(emit);
     if (valid) {
@@ -544,9 +567,6 @@ struct RunFinder {
 
 constexpr int ADW = 2000;  // jnnv2 window (both presets, src/jnn.h:84-98)
 
-__device__ inline int clampi_raw(int16_t v) {  // rm_outlier as an integer (the float it yields is that integer)
-    return v > 1200 ? 1200 : (v < 0 ? 0 : (int)v);
-}
 // rolling_window's t_i = tt / w (src/jnn.c:20-56).  tt is a float holding an exact integer (< 2000*1200 < 2^24),
 // so it is carried as an int here; the division by the constant 2000 is the correctly rounded three-operation
 // form of tstat_math.h (verified exhaustively for every float >= 2^-100 by oracle/verify_math.cpp).
