@@ -90,27 +90,55 @@ struct RowPrefetch {
     int shift8;   // added to every row base, in units of 8 samples (a second stream over the same rows)
     uint4 pf[8];
     uint32_t rb_of[8];  // (row base - rb0) / 8 of the eight rows this lane fetches pieces of
+    uint32_t rb_max;    // wave-uniform: the largest of them over the wave
+    int t_lo, t_hi;     // tiles t_lo..t_hi lie inside the buffer for every row of the wave: no clamping needed
     unsigned long long rowmask;
 
     __device__ void init(char *lds_, const int16_t *base_, int64_t hi_, int64_t rb_, unsigned long long rowmask_) {
-        lds = lds_; base = base_; hi = hi_; rb = rb_; rowmask = rowmask_; shift8 = 0;
+        lds = lds_; base = base_; hi = hi_; rb = rb_; rowmask = rowmask_;
         const int l = lane_id();
         const bool wanted = (rowmask_ >> l) & 1ull;
         long long m = wanted ? (long long)rb_ : 0x7fffffffffffffffll;  // rows nobody wants do not move the base
+        long long mx = wanted ? (long long)rb_ : -0x7fffffffffffffffll;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            const long long o = __shfl_xor(m, d, 64);
+            const long long o = __shfl_xor(m, d, 64), o2 = __shfl_xor(mx, d, 64);
             m = o < m ? o : m;
+            mx = o2 > mx ? o2 : mx;
         }
         rb0 = (m == 0x7fffffffffffffffll) ? 0 : m;
+        rb_max = (m == 0x7fffffffffffffffll) ? 0u : (uint32_t)((mx - rb0) >> 3);
         const uint32_t mine = wanted ? (uint32_t)((rb_ - rb0) >> 3) : 0u;
 #pragma unroll
         for (int it = 0; it < 8; ++it) rb_of[it] = (uint32_t)__shfl((int)mine, it * 8 + l / 8, 64);
+        set_shift(0);
     }
+    // a second stream over the same rows, displaced by s8 * 8 samples
+    __device__ void set_shift(int s8) {
+        shift8 = s8;
+        // piece position = rb0 + (rb_of + shift8) * 8 + tile * 64 + v * 8 must lie in [0, hi - 8] for v = 0..7
+        const int64_t first = rb0 + (int64_t)shift8 * 8, last = rb0 + ((int64_t)rb_max + shift8) * 8 + 56;
+        const int64_t lo64 = first >= 0 ? 0 : (-first + TILE - 1) / TILE;
+        int64_t hi64 = (hi - 8 - last) >= 0 ? (hi - 8 - last) / TILE : -1;
+        // the fast path addresses pieces with 32-bit byte offsets from rb0
+        const int64_t lim = ((int64_t)1 << 31) / (TILE * 2) - (((int64_t)rb_max + 8) * 16) / (TILE * 2) - 2;
+        if (hi64 > lim) hi64 = lim;
+        t_lo = (int)(lo64 > 0x7fffffff ? 0x7fffffff : lo64);
+        t_hi = (int)hi64;
+    }
+    __device__ __forceinline__ bool interior(int tile) const { return tile >= t_lo && tile <= t_hi; }
     __device__ __forceinline__ int64_t piece_pos(int it, int tile) const {
         return rb0 + (((int64_t)rb_of[it] + shift8) << 3) + (int64_t)tile * TILE + (lane_id() & 7) * 8;
     }
     __device__ __forceinline__ void issue(int tile) {
+        if (interior(tile)) {  // wave-uniform: plain 32-bit offset arithmetic, no clamping
+            const char *wave_base = reinterpret_cast<const char *>(base + rb0);
+            const int toff = (tile * TILE + shift8 * 8 + (lane_id() & 7) * 8) * 2;
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                pf[it] = *reinterpret_cast<const uint4 *>(wave_base + (int)(rb_of[it] * 16u) + toff);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             int64_t p0 = piece_pos(it, tile);
@@ -122,13 +150,16 @@ struct RowPrefetch {
     __device__ __forceinline__ void commit(int tile) {
         const int l = lane_id();
         const int v = l & 7;
+        const bool inside = interior(tile);
         __syncthreads();  // every lane has copied the previous tile into registers
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + l / 8;
-            const int64_t p0 = piece_pos(it, tile);
             uint4 q = pf[it];
-            if (p0 < 0 || p0 > hi - 8) q = make_uint4(0u, 0u, 0u, 0u);  // outside the buffer: zeros
+            if (!inside) {
+                const int64_t p0 = piece_pos(it, tile);
+                if (p0 < 0 || p0 > hi - 8) q = make_uint4(0u, 0u, 0u, 0u);  // outside the buffer: zeros
+            }
             uint32_t *dst = reinterpret_cast<uint32_t *>(lds + row * ROW_BYTES + v * 16);
             dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
         }

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
     // trail position = lead position - 2000 = (row base - 16) + (q - 31*64): the same rows, shifted
     trail = lead;
     trail.lds = lds + Stream1::LDS_BYTES;
-    trail.shift8 = -2;
+    trail.set_shift(-2);
     const int64_t m = n - ADW;
     const float mf = (float)(int)m;
     float s = 0.0f;
