@@ -129,16 +129,26 @@ def main():
         alg_bytes = 2 * S + 16 * E + 40 * R
         achieved = alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.rna and R == 10000 and args.read_len == 100000:
+            # PMC passes of this same command (separate rocprofv3 --pmc runs, see profiles/README.md): HBM bytes
+            # per step, and the VALU occupancy that actually bounds the dominant kernel (it is issue-bound: a
+            # wave64 vector instruction holds its SIMD for 4 cycles whatever its type)
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+                pmc = json.load(open(tpath))
+                traffic = pmc.get("hbm_bytes_per_step")
+                sq = pmc.get("sq_counters_per_step", {}).get("k_event_detect")
+                if sq:
+                    busy_ms = sq["SQ_ACTIVE_INST_VALU_quadcycles"] * 4 / 1024 / 2.4e9 * 1e3
+                    valu = {"kernel": "k_event_detect", "wave_instructions": sq["SQ_INSTS_VALU"],
+                            "busy_ms_at_2.4GHz": round(busy_ms, 2), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc)"}
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes, "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
-                    "dominant_kernel": dominant, "path_ms": round(path_ms, 4)}
+                    "dominant_kernel": dominant, "path_ms": round(path_ms, 4), "valu": valu}
 
         cpu = None
         if args.cpu_reads > 0 and world == 1:
