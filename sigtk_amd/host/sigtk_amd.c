@@ -568,7 +568,8 @@ static void *writer_main(void *arg) {
         double t1 = realtime();
         P->t_wait += t1 - t0;
         /* contiguous chunks of reads with about equal sample counts; a few per thread for balance */
-        uint32_t nchunks = (uint32_t)P->nthreads * 4;
+        const int wthreads = P->nthreads > 32 ? 32 : P->nthreads;  /* formatting is light: fewer threads, less start-up */
+        uint32_t nchunks = (uint32_t)wthreads * 4;
         if (nchunks > b->n) nchunks = b->n;
         if (nchunks > chunk_cap) {
             chunk = (sbuf_t *)realloc(chunk, sizeof(sbuf_t) * nchunks);
@@ -589,7 +590,7 @@ static void *writer_main(void *arg) {
         while (k < nchunks) chunk_lo[++k] = b->n;
         c.chunk = chunk;
         c.chunk_lo = chunk_lo;
-        pfor(P->nthreads, nchunks, write_chunk, &c);
+        pfor(wthreads, nchunks, write_chunk, &c);
         double t2 = realtime();
         P->t_format += t2 - t1;
         for (uint32_t i = 0; i < nchunks; i++)
@@ -727,7 +728,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     if (nthreads <= 0) {
         long nc = sysconf(_SC_NPROCESSORS_ONLN);
         nthreads = nc > 1 ? (int)(nc / 2) : 1;
-        if (nthreads > 32) nthreads = 32;
+        if (nthreads > 64) nthreads = 64;  /* inflate scales to ~64 threads; beyond that thread start-up dominates */
     }
 
     pipe_t P;
