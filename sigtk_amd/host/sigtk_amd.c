@@ -6,7 +6,7 @@
  *   src/cmain.c:40-156  options (-h -V -n -c --print-stat, ignored -o/--verbose), DNA/RNA and pore
  *                       detection from read-group 0, sequential or read-id mode
  *   src/cfunc.c         the TSV grammar of every subtool (byte-identical output)
- * What differs by design: records are not processed one at a time.  A loader pulls the records'
+ * What differs by design: records are not processed one at a time.  A reader thread pulls the records'
  * bytes off the file in order and a pool of threads inflates/parses them into the pinned staging of a
  * job (sgk_job_*, include/sigtk_gpu.h); svb-zd signals are handed to the GPU still compressed and
  * decoded there.  Several batches are in flight (one per GPU plus two), a writer thread formats the
@@ -193,16 +193,16 @@ static void pfor(int nthreads, uint32_t n, pfor_fn fn, void *ctx) {
 
 /* ------------------------------------------------------------------ batches and the pipeline
  *
- *   loader (main thread)                                  writer thread
- *   --------------------                                  -------------
- *   take a free batch                                     take the oldest submitted batch
- *   read the records' bytes off the file, in order        sgk_job_wait
- *   N threads: inflate + parse                            N threads: format rows into chunk buffers
- *   sgk_job_begin (layout, pinned staging)                fwrite the chunks in order
- *   N threads: copy svb-zd blobs / samples into staging   return the batch to the free list
- *   sgk_job_submit (async H2D, decode, kernels, D2H)
+ *   reader thread                 loader (main thread)                       writer thread
+ *   -------------                 --------------------                       -------------
+ *   take a free batch             take the next filled batch                 take the oldest submitted batch
+ *   read the records' bytes       N threads: inflate + parse                 sgk_job_wait
+ *   off the file, in order        sgk_job_begin (layout, pinned staging)     N threads: format rows into chunks
+ *   hand it over                  N threads: copy svb-zd blobs / samples     fwrite the chunks in order
+ *                                 sgk_job_submit (async H2D, decode,         return the batch to the free list
+ *                                 kernels, D2H)
  *
- * n_gpus + 2 batches circulate; batch k runs on GPU k mod n_gpus (whole batches are the sharding unit:
+ * n_gpus + 3 batches circulate; batch k runs on GPU k mod n_gpus (whole batches are the sharding unit:
  * every output row depends on one record only, src/cmain.c:118-120, so there is no collective). */
 
 typedef struct {
@@ -260,7 +260,11 @@ typedef struct {
     b5_file_t *f;
     int mode, nthreads, host_decode;
     opt_t opt;
-    queue_t free_q, ready_q;
+    queue_t free_q, filled_q, ready_q;
+    /* reader thread input */
+    uint64_t limit_bytes;
+    char **ids;      /* read-id mode: ids[0..n_ids) */
+    int n_ids;
     double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
     uint64_t n_reads, n_samples;
 } pipe_t;
@@ -609,6 +613,55 @@ static void *writer_main(void *arg) {
     return NULL;
 }
 
+/* ------------------------------------------------------------------ reader thread
+ * Pulls the records' bytes off the file (sequentially, or by read id) into free batches and hands each full batch
+ * to the loader, so that file reads overlap with inflating / staging the previous batch. */
+static void *reader_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    b5_file_t *f = P->f;
+    batch_t *b = q_pop(&P->free_q);
+    int ret = 0;
+    if (P->n_ids == 0) {
+        for (;;) {
+            uint64_t size = 0;
+            const double t0 = realtime();
+            ret = b5_next_raw(f, &b->raw, &b->raw_len, &b->raw_cap, &size);
+            P->t_read += realtime() - t0;
+            if (ret < 0) break;
+            batch_add_record(b, size);
+            if (b->raw_len >= P->limit_bytes) {
+                q_push(&P->filled_q, b);
+                b = q_pop(&P->free_q);
+            }
+        }
+        if (ret != B5_EOF) {
+            fprintf(stderr, "Error in slow5_get_next. Error code %d\n", ret);
+            exit(EXIT_FAILURE);
+        }
+    } else {
+        if (b5_index(f) < 0) {
+            ERROR("cmain", "Error loading index file for %s", f->path);
+            exit(EXIT_FAILURE);
+        }
+        for (int i = 0; i < P->n_ids; i++) {
+            fprintf(stderr, "Read ID %s\n", P->ids[i]);
+            uint64_t size = 0;
+            if (b5_get_raw(f, P->ids[i], &b->raw, &b->raw_len, &b->raw_cap, &size) < 0) {
+                ERROR("cmain", "%s", "Error when fetching the read");
+                exit(EXIT_FAILURE);
+            }
+            batch_add_record(b, size);
+            if (b->raw_len >= P->limit_bytes) {
+                q_push(&P->filled_q, b);
+                b = q_pop(&P->free_q);
+            }
+        }
+    }
+    b->last = 1;  /* the final (possibly empty) batch ends the stream */
+    q_push(&P->filled_q, b);
+    return NULL;
+}
+
 /* ------------------------------------------------------------------ cmain (src/cmain.c:40-156) */
 
 static struct option long_options[] = {
@@ -739,8 +792,9 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     P.host_decode = host_decode;
     P.opt = opt;
     q_init(&P.free_q);
+    q_init(&P.filled_q);
     q_init(&P.ready_q);
-    const int nbatch = n_gpus + 2;
+    const int nbatch = n_gpus + 3;  /* one being read, one being inflated/staged, n_gpus in flight, one being written */
     batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
     if (!pool) die_mem();
     const double t_jobs0 = realtime();
@@ -758,46 +812,23 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
 
     /* on-disk bytes per sample: ~0.85 (zlib over svb-zd), ~1.3 (svb-zd only), 2 (raw); the batch limit is
      * applied to the bytes read, which is all the loader knows before the records are inflated */
-    const uint64_t limit_bytes = batch_samples;
-    int ret = 0;
-    batch_t *b = q_pop(&P.free_q);
-    if (argc - optind == 1) {
-        for (;;) {
-            uint64_t size = 0;
-            const double t0 = realtime();
-            ret = b5_next_raw(f, &b->raw, &b->raw_len, &b->raw_cap, &size);
-            P.t_read += realtime() - t0;
-            if (ret < 0) break;
-            batch_add_record(b, size);
-            if (b->raw_len >= limit_bytes) {
-                batch_launch(&P, b);
-                b = q_pop(&P.free_q);
-            }
-        }
-        if (ret != B5_EOF) {
-            fprintf(stderr, "Error in slow5_get_next. Error code %d\n", ret);
-            exit(EXIT_FAILURE);
-        }
-    } else {
-        if (b5_index(f) < 0) {
-            ERROR("cmain", "Error loading index file for %s", argv[optind]);
-            exit(EXIT_FAILURE);
-        }
-        for (int i = optind + 1; i < argc; i++) {
-            fprintf(stderr, "Read ID %s\n", argv[i]);
-            uint64_t size = 0;
-            if (b5_get_raw(f, argv[i], &b->raw, &b->raw_len, &b->raw_cap, &size) < 0) {
-                ERROR("cmain", "%s", "Error when fetching the read");
-                exit(EXIT_FAILURE);
-            }
-            batch_add_record(b, size);
-            if (b->raw_len >= limit_bytes) {
-                batch_launch(&P, b);
-                b = q_pop(&P.free_q);
-            }
-        }
+    P.limit_bytes = batch_samples;
+    P.ids = argv + optind + 1;
+    P.n_ids = argc - optind - 1;
+    pthread_t rth;
+    if (pthread_create(&rth, NULL, reader_main, &P) != 0) {
+        ERROR("cmain", "%s", "cannot create the reader thread");
+        exit(EXIT_FAILURE);
     }
-    if (b->n) batch_launch(&P, b);
+    for (;;) {
+        batch_t *b = q_pop(&P.filled_q);
+        const int last = b->last;
+        b->last = 0;
+        if (b->n) batch_launch(&P, b);
+        else q_push(&P.free_q, b);
+        if (last) break;
+    }
+    pthread_join(rth, NULL);
     pool[nbatch].last = 1;
     q_push(&P.ready_q, &pool[nbatch]);
     pthread_join(wth, NULL);
@@ -960,5 +991,9 @@ int main(int argc, char *argv[]) {
     for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
     fprintf(stderr, "\n[%s] Real time: %.3f sec; CPU time: %.3f sec; Peak RAM: %.3f GB\n\n", __func__,
             realtime() - realtime0, cputime(), peakrss() / 1024.0 / 1024.0 / 1024.0);
-    return ret;
+    /* everything is written; leave without running the HIP runtime's exit handlers (they take longer than a
+     * small input does) */
+    fflush(stdout);
+    fflush(stderr);
+    _exit(ret);
 }
