@@ -316,10 +316,13 @@ class Job:
     def close(self):
         if self.h:
             self.L.sgk_job_destroy(self.h)
-            self.h = C.c_void_p()
+            self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: module globals may already be gone
+            pass
 
     def stage(self, signals, dig, off, rng, counts=None):
         """sgk_job_begin + fill the pinned staging (int16 arrays, or svb-zd blobs when `counts` is given)"""

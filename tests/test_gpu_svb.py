@@ -65,3 +65,38 @@ def test_corrupt_blobs_are_reported(gpu):
     got, status = _decode(gpu, [good, good[:-5], good + b"\x00\x00", good], [3000, 3000, 3000, 2999])
     assert list(status) == [0, 2, 2, 1]
     assert np.array_equal(got[0], a)
+
+
+def test_corrupted_blobs_are_rejected_not_trusted(gpu):
+    """bit flips, truncations, trailing junk and wrong count words: every batch is either rejected (per-read status
+    -> SGK_ERR_FORMAT from sgk_job_wait) or was still a well-formed stream; the decoder never reads or writes
+    outside the blob / the read's sample range, and the job stays usable."""
+    import random
+    rnd = random.Random(3)
+    reads, dig, off, rng = gpu.synth_reads_host(6, [5000, 1, 17, 4096, 30000, 1023], 5, 0)
+    good = [blow5.svb_zd_encode(r) for r in reads]
+    counts = [r.size for r in reads]
+    job = gpu.Job(0)
+    rejected = 0
+    for it in range(200):
+        blobs = [bytearray(b) for b in good]
+        k = rnd.randrange(len(blobs))
+        mode = it % 4
+        if mode == 0 and len(blobs[k]) > 5:
+            blobs[k][rnd.randrange(4, len(blobs[k]))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            blobs[k] = blobs[k][: rnd.randrange(0, len(blobs[k]))]
+        elif mode == 2:
+            blobs[k] = blobs[k] + bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 9)))
+        else:
+            blobs[k][0:4] = int(rnd.randrange(0, 70000)).to_bytes(4, "little")
+        try:
+            job.submit(gpu.TOOL_STAT, [bytes(b) for b in blobs], dig, off, rng, counts=counts)
+            job.wait()
+        except gpu.SigtkGpuError as e:
+            assert "malformed compressed signal" in str(e)
+            rejected += 1
+    assert rejected > 100
+    job.submit(gpu.TOOL_STAT, good, dig, off, rng, counts=counts)
+    assert job.wait()["stat"].size == 6
+    job.close()
