@@ -209,6 +209,21 @@ int sgk_svbzd_decode(const uint8_t *blobs, const uint64_t *blob_offsets, const u
                      uint32_t n_reads, int16_t *samples, const uint64_t *offsets, const uint32_t *lengths,
                      uint32_t *status, void *stream);
 
+/* ---- qts: quantise the raw signal (src/qts.c:27-43, :126-142) and re-encode it ------ */
+#define SGK_QTS_FLOOR 0     /* (raw >> b) << b                                       */
+#define SGK_QTS_ROUND 1     /* round_to_power_of_2(raw, b): the reference's default   */
+#define SGK_QTS_FILL_ONES 2 /* raw | ((1 << b) - 1)                                   */
+/* in place on the samples of every read; bits in [1, 15] */
+int sgk_qts(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+            uint32_t max_read_len, int bits, int method, void *stream);
+/* svb-zd ENCODE (slow5lib/src/slow5_press.c:1063-1089): canonical streamvbyte, so the blobs equal slow5lib's byte
+ * for byte.  Two steps: sgk_svbzd_size fills blob_lengths[r] (4 + key bytes + data bytes); the caller lays the blobs
+ * out (blob_offsets[r], 4-byte aligned) and sgk_svbzd_encode writes them. */
+int sgk_svbzd_size(const int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                   uint32_t *blob_lengths, void *stream);
+int sgk_svbzd_encode(const int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                     uint8_t *blobs, const uint64_t *blob_offsets, const uint32_t *blob_lengths, void *stream);
+
 /* ---- synthetic reads (BASELINE configs 2-5) ---------------------------- */
 /* Deterministic counter-based generator, identical on host and device (integer only).
  * kind 0: DNA-like (mean dwell 9 samples); kind 1: RNA-like (mean dwell 36, adaptor +

@@ -90,7 +90,8 @@ ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
     "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
-    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode", "sgk_synth_reads", "sgk_synth_reads_host",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
+    "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
     "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
     "sgk_segs_host_free", "sgk_prefix_host", "sgk_signal_in_picoamps", "sgk_getevents",
@@ -145,6 +146,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_ent.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sgk_ent_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.sgk_ent_finish.restype = None
+    L.sgk_qts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    L.sgk_svbzd_size.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.sgk_svbzd_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
     L.sgk_job_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.sgk_job_destroy.argtypes = [C.c_void_p]
     L.sgk_job_destroy.restype = None

@@ -218,3 +218,33 @@ def svbzd_decode(blobs, counts, device: torch.device):
                                  _ptr(reads.offsets), _ptr(reads.lengths), _ptr(status), _stream_ptr()),
               "sgk_svbzd_decode")
     return reads, status
+
+
+# ---------------------------------------------------------------------- qts + svb-zd encode (device API)
+
+def qts(b: DeviceReads, bits: int, method: int) -> None:
+    """sgk_qts: quantise the samples of every read in place (method 0 floor, 1 round, 2 fill-ones)."""
+    L = api.load_library()
+    api.check(L.sgk_qts(_ptr(b.samples), _ptr(b.offsets), _ptr(b.lengths), b.n_reads, b.max_read_len, int(bits),
+                        int(method), _stream_ptr()), "sgk_qts")
+
+
+def svbzd_encode(b: DeviceReads):
+    """sgk_svbzd_size + sgk_svbzd_encode -> list of blobs (bytes), one per read"""
+    L = api.load_library()
+    dev = b.samples.device
+    n = b.n_reads
+    blens = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    api.check(L.sgk_svbzd_size(_ptr(b.samples), _ptr(b.offsets), _ptr(b.lengths), n, _ptr(blens), _stream_ptr()),
+              "sgk_svbzd_size")
+    torch.cuda.synchronize()
+    lens = blens[:n].cpu().numpy().astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum((lens + 7) // 8 * 8, out=offs[1:])
+    blobs = torch.zeros(max(int(offs[-1]), 8), dtype=torch.uint8, device=dev)
+    d_offs = torch.from_numpy(offs[:n].copy() if n else np.zeros(1, dtype=np.int64)).to(dev)
+    api.check(L.sgk_svbzd_encode(_ptr(b.samples), _ptr(b.offsets), _ptr(b.lengths), n, _ptr(blobs), _ptr(d_offs),
+                                 _ptr(blens), _stream_ptr()), "sgk_svbzd_encode")
+    torch.cuda.synchronize()
+    host = blobs.cpu().numpy()
+    return [host[int(offs[r]):int(offs[r]) + int(lens[r])].tobytes() for r in range(n)]
