@@ -294,6 +294,7 @@ typedef struct sgk_job sgk_job_t;
 #define SGK_TOOL_JNN 3
 #define SGK_TOOL_PREFIX 4
 #define SGK_TOOL_ENT 5
+#define SGK_TOOL_QTS 6 /* submitted with sgk_job_submit_qts */
 
 #define SGK_SIGNAL_INT16 0 /* caller stages decoded int16 samples                        */
 #define SGK_SIGNAL_SVBZD 1 /* caller stages svb-zd blobs; decoded on the GPU (8f-1)      */
@@ -323,6 +324,12 @@ typedef struct sgk_job_output {
     const sgk_stat_rec_t *stat;
     const sgk_prefix_rec_t *prefix;
     sgk_event_status_t event_status;
+    /* qts: the quantised signal, as svb-zd blobs (blob r at qts_blobs + qts_blob_offsets[r], qts_blob_lengths[r]
+     * bytes) or, for files without signal compression, as int16 samples at qts_samples + offsets[r] */
+    const uint8_t *qts_blobs;
+    const uint64_t *qts_blob_offsets;
+    const uint32_t *qts_blob_lengths;
+    const int16_t *qts_samples;
     const sgk_ent_hist_t *ent;            /* ent: one record per read */
     uint16_t *ent_over_raw, *ent_over_delta; /* ent: host copies of the overflow lists (NULL if all empty) */
 } sgk_job_output_t;
@@ -335,6 +342,9 @@ int sgk_job_begin(sgk_job_t *job, uint32_t n_reads, const uint32_t *lengths, int
                   const uint32_t *blob_bytes, sgk_job_input_t *in);
 /* may be called again after sgk_job_wait to run another tool over the same staged batch */
 int sgk_job_submit(sgk_job_t *job, int tool, int rna, int pore, int flags);
+/* qts over the staged batch: quantise (bits in [1,15], method SGK_QTS_*), then hand the signal back as svb-zd blobs
+ * (out_signal_format SGK_SIGNAL_SVBZD) or int16 samples (SGK_SIGNAL_INT16) */
+int sgk_job_submit_qts(sgk_job_t *job, int bits, int method, int out_signal_format);
 /* SGK_ERR_FORMAT if a blob did not decode, SGK_ERR_CAPACITY on event-slot overflow */
 int sgk_job_wait(sgk_job_t *job);
 /* valid after sgk_job_wait until the job's next sgk_job_begin */

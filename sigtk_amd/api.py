@@ -70,10 +70,12 @@ class JobOutput(C.Structure):
                 ("ev_mean", C.POINTER(C.c_float)), ("ev_stdv", C.POINTER(C.c_float)),
                 ("seg_x", C.POINTER(C.c_int32)), ("seg_y", C.POINTER(C.c_int32)),
                 ("stat", C.c_void_p), ("prefix", C.c_void_p), ("event_status", EventStatus),
+                ("qts_blobs", C.c_void_p), ("qts_blob_offsets", C.POINTER(C.c_uint64)),
+                ("qts_blob_lengths", C.POINTER(C.c_uint32)), ("qts_samples", C.c_void_p),
                 ("ent", C.c_void_p), ("ent_over_raw", C.c_void_p), ("ent_over_delta", C.c_void_p)]
 
 
-TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX, TOOL_ENT = range(6)
+TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX, TOOL_ENT, TOOL_QTS = range(7)
 ENT_HIST_BYTES = 4 * (4 + 8192 + 4096 + 512)   # sizeof(sgk_ent_hist_t)
 SIGNAL_INT16, SIGNAL_SVBZD = 0, 1
 JOB_EVENTS_COMPACT = 1
@@ -95,7 +97,8 @@ ABI_SYMBOLS = [
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
     "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
     "sgk_segs_host_free", "sgk_prefix_host", "sgk_signal_in_picoamps", "sgk_getevents",
-    "sgk_job_create", "sgk_job_destroy", "sgk_job_device", "sgk_job_begin", "sgk_job_submit", "sgk_job_wait",
+    "sgk_job_create", "sgk_job_destroy", "sgk_job_device", "sgk_job_begin", "sgk_job_submit", "sgk_job_submit_qts",
+    "sgk_job_wait",
     "sgk_job_output",
 ]
 
@@ -156,6 +159,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_job_device.argtypes = [C.c_void_p]
     L.sgk_job_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(JobInput)]
     L.sgk_job_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sgk_job_submit_qts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.sgk_job_wait.argtypes = [C.c_void_p]
     L.sgk_job_output.argtypes = [C.c_void_p, C.POINTER(JobOutput)]
     L.sgk_event_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.POINTER(EventsHost)]
@@ -351,6 +355,12 @@ class Job:
         self._tool = tool
         check(self.L.sgk_job_submit(self.h, tool, rna, pore, flags), "sgk_job_submit")
 
+    def launch_qts(self, bits: int, method: int, out_svb: bool):
+        self._tool = TOOL_QTS
+        self._qts_svb = out_svb
+        check(self.L.sgk_job_submit_qts(self.h, bits, method, SIGNAL_SVBZD if out_svb else SIGNAL_INT16),
+              "sgk_job_submit_qts")
+
     def submit(self, tool: int, signals, dig, off, rng, rna: int = 0, pore: int = 0, flags: int = 0, counts=None):
         self.stage(signals, dig, off, rng, counts)
         self.launch(tool, rna, pore, flags)
@@ -384,6 +394,13 @@ class Job:
             res["stat"] = np.frombuffer(C.string_at(o.stat, n * STAT_DTYPE.itemsize), dtype=STAT_DTYPE).copy()
         elif self._tool == TOOL_PREFIX:
             res["prefix"] = np.frombuffer(C.string_at(o.prefix, n * PREFIX_DTYPE.itemsize), dtype=PREFIX_DTYPE).copy()
+        elif self._tool == TOOL_QTS:
+            if self._qts_svb:
+                res["blobs"] = [C.string_at(o.qts_blobs + int(o.qts_blob_offsets[r]), int(o.qts_blob_lengths[r]))
+                                for r in range(n)]
+            else:
+                res["samples"] = [np.frombuffer(C.string_at(o.qts_samples + 2 * int(o.offsets[r]), 2 * int(o.lengths[r])),
+                                                dtype=np.int16).copy() for r in range(n)]
         elif self._tool == TOOL_ENT:
             ent = np.zeros((n, 3), dtype=np.float64)
             for r in range(n):

@@ -224,3 +224,32 @@ def read_signal_blobs(path: str):
 
 def iter_reads(path: str) -> Iterator[Read]:
     yield from read_blow5(path).reads
+
+
+def digest(path: str) -> str:
+    """sha256 over what a reader sees in a file: (read id, read group, digitisation, offset, range, sampling rate,
+    samples) of every record, in file order.  Used to compare `qts` outputs written by different writers."""
+    import hashlib
+    h = hashlib.sha256()
+    for r in read_blow5(path).reads:
+        h.update(r.read_id.encode())
+        h.update(struct.pack("<Idddd", r.read_group, r.digitisation, r.offset, r.range, r.sampling_rate))
+        h.update(r.raw.astype("<i2").tobytes())
+    return h.hexdigest()
+
+
+def raw_records(path: str):
+    """-> list of the inflated record byte strings of a file (whole records, auxiliary fields included)"""
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    record_press = buf[9]
+    (hsize,) = struct.unpack_from("<I", buf, 64)
+    pos = 68 + hsize
+    out = []
+    while buf[pos : pos + 5] != EOF_MARK or pos + 5 != len(buf):
+        (size,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        rec = buf[pos : pos + size]
+        pos += size
+        out.append(zlib.decompress(rec) if record_press == 1 else bytes(rec))
+    return out

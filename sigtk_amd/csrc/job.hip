@@ -200,20 +200,11 @@ static int d2h(GrowPin &h, const GrowDev &d, size_t bytes, hipStream_t st) {
     return SGK_OK;
 }
 
-int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
-    if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
-    if (tool < SGK_TOOL_PA || tool > SGK_TOOL_ENT) return SGK_ERR_ARG;
-    SGK_HIP_TRY(hipSetDevice(j->device));
-    j->tool = tool;
-    j->flags = flags;
+// enqueue the uploads of a staged batch (and the svb-zd decode) and describe the device batch
+static int job_upload(sgk_job_t *j, sgk_batch_t *view) {
     const size_t nr = j->n_reads;
     hipStream_t st = j->st;
     int rc;
-    if (nr == 0) {
-        j->submitted = true;
-        return SGK_OK;
-    }
-    // ---- inputs
     if ((rc = h2d(j->d_offsets, j->h_offsets, nr * 8, st)) != SGK_OK) return rc;
     if ((rc = h2d(j->d_lengths, j->h_lengths, nr * 4, st)) != SGK_OK) return rc;
     if ((rc = h2d(j->d_dig, j->h_dig, nr * 8, st)) != SGK_OK) return rc;
@@ -233,16 +224,44 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
     } else {
         if ((rc = h2d(j->d_samples, j->h_samples, j->n_samples * sizeof(int16_t), st)) != SGK_OK) return rc;
     }
+    view->samples = j->d_samples.as<int16_t>();
+    view->offsets = j->d_offsets.as<uint64_t>();
+    view->lengths = j->d_lengths.as<uint32_t>();
+    view->digitisation = j->d_dig.as<double>();
+    view->offset = j->d_off.as<double>();
+    view->range = j->d_rng.as<double>();
+    view->n_reads = j->n_reads;
+    view->max_read_len = j->max_len;
+    view->n_samples = j->n_samples;
+    return SGK_OK;
+}
+
+// blob r of the qts output starts at the 8-byte aligned running sum of the lengths; total[0] = arena bytes used
+__global__ void k_blob_layout(const uint32_t *lens, uint32_t n, uint64_t *offs, uint64_t *total) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t o = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        offs[r] = o;
+        o += ((uint64_t)lens[r] + 7u) & ~7ull;
+    }
+    total[0] = o;
+}
+
+int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
+    if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
+    if (tool < SGK_TOOL_PA || tool > SGK_TOOL_ENT) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(j->device));
+    j->tool = tool;
+    j->flags = flags;
+    const size_t nr = j->n_reads;
+    hipStream_t st = j->st;
+    int rc;
+    if (nr == 0) {
+        j->submitted = true;
+        return SGK_OK;
+    }
     sgk_batch_t view;
-    view.samples = j->d_samples.as<int16_t>();
-    view.offsets = j->d_offsets.as<uint64_t>();
-    view.lengths = j->d_lengths.as<uint32_t>();
-    view.digitisation = j->d_dig.as<double>();
-    view.offset = j->d_off.as<double>();
-    view.range = j->d_rng.as<double>();
-    view.n_reads = j->n_reads;
-    view.max_read_len = j->max_len;
-    view.n_samples = j->n_samples;
+    if ((rc = job_upload(j, &view)) != SGK_OK) return rc;
     const uint32_t *lens = j->h_lengths.as<uint32_t>();
     // ---- kernels + results
     switch (tool) {
@@ -319,6 +338,51 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
     return SGK_OK;
 }
 
+int sgk_job_submit_qts(sgk_job_t *j, int bits, int method, int out_fmt) {
+    if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
+    if (out_fmt != SGK_SIGNAL_INT16 && out_fmt != SGK_SIGNAL_SVBZD) return SGK_ERR_ARG;
+    if (bits < 1 || bits > 15 || method < SGK_QTS_FLOOR || method > SGK_QTS_FILL_ONES) return SGK_ERR_ARG;
+    SGK_HIP_TRY(hipSetDevice(j->device));
+    j->tool = SGK_TOOL_QTS;
+    j->flags = out_fmt;
+    const size_t nr = j->n_reads;
+    hipStream_t st = j->st;
+    int rc;
+    if (nr == 0) {
+        j->submitted = true;
+        return SGK_OK;
+    }
+    sgk_batch_t view;
+    if ((rc = job_upload(j, &view)) != SGK_OK) return rc;
+    int16_t *smp = j->d_samples.as<int16_t>();
+    if ((rc = sgk_qts(smp, view.offsets, view.lengths, j->n_reads, j->max_len, bits, method, st)) != SGK_OK) return rc;
+    if (out_fmt == SGK_SIGNAL_INT16) {
+        if ((rc = d2h(j->h_out[0], j->d_samples, j->n_samples * sizeof(int16_t), st)) != SGK_OK) return rc;
+    } else {
+        // d_out[0] blobs (worst-case sized), d_out[1] blob offsets, d_out[2] total, d_cnt blob lengths
+        const uint32_t *lens = j->h_lengths.as<uint32_t>();
+        size_t bound = 0;
+        for (size_t r = 0; r < nr; ++r) bound += round_up(4 + ((size_t)lens[r] + 3) / 4 + 3 * (size_t)lens[r], 8);
+        if ((rc = j->d_out[0].ensure(bound + 16)) != SGK_OK) return rc;
+        if ((rc = j->d_out[1].ensure(nr * 8)) != SGK_OK) return rc;
+        if ((rc = j->d_out[2].ensure(8)) != SGK_OK) return rc;
+        if ((rc = j->d_cnt.ensure(nr * 4)) != SGK_OK) return rc;
+        if ((rc = sgk_svbzd_size(smp, view.offsets, view.lengths, j->n_reads, j->d_cnt.as<uint32_t>(), st)) != SGK_OK) return rc;
+        hipLaunchKernelGGL(k_blob_layout, dim3(1), dim3(64), 0, st, j->d_cnt.as<uint32_t>(), j->n_reads,
+                           j->d_out[1].as<uint64_t>(), j->d_out[2].as<uint64_t>());
+        SGK_HIP_TRY(hipGetLastError());
+        rc = sgk_svbzd_encode(smp, view.offsets, view.lengths, j->n_reads, j->d_out[0].as<uint8_t>(),
+                              j->d_out[1].as<uint64_t>(), j->d_cnt.as<uint32_t>(), st);
+        if (rc != SGK_OK) return rc;
+        if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = d2h(j->h_out[1], j->d_out[1], nr * 8, st)) != SGK_OK) return rc;
+        if ((rc = d2h(j->h_out[2], j->d_out[2], 8, st)) != SGK_OK) return rc;
+        // the blobs themselves are fetched by sgk_job_wait once their total size is known
+    }
+    j->submitted = true;
+    return SGK_OK;
+}
+
 int sgk_job_wait(sgk_job_t *j) {
     if (!j || !j->submitted) return SGK_ERR_ARG;
     SGK_HIP_TRY(hipSetDevice(j->device));
@@ -332,6 +396,12 @@ int sgk_job_wait(sgk_job_t *j) {
             if (ds[r] != 0) return SGK_ERR_FORMAT;
     }
     if (j->tool == SGK_TOOL_EVENT) return sgk_event_status(j->d_ws.p, &j->ev_status, j->st);
+    if (j->tool == SGK_TOOL_QTS && j->flags == SGK_SIGNAL_SVBZD) {
+        const uint64_t total = j->h_out[2].as<uint64_t>()[0];
+        int rc;
+        if ((rc = d2h(j->h_out[0], j->d_out[0], (size_t)total, j->st)) != SGK_OK) return rc;
+        SGK_HIP_TRY(hipStreamSynchronize(j->st));
+    }
     if (j->tool == SGK_TOOL_ENT) {
         const sgk_ent_hist_t *rec = j->h_out[0].as<sgk_ent_hist_t>();
         j->ent_over = false;
@@ -380,6 +450,15 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
             break;
         case SGK_TOOL_PREFIX:
             out->prefix = j->h_out[0].as<sgk_prefix_rec_t>();
+            break;
+        case SGK_TOOL_QTS:
+            if (j->flags == SGK_SIGNAL_SVBZD) {
+                out->qts_blobs = j->h_out[0].as<uint8_t>();
+                out->qts_blob_offsets = j->h_out[1].as<uint64_t>();
+                out->qts_blob_lengths = j->h_cnt.as<uint32_t>();
+            } else {
+                out->qts_samples = j->h_out[0].as<int16_t>();
+            }
             break;
         case SGK_TOOL_ENT:
             out->ent = j->h_out[0].as<sgk_ent_hist_t>();

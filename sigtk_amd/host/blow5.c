@@ -42,6 +42,7 @@ b5_file_t *b5_open(const char *path) {
     f->hdr_text = (char *)malloc((size_t)hsize + 1);
     if (!f->hdr_text || fread(f->hdr_text, 1, hsize, fp) != hsize) { b5_close(f); return NULL; }
     f->hdr_text[hsize] = '\0';
+    f->hdr_size = hsize;
     f->first_rec = 68 + (uint64_t)hsize;
     if (f->record_press > 1 || f->signal_press > 1) { b5_close(f); return NULL; }
     return f;
@@ -308,6 +309,8 @@ int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t 
     uint16_t idl;
     memcpy(&idl, p, 2);
     if (2 + (uint64_t)idl + 44 > n) return B5_ERR_FORMAT;
+    out->rec = p;
+    out->rec_len = n;
     out->read_id = (const char *)(p + 2);
     out->id_len = idl;
     const uint8_t *q = p + 2 + idl;

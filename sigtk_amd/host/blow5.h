@@ -36,6 +36,7 @@ typedef struct {
     uint8_t signal_press; /* 0 none, 1 svb-zd */
     uint32_t num_read_groups;
     char *hdr_text;       /* header text block */
+    uint32_t hdr_size;    /* its length; the file starts with 68 fixed bytes followed by it */
     uint64_t first_rec;   /* file offset of the first record */
     b5_idx_entry_t *idx;  /* built lazily by b5_index (sorted by id) */
     uint64_t n_idx;
@@ -69,6 +70,8 @@ typedef struct {
     uint16_t id_len;
     uint32_t read_group;
     double digitisation, offset, range, sampling_rate;
+    const uint8_t *rec;    /* the whole (inflated) record and its length: qts rewrites the signal and keeps the rest */
+    uint64_t rec_len;
     const uint8_t *signal; /* svb-zd blob (signal_press 1) or little-endian int16 samples */
     uint64_t signal_bytes;
     uint32_t n_samples;    /* from the blob's count word, or signal_bytes / 2 */

@@ -24,6 +24,7 @@
 #include <sys/time.h>
 
 #include <unistd.h>
+#include <zlib.h>
 
 #include "blow5.h"
 #include "fmt.h"
@@ -49,7 +50,7 @@ typedef struct {
     int8_t rna, compact, p_stat, pore; /* opt_t, src/sigtk.h:115-120 */
 } opt_t;
 
-enum { MODE_EVENT, MODE_STAT, MODE_PREFIX, MODE_JNN, MODE_PA, MODE_ENT };
+enum { MODE_EVENT, MODE_STAT, MODE_PREFIX, MODE_JNN, MODE_PA, MODE_ENT, MODE_QTS };
 
 static double realtime(void) {
     struct timeval tp;
@@ -265,6 +266,9 @@ typedef struct {
     uint64_t limit_bytes;
     char **ids;      /* read-id mode: ids[0..n_ids) */
     int n_ids;
+    /* qts */
+    int q_bits, q_method;
+    FILE *out_fp;    /* rows / records go here (stdout except for qts) */
     double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
     uint64_t n_reads, n_samples;
 } pipe_t;
@@ -355,7 +359,10 @@ static void batch_launch(pipe_t *P, batch_t *b) {
         case MODE_ENT: tool = SGK_TOOL_ENT; break;
         default: break;
     }
-    rc = sgk_job_submit(b->job, tool, P->opt.rna, P->opt.pore, flags);
+    if (P->mode == MODE_QTS)
+        rc = sgk_job_submit_qts(b->job, P->q_bits, P->q_method, P->f->signal_press == 1 ? SGK_SIGNAL_SVBZD : SGK_SIGNAL_INT16);
+    else
+        rc = sgk_job_submit(b->job, tool, P->opt.rna, P->opt.pore, flags);
     if (rc != SGK_OK) gpu_fail("sgk_job_submit", rc);
     P->t_stage += realtime() - t1;
     q_push(&P->ready_q, b);
@@ -525,6 +532,60 @@ static void row_ent(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, ui
     o->n = (size_t)(p - o->p);
 }
 
+/* qts (src/qts.c:118-150): the record as it was read, with the signal replaced by the quantised one (and
+ * len_raw_signal with it); everything else -- id, read group, scaling, auxiliary fields -- is kept byte for byte.
+ * Emitted as the file stores it: u64 size, then the record (one zlib stream when the file compresses records). */
+static __thread uint8_t *qts_tmp;
+static __thread size_t qts_tmp_cap;
+static void row_qts(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r, const b5_file_t *f) {
+    const b5_view_t *v = &b->recs[r].v;
+    const size_t head = (size_t)(v->signal - v->rec) - 8; /* up to the u64 len_raw_signal */
+    const uint8_t *tail = v->signal + v->signal_bytes;
+    const size_t tail_len = (size_t)(v->rec + v->rec_len - tail);
+    const uint8_t *sig;
+    uint64_t sig_bytes, len_field;
+    if (f->signal_press == 1) {
+        sig = out->qts_blobs + out->qts_blob_offsets[r];
+        sig_bytes = out->qts_blob_lengths[r];
+        len_field = sig_bytes;
+    } else {
+        sig = (const uint8_t *)(out->qts_samples + out->offsets[r]);
+        sig_bytes = (uint64_t)b->lengths[r] * 2;
+        len_field = b->lengths[r];
+    }
+    const size_t n = head + 8 + (size_t)sig_bytes + tail_len;
+    if (f->record_press == 1) {
+        if (qts_tmp_cap < n) {
+            qts_tmp = (uint8_t *)realloc(qts_tmp, n + n / 4 + 64);
+            if (!qts_tmp) die_mem();
+            qts_tmp_cap = n + n / 4 + 64;
+        }
+        uint8_t *t = qts_tmp;
+        memcpy(t, v->rec, head);
+        memcpy(t + head, &len_field, 8);
+        memcpy(t + head + 8, sig, (size_t)sig_bytes);
+        memcpy(t + head + 8 + sig_bytes, tail, tail_len);
+        uLongf zlen = compressBound((uLong)n);
+        char *p = sbuf_room(o, 8 + (size_t)zlen);
+        if (compress2((Bytef *)p + 8, &zlen, t, (uLong)n, Z_DEFAULT_COMPRESSION) != Z_OK) {
+            ERROR("qts", "%s", "zlib compression failed");
+            exit(EXIT_FAILURE);
+        }
+        const uint64_t z64 = zlen;
+        memcpy(p, &z64, 8);
+        o->n += 8 + (size_t)zlen;
+    } else {
+        char *p = sbuf_room(o, 8 + n);
+        const uint64_t n64 = n;
+        memcpy(p, &n64, 8);
+        memcpy(p + 8, v->rec, head);
+        memcpy(p + 8 + head, &len_field, 8);
+        memcpy(p + 16 + head, sig, (size_t)sig_bytes);
+        memcpy(p + 16 + head + sig_bytes, tail, tail_len);
+        o->n += 8 + n;
+    }
+}
+
 /* ------------------------------------------------------------------ writer */
 
 typedef struct {
@@ -548,6 +609,7 @@ static void write_chunk(void *ctx_, uint32_t k, int tid) {
             case MODE_STAT: row_stat(o, c->b, &c->out, r); break;
             case MODE_PREFIX: row_prefix(o, c->b, &c->out, r, opt); break;
             case MODE_ENT: row_ent(o, c->b, &c->out, r); break;
+            case MODE_QTS: row_qts(o, c->b, &c->out, r, c->P->f); break;
             default: row_pa(o, c->b, &c->out, r); break;
         }
     }
@@ -598,8 +660,8 @@ static void *writer_main(void *arg) {
         double t2 = realtime();
         P->t_format += t2 - t1;
         for (uint32_t i = 0; i < nchunks; i++)
-            if (chunk[i].n && fwrite(chunk[i].p, 1, chunk[i].n, stdout) != chunk[i].n) {
-                ERROR("writer", "%s", "write to stdout failed");
+            if (chunk[i].n && fwrite(chunk[i].p, 1, chunk[i].n, P->out_fp) != chunk[i].n) {
+                ERROR("writer", "%s", "write to the output failed");
                 exit(EXIT_FAILURE);
             }
         P->t_write += realtime() - t2;
@@ -660,6 +722,53 @@ static void *reader_main(void *arg) {
     b->last = 1;  /* the final (possibly empty) batch ends the stream */
     q_push(&P->filled_q, b);
     return NULL;
+}
+
+/* ------------------------------------------------------------------ the pipeline driver */
+static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
+    q_init(&P->free_q);
+    q_init(&P->filled_q);
+    q_init(&P->ready_q);
+    const int nbatch = n_gpus + 3;  /* one being read, one being inflated/staged, n_gpus in flight, one being written */
+    batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
+    if (!pool) die_mem();
+    const double t_jobs0 = realtime();
+    for (int i = 0; i < nbatch; i++) {
+        const int rc = sgk_job_create(i % n_gpus, &pool[i].job);
+        if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
+        q_push(&P->free_q, &pool[i]);
+    }
+    const double t_jobs = realtime() - t_jobs0;
+    pthread_t wth, rth;
+    if (pthread_create(&wth, NULL, writer_main, P) != 0 || pthread_create(&rth, NULL, reader_main, P) != 0) {
+        ERROR("cmain", "%s", "cannot create the pipeline threads");
+        exit(EXIT_FAILURE);
+    }
+    /* loader: inflate/parse, stage and submit every filled batch */
+    for (;;) {
+        batch_t *b = q_pop(&P->filled_q);
+        const int last = b->last;
+        b->last = 0;
+        if (b->n) batch_launch(P, b);
+        else q_push(&P->free_q, b);
+        if (last) break;
+    }
+    pthread_join(rth, NULL);
+    pool[nbatch].last = 1;
+    q_push(&P->ready_q, &pool[nbatch]);
+    pthread_join(wth, NULL);
+    if (getenv("SGK_CLI_TIMING"))
+        fprintf(stderr,
+                "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
+                "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s | HIP init %.3f s, job create %.3f s\n",
+                (unsigned long)P->n_reads, (unsigned long)P->n_samples, P->nthreads, n_gpus, P->t_read, P->t_parse,
+                P->t_stage, P->t_wait, P->t_format, P->t_write, t_init, t_jobs);
+    for (int i = 0; i < nbatch; i++) {
+        sgk_job_destroy(pool[i].job);
+        for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
+        free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+    }
+    free(pool);
 }
 
 /* ------------------------------------------------------------------ cmain (src/cmain.c:40-156) */
@@ -791,63 +900,132 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     P.nthreads = nthreads;
     P.host_decode = host_decode;
     P.opt = opt;
-    q_init(&P.free_q);
-    q_init(&P.filled_q);
-    q_init(&P.ready_q);
-    const int nbatch = n_gpus + 3;  /* one being read, one being inflated/staged, n_gpus in flight, one being written */
-    batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
-    if (!pool) die_mem();
-    const double t_jobs0 = realtime();
-    for (int i = 0; i < nbatch; i++) {
-        const int rc = sgk_job_create(i % n_gpus, &pool[i].job);
-        if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
-        q_push(&P.free_q, &pool[i]);
-    }
-    const double t_jobs = realtime() - t_jobs0;
-    pthread_t wth;
-    if (pthread_create(&wth, NULL, writer_main, &P) != 0) {
-        ERROR("cmain", "%s", "cannot create the writer thread");
-        exit(EXIT_FAILURE);
-    }
-
-    /* on-disk bytes per sample: ~0.85 (zlib over svb-zd), ~1.3 (svb-zd only), 2 (raw); the batch limit is
-     * applied to the bytes read, which is all the loader knows before the records are inflated */
+    P.out_fp = stdout;
     P.limit_bytes = batch_samples;
     P.ids = argv + optind + 1;
     P.n_ids = argc - optind - 1;
-    pthread_t rth;
-    if (pthread_create(&rth, NULL, reader_main, &P) != 0) {
-        ERROR("cmain", "%s", "cannot create the reader thread");
+    run_pipeline(&P, n_gpus, t_init);
+    fflush(stdout);
+    b5_close(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ qtsmain (src/qts.c:46-165)
+ * Same options as the reference (-o FILE, -b INT in [1,8], -m floor|round|fill-ones).  The output keeps the
+ * input's header block and compression settings verbatim (the reference re-serialises the header through slow5lib
+ * and always writes zlib + svb-zd); records carry the same fields, auxiliary data included, with the quantised
+ * signal -- quantised and re-encoded (svb-zd) on the GPU, deflated on the host thread pool. */
+static struct option qts_long_options[] = {
+    {"verbose", required_argument, 0, 'v'}, {"help", no_argument, 0, 'h'},   {"version", no_argument, 0, 'V'},
+    {"output", required_argument, 0, 'o'},  {"bits", required_argument, 0, 'b'}, {"method", required_argument, 0, 'm'},
+    {"gpus", required_argument, 0, 0},      {"batch-samples", required_argument, 0, 0}, {"threads", required_argument, 0, 't'},
+    {0, 0, 0, 0}};
+
+static int qtsmain(int argc, char *argv[]) {
+    const char *optstring = "hVv:o:b:m:t:";
+    int longindex = 0, c;
+    FILE *fp_help = stderr;
+    char *out_fn = NULL;
+    int b = 1, n_gpus = 1, nthreads = 0;
+    const char *method = "round";
+    uint64_t batch_samples = 64ull << 20;
+    while ((c = getopt_long(argc, argv, optstring, qts_long_options, &longindex)) >= 0) {
+        if (c == 'V') {
+            fprintf(stdout, "sigtk %s\n", SIGTK_VERSION);
+            exit(EXIT_SUCCESS);
+        } else if (c == 'h') {
+            fp_help = stdout;
+        } else if (c == 'o') {
+            out_fn = optarg;
+        } else if (c == 'b') {
+            b = atoi(optarg);
+            if (b < 1 || b > 8) {
+                fprintf(stderr, "Error: number of bits to truncate must be between 1 and 8\n");
+                exit(EXIT_FAILURE);
+            }
+        } else if (c == 'm') {
+            method = optarg;
+        } else if (c == 't') {
+            nthreads = atoi(optarg);
+        } else if (c == 0 && longindex == 6) {
+            n_gpus = atoi(optarg);
+        } else if (c == 0 && longindex == 7) {
+            batch_samples = strtoull(optarg, NULL, 10);
+        }
+    }
+    if (argc - optind != 1 || fp_help == stdout) {
+        fprintf(fp_help, "Usage: sigtk qts a.blow5 -o out.blow5\n");
+        fprintf(fp_help, "\nbasic options:\n");
+        fprintf(fp_help, "   -h                            help\n");
+        fprintf(fp_help, "   -o FILE                       output file\n");
+        fprintf(fp_help, "   --version                     print version\n");
+        fprintf(fp_help, "   -b INT                        number of lower significant bits to eliminate [%d]\n", b);
+        fprintf(fp_help, "   -m [floor|round|fill-ones]    quantisation method [round]\n");
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
+    if (out_fn == NULL) {
+        fprintf(stderr, "Error: output file not specified\n");
         exit(EXIT_FAILURE);
     }
-    for (;;) {
-        batch_t *b = q_pop(&P.filled_q);
-        const int last = b->last;
-        b->last = 0;
-        if (b->n) batch_launch(&P, b);
-        else q_push(&P.free_q, b);
-        if (last) break;
+    int q_method;
+    if (strcmp(method, "floor") == 0) q_method = SGK_QTS_FLOOR;
+    else if (strcmp(method, "round") == 0) q_method = SGK_QTS_ROUND;
+    else if (strcmp(method, "fill-ones") == 0) q_method = SGK_QTS_FILL_ONES;
+    else {
+        fprintf(stderr, "Unknown method for -m. Available options are floor,round,fill-ones.\n");
+        exit(EXIT_FAILURE);
     }
-    pthread_join(rth, NULL);
-    pool[nbatch].last = 1;
-    q_push(&P.ready_q, &pool[nbatch]);
-    pthread_join(wth, NULL);
-    fflush(stdout);
-    if (getenv("SGK_CLI_TIMING"))
-        fprintf(stderr,
-                "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
-                "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s | HIP init %.3f s, job create %.3f s\n",
-                (unsigned long)P.n_reads, (unsigned long)P.n_samples, nthreads, n_gpus, P.t_read, P.t_parse, P.t_stage,
-                P.t_wait, P.t_format, P.t_write, t_init, t_jobs);
-    const double t_end0 = realtime();
-    for (int i = 0; i < nbatch; i++) {
-        sgk_job_destroy(pool[i].job);
-        for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
-        free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+    b5_file_t *f = b5_open(argv[optind]);
+    if (!f) {
+        fprintf(stderr, "Error in opening file\n");
+        exit(EXIT_FAILURE);
     }
-    free(pool);
+    FILE *out = fopen(out_fn, "wb");
+    if (!out) {
+        fprintf(stderr, "Error opening file!\n");
+        exit(EXIT_FAILURE);
+    }
+    /* header block: the fixed 68 bytes and the header text, as they are */
+    {
+        const size_t hb = 68 + (size_t)f->hdr_size;
+        uint8_t *h = (uint8_t *)malloc(hb);
+        if (!h) die_mem();
+        if (fseek(f->fp, 0, SEEK_SET) != 0 || fread(h, 1, hb, f->fp) != hb || fwrite(h, 1, hb, out) != hb ||
+            fseek(f->fp, (long)f->first_rec, SEEK_SET) != 0) {
+            fprintf(stderr, "Error writing header!\n");
+            exit(EXIT_FAILURE);
+        }
+        free(h);
+    }
+    const double t_init0 = realtime();
+    const int ndev = sgk_device_count();
+    const double t_init = realtime() - t_init0;
+    if (ndev <= 0) {
+        ERROR("qtsmain", "%s", "no usable GPU: sigtk-amd has no CPU compute path");
+        exit(EXIT_FAILURE);
+    }
+    if (n_gpus < 1) n_gpus = 1;
+    if (n_gpus > ndev) n_gpus = ndev;
+    if (nthreads <= 0) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        nthreads = nc > 1 ? (int)(nc / 2) : 1;
+        if (nthreads > 64) nthreads = 64;
+    }
+    pipe_t P;
+    memset(&P, 0, sizeof P);
+    P.f = f;
+    P.mode = MODE_QTS;
+    P.nthreads = nthreads;
+    P.q_bits = b;
+    P.q_method = q_method;
+    P.out_fp = out;
+    P.limit_bytes = batch_samples;
+    run_pipeline(&P, n_gpus, t_init);
+    if (fwrite("5WOLB", 1, 5, out) != 5 || fclose(out) != 0) {
+        fprintf(stderr, "Error writing record!\n");
+        exit(EXIT_FAILURE);
+    }
     b5_close(f);
-    if (getenv("SGK_CLI_TIMING")) fprintf(stderr, "[sigtk-amd] teardown %.3f s\n", realtime() - t_end0);
     return 0;
 }
 
@@ -961,7 +1139,8 @@ static void print_usage(FILE *fp) {
     fprintf(fp, "         prefix    prefix segments such as adaptor and polyA\n");
     fprintf(fp, "         jnn       print segments found using JNN segmenter\n");
     fprintf(fp, "         ent       calculate entropies\n");
-    fprintf(fp, "\n(sigtk-amd: the per-read raw-signal subtools on MI355X; sref/ss/qts are not part of it)\n");
+    fprintf(fp, "         qts       quantise the raw signal in a S/BLOW5 files\n");
+    fprintf(fp, "\n(sigtk-amd: the per-read raw-signal subtools on MI355X; sref/ss are not part of it)\n");
     exit(fp == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
 }
 
@@ -973,6 +1152,8 @@ int main(int argc, char *argv[]) {
     } else if (strcmp(argv[1], "event") == 0 || strcmp(argv[1], "stat") == 0 || strcmp(argv[1], "prefix") == 0 ||
                strcmp(argv[1], "pa") == 0 || strcmp(argv[1], "jnn") == 0 || strcmp(argv[1], "ent") == 0) {
         ret = cmain(argc - 1, argv + 1, argv[1]);
+    } else if (strcmp(argv[1], "qts") == 0) {
+        ret = qtsmain(argc - 1, argv + 1);
     } else if (strcmp(argv[1], "_dump") == 0) {
         return dumpmain(argc - 1, argv + 1);
     } else if (strcmp(argv[1], "_fmtcheck") == 0) {

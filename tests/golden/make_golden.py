@@ -73,6 +73,11 @@ def main():
         save("sp1_dna.ent.tsv", ref(tmp, "ent", sp1))
         # long-form event output of the whole file is ~6.5 MB: keep its hash only
         manifest["sp1_dna.event.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", sp1)).hexdigest()
+        # qts writes a BLOW5: keep a digest of what a reader sees in the reference's output (ids, scaling, signal)
+        for bits, method in ((1, "round"), (3, "round"), (2, "floor"), (4, "fill-ones")):
+            outp = os.path.join(tmp, "q.blow5")
+            ref(tmp, "qts", sp1, "-o", outp, "-b", str(bits), "-m", method)
+            manifest["sp1_dna.qts_b%d_%s.sha256" % (bits, method)] = blow5.digest(outp)
         for name, spec in SYNTH.items():
             f = os.path.join(tmp, name + ".blow5")
             write_synth_blow5(f, spec)

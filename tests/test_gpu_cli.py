@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from sigtk_amd import api, blow5, build
@@ -119,6 +120,46 @@ def test_corrupt_signal_blob_fails_like_a_read_error(cli, tmp_path, sp1):
     open(path, "wb").write(bytes(data))
     p = subprocess.run([cli, "stat", path], capture_output=True)
     assert p.returncode != 0
+
+
+@pytest.mark.parametrize("bits,method", [(1, "round"), (3, "round"), (2, "floor"), (4, "fill-ones")])
+def test_qts_output_reads_back_like_the_references(cli, tmp_path, bits, method):
+    """`qts` (src/qts.c): what a reader sees in our output file equals what it sees in the file the reference wrote
+    (digest of ids, scaling and quantised samples, from make_golden.py); everything but the signal -- auxiliary
+    fields included -- is kept byte for byte, and the header block is the input's."""
+    import struct
+    outp = str(tmp_path / "q.blow5")
+    p = subprocess.run([cli, "qts", SP1, "-o", outp, "-b", str(bits), "-m", method, "--batch-samples", "150000"],
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert blow5.digest(outp) == MANIFEST["sp1_dna.qts_b%d_%s.sha256" % (bits, method)]
+    src, dst = open(SP1, "rb").read(), open(outp, "rb").read()
+    (hsize,) = struct.unpack_from("<I", src, 64)
+    assert dst[: 68 + hsize] == src[: 68 + hsize] and dst[-5:] == b"5WOLB"
+    for a, b in zip(blow5.raw_records(SP1), blow5.raw_records(outp)):
+        (idl,) = struct.unpack_from("<H", a, 0)
+        sig = 2 + idl + 36          # offset of len_raw_signal
+        (la,) = struct.unpack_from("<Q", a, sig)
+        (lb,) = struct.unpack_from("<Q", b, sig)
+        assert a[:sig] == b[:sig]                                   # id, read group, scaling, sampling rate
+        assert a[sig + 8 + la:] == b[sig + 8 + lb:] and len(a[sig + 8 + la:]) > 0   # auxiliary fields
+
+
+def test_qts_other_layouts_and_errors(cli, tmp_path, sp1):
+    recs = sp1.reads[:7]
+    for rp, sp in ((0, 0), (1, 0), (0, 1)):
+        inp, outp = str(tmp_path / "i.blow5"), str(tmp_path / "o.blow5")
+        blow5.write_blow5(inp, recs, {"experiment_type": "genomic_dna", "sequencing_kit": "sqk-lsk109"}, rp, sp)
+        assert subprocess.run([cli, "qts", inp, "-o", outp, "-b", "2"], capture_output=True).returncode == 0
+        got = blow5.read_blow5(outp)
+        assert (got.record_press, got.signal_press) == (rp, sp)
+        for g, r in zip(got.reads, recs):
+            x = r.raw.astype(np.int64)
+            e = np.where((x & 3) < 2, x & ~3, (x & ~3) + 4).astype(np.int16)
+            assert g.read_id == r.read_id and np.array_equal(g.raw, e)
+    assert subprocess.run([cli, "qts", SP1], capture_output=True).returncode != 0                      # no -o
+    assert subprocess.run([cli, "qts", SP1, "-o", str(tmp_path / "x"), "-b", "9"], capture_output=True).returncode != 0
+    assert subprocess.run([cli, "qts", SP1, "-o", str(tmp_path / "x"), "-m", "nearest"], capture_output=True).returncode != 0
 
 
 def test_more_gpus_requested_than_present(cli):

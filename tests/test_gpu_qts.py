@@ -76,3 +76,23 @@ def test_quantisers_match_qts_c(gpu, method, name, bits):
         o = int(b.offsets_host[r])
         assert np.array_equal(host[o:o + a.size], e), (name, bits, r)
     assert host[0] == 12345        # nothing outside the reads was touched
+
+
+@pytest.mark.parametrize("svb_in,svb_out", [(False, True), (True, True), (True, False)])
+def test_qts_through_a_job(gpu, svb_in, svb_out):
+    """sgk_job_submit_qts: (decode ->) quantise -> (encode) with the blobs laid out on the device"""
+    lens = [0, 1, 5, 4096, 30001, 100000]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=41, kind=0)
+    job = gpu.Job(0)
+    job.stage([blow5.svb_zd_encode(r) for r in reads] if svb_in else reads, dig, off, rng,
+              counts=[r.size for r in reads] if svb_in else None)
+    job.launch_qts(3, 1, svb_out)
+    res = job.wait()
+    for r, raw in enumerate(reads):
+        x = raw.astype(np.int64)
+        e = np.where((x & 7) < 4, x & ~7, (x & ~7) + 8).astype(np.int16)
+        if svb_out:
+            assert res["blobs"][r] == blow5.svb_zd_encode(e), "read %d" % r
+        else:
+            assert np.array_equal(res["samples"][r], e)
+    job.close()
