@@ -48,5 +48,27 @@ def main():
                       "hbm_frac": round(byts / ms / 1e6 / 8000.0, 4)}))
 
 
+    # ---- the encoder on the decoded samples (size pass + encode pass)
+    blens_out = torch.zeros(n, dtype=torch.int32, device=dev)
+    enc_blobs = torch.zeros(int(boffs[-1] + blens[-1]) + 64, dtype=torch.uint8, device=dev)
+
+    def run_enc():
+        api.check(L.sgk_svbzd_size(out.samples.data_ptr(), out.offsets.data_ptr(), out.lengths.data_ptr(), n,
+                                   blens_out.data_ptr(), stream))
+        api.check(L.sgk_svbzd_encode(out.samples.data_ptr(), out.offsets.data_ptr(), out.lengths.data_ptr(), n,
+                                     enc_blobs.data_ptr(), d_boffs.data_ptr(), blens_out.data_ptr(), stream))
+    run_enc(); torch.cuda.synchronize()
+    assert torch.equal(blens_out, d_blens)
+    o5 = int(boffs[5]); assert enc_blobs[o5:o5 + len(blobs[5])].cpu().numpy().tobytes() == blobs[5]
+    L.sgk_profile_reset(); L.sgk_profile_enable(1)
+    for _ in range(5): run_enc()
+    torch.cuda.synchronize(); L.sgk_profile_enable(0)
+    pr = {k: v[0] / v[1] for k, v in api.profile_read().items()}
+    ms_e = pr["k_svbzd_size"] + pr["k_svbzd_encode"]
+    print(json.dumps({"kernel": "k_svbzd_size + k_svbzd_encode", "reads": n, "samples": S, "ms": round(ms_e, 4),
+                      "kernels_ms": {k: round(v, 4) for k, v in pr.items()}, "samples_per_s": round(S / ms_e * 1e3, 1),
+                      "GBps": round(byts / ms_e / 1e6, 1), "hbm_frac": round(byts / ms_e / 1e6 / 8000.0, 4)}))
+
+
 if __name__ == "__main__":
     main()
