@@ -54,6 +54,14 @@ def main():
             out[name] = {"identical": g.stdout == r.stdout and g.returncode == 0, "sigtk_amd_s": round(tg, 3),
                          "reference_s": round(tr, 3), "stdout_mb": round(len(r.stdout) / 1e6, 1),
                          "stages": stages[0] if stages else None}
+        if not a.no_ref:
+            # qts writes a file: compare what a reader sees in the two outputs
+            og, orf = os.path.join(tmp, "g.blow5"), os.path.join(tmp, "r.blow5")
+            t0 = time.perf_counter(); g = subprocess.run([build.CLI, "qts", f, "-o", og, "-b", "2"], capture_output=True); tg = time.perf_counter() - t0
+            t0 = time.perf_counter(); r = subprocess.run([REF_BIN, "qts", f, "-o", orf, "-b", "2"], capture_output=True, cwd=tmp); tr = time.perf_counter() - t0
+            out["qts -b 2"] = {"identical": g.returncode == 0 and r.returncode == 0 and blow5.digest(og) == blow5.digest(orf),
+                               "sigtk_amd_s": round(tg, 3), "reference_s": round(tr, 3),
+                               "out_mb": round(os.path.getsize(og) / 1e6, 1), "ref_out_mb": round(os.path.getsize(orf) / 1e6, 1)}
         print(json.dumps(out))
 
 
