@@ -121,6 +121,19 @@ def main():
                 fail("%s pa read %d" % (tag, r))
             if raw.size and not np.array_equal(ent[r].view(np.uint64), orc.ent(raw).view(np.uint64)):
                 fail("%s ent read %d" % (tag, r))
+        bits = int(rs.randint(1, 9)); method = int(rs.randint(0, 3)); svb_out = bool(rs.randint(0, 2))
+        job.launch_qts(bits, method, svb_out)
+        q = job.wait()
+        for r, raw in enumerate(reads):
+            x = raw.astype(np.int64)
+            mask = (1 << bits) - 1
+            if method == 0: e = (x >> bits) << bits
+            elif method == 2: e = x | mask
+            else: e = np.where((x & mask) < (1 << (bits - 1)), x & ~mask, (x & ~mask) + (1 << bits))
+            e = e.astype(np.int16)
+            good = (q["blobs"][r] == blow5.svb_zd_encode(e)) if svb_out else np.array_equal(q["samples"][r], e)
+            if not good:
+                fail("%s qts read %d bits %d method %d svb_out %d" % (tag, r, bits, method, svb_out))
         stats["batches"] += 1
         stats["reads"] += nr
         stats["samples"] += int(sum(lens))
