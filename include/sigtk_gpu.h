@@ -16,12 +16,18 @@
  *   find_adaptor/jnnv2   src/jnn.c:99,181         sgk_prefix
  *   find_polya/jnn_pa    src/jnn.c:295,352        sgk_prefix
  *   prefix_func compute  src/cfunc.c:169-216      sgk_prefix
+ *   entropy (ent)        src/ent.c:25-50,107-164  sgk_ent + sgk_ent_finish
+ *   qts quantisers       src/qts.c:27-43,126-142  sgk_qts
+ *   svb-zd decode/encode slow5_press.c:1063-1146  sgk_svbzd_decode / sgk_svbzd_size + sgk_svbzd_encode
+ *   the record loop      src/cmain.c:118-120      sgk_job_* (pipelined batches: staging, stream, results)
  *
  * Conventions
  *   - Plain C: pointers and sizes only.  No exceptions, no exit(): every function returns
  *     SGK_OK (0) or a negative sgk error code; sgk_strerror() names it.
  *   - "Device API" functions take DEVICE pointers and a hipStream_t passed as void*
  *     (NULL = default stream) and only enqueue work; nothing is synchronised.
+ *   - "Jobs" (sgk_job_*) are the throughput path for host callers: pinned staging the caller fills, asynchronous
+ *     upload / kernels / download on a private stream, results in pinned buffers; several can be in flight.
  *   - "Host API" functions (suffix _host and the per-read shims) take HOST pointers,
  *     stage through the GPU and synchronise before returning.  Results they allocate are
  *     released with the matching *_free function.
@@ -37,8 +43,8 @@
  *            which lets a packer start every read on an aligned boundary.  Any offsets are
  *            accepted; reads starting on a multiple of 8 samples (16 bytes) take the
  *            vectorised load paths (the host packer aligns to 64 samples = 128 bytes).  The
- *            event fast path additionally wants >= 64 readable samples in front of a read and
- *            >= 16 behind it (neighbouring reads or padding); reads without that room, or
+ *            event fast path additionally wants >= 64 (DNA) / 256 (RNA parameters) readable samples in front of
+ *            a read and >= 16 behind it (neighbouring reads or padding, any content); reads without that room, or
  *            starting on an odd sample, are processed by the slower exact fallback kernel;
  *   digitisation/offset/range  the three per-read doubles of slow5_rec_t
  *            (slow5lib/include/slow5/slow5_defs.h:84-92), narrowed to float on the device
