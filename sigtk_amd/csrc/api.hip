@@ -339,14 +339,15 @@ static int event_collect(const void *d_samples, bool float_input, const DeviceBa
     out->mean = (float *)malloc((tot ? tot : 1) * 4);
     out->stdv = (float *)malloc((tot ? tot : 1) * 4);
     if (!out->start || !out->length || !out->mean || !out->stdv) return SGK_ERR_NOMEM;
-    for (uint32_t r = 0; r < nr; ++r) {
-        const size_t k = nev[r];
-        if (!k) continue;
-        const uint64_t o = out->ev_offsets[r], s = slots[r];
-        SGK_HIP_TRY(hipMemcpy(out->start + o, d_start.as<uint32_t>() + s, k * 4, hipMemcpyDeviceToHost));
-        SGK_HIP_TRY(hipMemcpy(out->length + o, d_len.as<uint32_t>() + s, k * 4, hipMemcpyDeviceToHost));
-        SGK_HIP_TRY(hipMemcpy(out->mean + o, d_mean.as<float>() + s, k * 4, hipMemcpyDeviceToHost));
-        SGK_HIP_TRY(hipMemcpy(out->stdv + o, d_sd.as<float>() + s, k * 4, hipMemcpyDeviceToHost));
+    // one bulk copy per array (capacity layout), compacted on the host
+    std::vector<uint32_t> tmp((size_t)nslots ? (size_t)nslots : 1);
+    void *dev[4] = {d_start.p, d_len.p, d_mean.p, d_sd.p};
+    void *dst[4] = {out->start, out->length, out->mean, out->stdv};
+    for (int a = 0; a < 4; ++a) {
+        SGK_HIP_TRY(hipMemcpy(tmp.data(), dev[a], (size_t)nslots * 4, hipMemcpyDeviceToHost));
+        uint32_t *o = static_cast<uint32_t *>(dst[a]);
+        for (uint32_t r = 0; r < nr; ++r)
+            if (nev[r]) memcpy(o + out->ev_offsets[r], tmp.data() + slots[r], (size_t)nev[r] * 4);
     }
     return SGK_OK;
 }

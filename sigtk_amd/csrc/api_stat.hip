@@ -145,12 +145,14 @@ int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
     out->x = (int32_t *)malloc((tot ? tot : 1) * 4);
     out->y = (int32_t *)malloc((tot ? tot : 1) * 4);
     if (!out->x || !out->y) return SGK_ERR_NOMEM;
-    for (uint32_t r = 0; r < nr; ++r) {
-        if (!ns[r]) continue;
-        SGK_HIP_TRY(hipMemcpy(out->x + out->seg_offsets[r], d_x.as<int32_t>() + slots[r], (size_t)ns[r] * 4,
-                              hipMemcpyDeviceToHost));
-        SGK_HIP_TRY(hipMemcpy(out->y + out->seg_offsets[r], d_y.as<int32_t>() + slots[r], (size_t)ns[r] * 4,
-                              hipMemcpyDeviceToHost));
+    // one bulk copy per array (capacity layout), compacted on the host
+    const size_t nslots = (size_t)slots[nr];
+    std::vector<int32_t> tmp(nslots ? nslots : 1);
+    for (int a = 0; a < 2; ++a) {
+        SGK_HIP_TRY(hipMemcpy(tmp.data(), a ? d_y.p : d_x.p, nslots * 4, hipMemcpyDeviceToHost));
+        int32_t *o = a ? out->y : out->x;
+        for (uint32_t r = 0; r < nr; ++r)
+            if (ns[r]) memcpy(o + out->seg_offsets[r], tmp.data() + slots[r], (size_t)ns[r] * 4);
     }
     return SGK_OK;
 }
