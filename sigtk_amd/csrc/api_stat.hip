@@ -146,10 +146,9 @@ int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
     out->y = (int32_t *)malloc((tot ? tot : 1) * 4);
     if (!out->x || !out->y) return SGK_ERR_NOMEM;
     // one bulk copy per array (capacity layout), compacted on the host
-    const size_t nslots = (size_t)slots[nr];
-    std::vector<int32_t> tmp(nslots ? nslots : 1);
+    std::vector<int32_t> tmp(nslots ? (size_t)nslots : 1);
     for (int a = 0; a < 2; ++a) {
-        SGK_HIP_TRY(hipMemcpy(tmp.data(), a ? d_y.p : d_x.p, nslots * 4, hipMemcpyDeviceToHost));
+        SGK_HIP_TRY(hipMemcpy(tmp.data(), a ? d_y.p : d_x.p, (size_t)nslots * 4, hipMemcpyDeviceToHost));
         int32_t *o = a ? out->y : out->x;
         for (uint32_t r = 0; r < nr; ++r)
             if (ns[r]) memcpy(o + out->seg_offsets[r], tmp.data() + slots[r], (size_t)ns[r] * 4);
