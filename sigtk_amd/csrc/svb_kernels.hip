@@ -56,9 +56,13 @@ __global__ __launch_bounds__(64) void k_svbzd_decode(SvbArgs a) {
         uint32_t kw = 0;
         if (vl < count) {
             const uint32_t kb = vl / 4;  // key byte index (vl is a multiple of 16)
+            if (kb + 4 <= nkeys && (reinterpret_cast<uintptr_t>(keys + kb) & 3u) == 0) {
+                kw = *reinterpret_cast<const uint32_t *>(keys + kb);  // the lane's four key bytes in one load
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (kb + j < nkeys) kw |= (uint32_t)keys[kb + j] << (8 * j);
+                for (int j = 0; j < 4; ++j)
+                    if (kb + j < nkeys) kw |= (uint32_t)keys[kb + j] << (8 * j);
+            }
         }
         const int nval = vl >= count ? 0 : (count - vl >= SVB_VPL ? SVB_VPL : (int)(count - vl));
         // byte count of this lane: nval + sum of its codes
@@ -91,10 +95,10 @@ __global__ __launch_bounds__(64) void k_svbzd_decode(SvbArgs a) {
             const int len = (int)((kw >> (2 * k)) & 3u) + 1;
             uint32_t v = 0;
             if (k < nval) {
-                v = (uint32_t)stage[pos];
-                if (len > 1) v |= (uint32_t)stage[pos + 1] << 8;
-                if (len > 2) v |= (uint32_t)stage[pos + 2] << 16;
-                if (len > 3) v |= (uint32_t)stage[pos + 3] << 24;
+                // the 4 bytes at stage[pos] through two aligned dword reads and a byte-granular funnel shift
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(stage) + (pos >> 2);
+                const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], (uint32_t)(pos & 3));
+                v = w & (0xffffffffu >> (32 - 8 * len));
                 pos += len;
             }
             const int32_t delta = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
