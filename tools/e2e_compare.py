@@ -40,7 +40,8 @@ def main():
         blow5.write_blow5(f, recs, attrs)
         out = {"reads": a.reads, "samples": int(sum(len(r) for r in reads)), "file_mb": round(os.path.getsize(f) / 1e6, 1)}
         tools = (["event", "-c"], ["stat"], ["jnn"]) if a.no_ref else \
-            (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["ent"])
+            (["event", "-c"], ["event"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["ent"]) + \
+            ((["pa"],) if a.reads <= 1000 else ())   # pa prints ~10 bytes per sample
         for tool in tools:
             name = " ".join(tool)
             env = dict(os.environ, SGK_CLI_TIMING="1")
