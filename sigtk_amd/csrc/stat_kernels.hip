@@ -394,12 +394,14 @@ struct JnnAuto {
     int window, error, seg_dist;
     int hi_i, lo_i;  // integer form of the thresholds for integer-valued samples: in  <=>  lo_i < iv < hi_i
     int first_min_i; // (float)c >= first_min  <=>  c >= first_min_i
+    int keep_min;    // an ended segment is kept iff c >= keep_min
     int open_m;      // -1 while a segment is open, else 0 (all predicates are kept as 0 / -1 lane masks)
     int err, run_err, c, w, start, nseg, last_x, last_y;
     __device__ void init(float top_, float bot_, int corrector, int seg_dist_, int window_, float stall_len, int error_) {
         top = top_; bot = bot_; window = window_; error = error_; seg_dist = seg_dist_;
         first_min = (float)window_ * stall_len;
         first_min_i = (int)ceilf(first_min);
+        keep_min = first_min_i < window_ ? first_min_i : window_;  // c >= window || (nseg == 0 && c >= first_min_i)
         // v < top <=> iv < ceil(top), v > bot <=> iv > floor(bot) for an integer iv in [0, 1200]; NaN thresholds
         // compare false with everything
         hi_i = (top_ != top_) ? -0x40000000 : (top_ > 4000.0f ? 4000 : (top_ < -4.0f ? -4 : (int)ceilf(top_)));
@@ -430,13 +432,12 @@ struct JnnAuto {
         run_err = (run_err - tol) & ~in;
         // "if (c >= window && c >= w && c % w == 0) err--" (jnn.c:228, 238): c >= w needs more tolerated
         // samples in the segment than in-range samples before it
-        const int fix = cnt & ((window - 1 - c1) >> 31) & ((w1 - 1 - c1) >> 31);
-        // a segment that ends is kept if it is long enough (jnn.c:243-262), otherwise it is just dropped; with
-        // thresholds at mean +- 0.75 std short runs are dropped every few samples, so dropping must not branch
-        const int first = (nseg - 1) >> 31;              // no segment yet
-        const int keep = rest & (((window - 1 - c) >> 31) | (first & ((first_min_i - 1 - c) >> 31)));
+        // cheap necessary conditions, evaluated on every sample: c1 >= w1 for the correction, and for keeping an
+        // ended segment c >= keep_min (= window, or min(window, first_min_i) while no segment has been kept yet)
+        const int fix = cnt & ((w1 - 1 - c1) >> 31);
+        const int keep = rest & ((keep_min - 1 - c) >> 31);
         if (__any((fix | keep) != 0)) {
-            if (fix) {
+            if (fix && c1 >= window) {
                 if ((c1 % w1) == 0) --err1;
             }
             if (keep) {
@@ -448,6 +449,7 @@ struct JnnAuto {
                     last_x = start; last_y = end;
                     ++nseg;
                 }
+                keep_min = window;  // "first segment" rule (jnn.c:243) no longer applies
             }
         }
         open_m = (open_m | in) & ~rest;
