@@ -36,8 +36,12 @@ def main():
 
     while time.time() < t_end and len(stats["mismatches"]) < 5:
         kind = int(rs.randint(0, 2))
-        nr = int(rs.randint(1, 24))
-        lens = [int(x) for x in np.exp(rs.uniform(np.log(1), np.log(200000), size=nr)).astype(np.int64)]
+        if rs.rand() < 0.1:   # many tiny reads: slot / offset arithmetic, reads shorter than every window
+            nr = int(rs.randint(200, 2000))
+            lens = [int(x) for x in rs.randint(0, 500, size=nr)]
+        else:
+            nr = int(rs.randint(1, 24))
+            lens = [int(x) for x in np.exp(rs.uniform(np.log(1), np.log(200000), size=nr)).astype(np.int64)]
         seed = int(rs.randint(0, 1 << 30))
         reads, dig, off, rng = api.synth_reads_host(nr, lens, seed, kind)
         dig = np.asarray(dig, dtype=np.float64).copy(); off = np.asarray(off, dtype=np.float64).copy()
