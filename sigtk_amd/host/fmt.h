@@ -8,8 +8,9 @@
  *   significant bits, and 10^6 = 15625 * 2^6, so frac * 10^6 is a product of a 24-bit and a 14-bit
  *   integer times a power of two: EXACT in double.  rint() of it (round-half-even) is therefore the
  *   correctly rounded 6-decimal fraction; a carry into ip when it reaches 10^6.
- * Anything outside |v| < 1e15 (incl. inf/nan) goes through snprintf.  `sigtk-amd _fmtcheck` checks the
- * routine against snprintf on every float bit pattern of a stride and on edge cases (tests/test_cli_cpu.py).
+ * Anything outside |v| < 1e15 (incl. inf/nan) goes through snprintf.  `sigtk-amd _fmtcheck stride [first last]`
+ * checks the routine against snprintf; it has been run over ALL 2^32 float bit patterns (stride 1, eight ranges in
+ * parallel, 0 mismatches), and a strided run plus the tie/carry cases is part of tests/test_cli_cpu.py.
  */
 #ifndef SGK_FMT_H
 #define SGK_FMT_H

@@ -1092,10 +1092,12 @@ static int dumpmain(int argc, char *argv[]) {
 
 /* hidden helper for tests: fmt_f6 / fmt_i64 against snprintf on every stride-th float bit pattern */
 static int fmtcheckmain(int argc, char *argv[]) {
+    /* _fmtcheck [stride [first last]]: every stride-th float bit pattern in [first, last] (defaults: all) */
     const uint32_t stride = argc > 1 ? (uint32_t)strtoul(argv[1], NULL, 10) : 9973u;
+    const uint64_t first = argc > 3 ? strtoull(argv[2], NULL, 0) : 0, last = argc > 3 ? strtoull(argv[3], NULL, 0) : 0xffffffffull;
     uint64_t bad = 0, n = 0;
     char a[512], b[512];
-    for (uint64_t u = 0; u <= 0xffffffffull; u += stride ? stride : 1) {
+    for (uint64_t u = first; u <= last; u += stride ? stride : 1) {
         const uint32_t w = (uint32_t)u;
         float f;
         memcpy(&f, &w, 4);
