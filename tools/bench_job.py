@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reads", type=int, default=2000)
     ap.add_argument("--read-len", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--jobs", type=int, default=3, help="jobs kept in flight for the overlapped measurement")
     a = ap.parse_args()
     import torch  # noqa: F401  (HIP runtime order, see tests/conftest.py)
     torch.cuda.init()
@@ -45,7 +46,30 @@ def main():
             dt = min(ts)
             out["%s / %s" % (fmt, name)] = {"submit_to_done_ms": round(dt * 1e3, 2), "samples_per_s": round(S / dt, 1),
                                             "input_MB": round(in_bytes / 1e6, 1)}
-        job.close()
+        # several jobs in flight on their own streams: transfers of one overlap the kernels / transfers of the others
+        jobs = [job] + [api.Job(0) for _ in range(a.jobs - 1)]
+        for j in jobs[1:]:
+            j.stage(sig, dig, off, rng, counts)
+        for flags, name in ((api.JOB_EVENTS_COMPACT, "event -c"),):
+            for j in jobs:
+                j.launch(api.TOOL_EVENT, flags=flags)
+            for j in jobs:
+                api.check(L.sgk_job_wait(j.h))
+            rounds = 4
+            t0 = time.perf_counter()
+            for j in jobs:
+                j.launch(api.TOOL_EVENT, flags=flags)
+            for _ in range(rounds - 1):
+                for j in jobs:
+                    api.check(L.sgk_job_wait(j.h))
+                    j.launch(api.TOOL_EVENT, flags=flags)
+            for j in jobs:
+                api.check(L.sgk_job_wait(j.h))
+            dt = time.perf_counter() - t0
+            out["%s / %s, %d jobs in flight" % (fmt, name, a.jobs)] = {
+                "samples_per_s": round(S * rounds * len(jobs) / dt, 1), "ms_per_job": round(dt / (rounds * len(jobs)) * 1e3, 2)}
+        for j in jobs:
+            j.close()
     print(json.dumps({"reads": a.reads, "samples": S, "results": out}))
 
 
