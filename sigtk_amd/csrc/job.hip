@@ -84,7 +84,9 @@ struct sgk_job {
     GrowDev d_samples, d_blobs, d_offsets, d_lengths, d_boffs, d_blens, d_dig, d_off, d_rng, d_slots, d_ws, d_dstat;
     // outputs: four generic arrays (start/length/mean/stdv | seg x/y | pa | records) + per-read counts
     GrowDev d_out[4], d_cnt;
-    GrowPin h_out[4], h_cnt, h_dstat;
+    GrowDev d_dense[4], d_doffs;      // event / jnn: items gathered to dense per-read ranges before the download
+    GrowPin h_out[4], h_cnt, h_dstat, h_doffs, h_err;
+    int n_dense = 0;                  // arrays to fetch in sgk_job_wait once the dense total is known
     size_t ws_bytes = 0;
     int tool = -1, flags = 0;
     bool begun = false, submitted = false, ent_over = false;
@@ -236,15 +238,54 @@ static int job_upload(sgk_job_t *j, sgk_batch_t *view) {
     return SGK_OK;
 }
 
-// blob r of the qts output starts at the 8-byte aligned running sum of the lengths; total[0] = arena bytes used
-__global__ void k_blob_layout(const uint32_t *lens, uint32_t n, uint64_t *offs, uint64_t *total) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t o = 0;
-    for (uint32_t r = 0; r < n; ++r) {
-        offs[r] = o;
-        o += ((uint64_t)lens[r] + 7u) & ~7ull;
+// offs[r] = running sum of counts[0..r) with every count rounded up to `align` (a power of two); offs[n] = total.
+// One 1024-thread workgroup: a contiguous slice of reads per thread, block scan of the slice sums in LDS.
+// With `slots` (capacity arena, n+1 entries) a count is first clamped to its read's capacity.
+__device__ inline uint64_t layout_item(const uint32_t *counts, const uint64_t *slots, uint32_t r, uint64_t m) {
+    uint64_t c = counts[r];
+    if (slots) {
+        const uint64_t cap = slots[r + 1] - slots[r];
+        c = c < cap ? c : cap;
     }
-    total[0] = o;
+    return (c + m) & ~m;
+}
+__global__ __launch_bounds__(1024) void k_layout(const uint32_t *counts, const uint64_t *slots, uint32_t n, uint32_t align,
+                                                 uint64_t *offs) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    const uint64_t m = (uint64_t)align - 1;
+    uint64_t sum = 0;
+    for (uint32_t r = lo; r < hi; ++r) sum += layout_item(counts, slots, r, m);
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t o = part[t] - sum;
+    for (uint32_t r = lo; r < hi; ++r) {
+        offs[r] = o;
+        o += layout_item(counts, slots, r, m);
+    }
+    if (t == 1023) offs[n] = part[1023];
+}
+
+// items of read r: src[k][slots[r] .. +counts[r]) -> dst[k][doffs[r] ..), k < narr (4-byte items)
+struct GatherArgs {
+    const uint32_t *src[4];
+    uint32_t *dst[4];
+};
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, int narr, const uint64_t *slots, const uint32_t *counts,
+                                                const uint64_t *doffs) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t s = slots[r], d = doffs[r], cap = slots[r + 1] - s;
+    const uint32_t c = counts[r] < cap ? counts[r] : (uint32_t)cap;  // an overflowing read keeps what fitted
+    for (int k = 0; k < narr; ++k)
+        for (uint32_t i = threadIdx.x; i < c; i += 256) g.dst[k][d + i] = g.src[k][s + i];
 }
 
 int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
@@ -300,9 +341,29 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
                              j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
             if (rc != SGK_OK) return rc;
             if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
+            // the arena is capacity-sized (n/3+2 slots per read): gather what was produced into dense ranges on the
+            // device and download only that (sgk_job_wait fetches the arrays once the total is known)
             const int ncopy = (ev && (flags & SGK_JOB_EVENTS_COMPACT)) ? 2 : narr;
-            for (int k = 0; k < ncopy; ++k)
-                if ((rc = d2h(j->h_out[k], j->d_out[k], s * 4, st)) != SGK_OK) return rc;
+            if ((rc = j->d_doffs.ensure((nr + 1) * 8)) != SGK_OK) return rc;
+            hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, j->d_cnt.as<uint32_t>(), j->d_slots.as<uint64_t>(),
+                               j->n_reads, 1u, j->d_doffs.as<uint64_t>());
+            SGK_HIP_TRY(hipGetLastError());
+            GatherArgs g;
+            for (int k = 0; k < 4; ++k) { g.src[k] = nullptr; g.dst[k] = nullptr; }
+            for (int k = 0; k < ncopy; ++k) {
+                if ((rc = j->d_dense[k].ensure(s * 4)) != SGK_OK) return rc;
+                g.src[k] = j->d_out[k].as<uint32_t>();
+                g.dst[k] = j->d_dense[k].as<uint32_t>();
+            }
+            hipLaunchKernelGGL(k_gather, dim3(j->n_reads), dim3(256), 0, st, g, ncopy, j->d_slots.as<uint64_t>(),
+                               j->d_cnt.as<uint32_t>(), j->d_doffs.as<uint64_t>());
+            SGK_HIP_TRY(hipGetLastError());
+            if ((rc = d2h(j->h_doffs, j->d_doffs, (nr + 1) * 8, st)) != SGK_OK) return rc;
+            if (!ev) {  // sgk_jnn counts the reads whose segments overflowed their slots in the workspace's first word
+                if ((rc = j->h_err.ensure(64)) != SGK_OK) return rc;
+                SGK_HIP_TRY(hipMemcpyAsync(j->h_err.p, j->d_ws.p, 4, hipMemcpyDeviceToHost, st));
+            }
+            j->n_dense = ncopy;
             break;
         }
         case SGK_TOOL_STAT: {
@@ -364,19 +425,17 @@ int sgk_job_submit_qts(sgk_job_t *j, int bits, int method, int out_fmt) {
         size_t bound = 0;
         for (size_t r = 0; r < nr; ++r) bound += round_up(4 + ((size_t)lens[r] + 3) / 4 + 3 * (size_t)lens[r], 8);
         if ((rc = j->d_out[0].ensure(bound + 16)) != SGK_OK) return rc;
-        if ((rc = j->d_out[1].ensure(nr * 8)) != SGK_OK) return rc;
-        if ((rc = j->d_out[2].ensure(8)) != SGK_OK) return rc;
+        if ((rc = j->d_out[1].ensure((nr + 1) * 8)) != SGK_OK) return rc;
         if ((rc = j->d_cnt.ensure(nr * 4)) != SGK_OK) return rc;
         if ((rc = sgk_svbzd_size(smp, view.offsets, view.lengths, j->n_reads, j->d_cnt.as<uint32_t>(), st)) != SGK_OK) return rc;
-        hipLaunchKernelGGL(k_blob_layout, dim3(1), dim3(64), 0, st, j->d_cnt.as<uint32_t>(), j->n_reads,
-                           j->d_out[1].as<uint64_t>(), j->d_out[2].as<uint64_t>());
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, j->d_cnt.as<uint32_t>(),
+                           static_cast<const uint64_t *>(nullptr), j->n_reads, 8u, j->d_out[1].as<uint64_t>());
         SGK_HIP_TRY(hipGetLastError());
         rc = sgk_svbzd_encode(smp, view.offsets, view.lengths, j->n_reads, j->d_out[0].as<uint8_t>(),
                               j->d_out[1].as<uint64_t>(), j->d_cnt.as<uint32_t>(), st);
         if (rc != SGK_OK) return rc;
         if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
-        if ((rc = d2h(j->h_out[1], j->d_out[1], nr * 8, st)) != SGK_OK) return rc;
-        if ((rc = d2h(j->h_out[2], j->d_out[2], 8, st)) != SGK_OK) return rc;
+        if ((rc = d2h(j->h_out[1], j->d_out[1], (nr + 1) * 8, st)) != SGK_OK) return rc;
         // the blobs themselves are fetched by sgk_job_wait once their total size is known
     }
     j->submitted = true;
@@ -395,9 +454,21 @@ int sgk_job_wait(sgk_job_t *j) {
         for (uint32_t r = 0; r < j->n_reads; ++r)
             if (ds[r] != 0) return SGK_ERR_FORMAT;
     }
+    if (j->tool == SGK_TOOL_EVENT || j->tool == SGK_TOOL_JNN) {
+        const uint64_t total = j->h_doffs.as<uint64_t>()[j->n_reads];
+        int rc;
+        for (int k = 0; k < j->n_dense; ++k)
+            if ((rc = d2h(j->h_out[k], j->d_dense[k], (size_t)total * 4, j->st)) != SGK_OK) return rc;
+        SGK_HIP_TRY(hipStreamSynchronize(j->st));
+    }
+    if (j->tool == SGK_TOOL_JNN) {
+        uint32_t nerr;
+        memcpy(&nerr, j->h_err.p, 4);
+        if (nerr) return SGK_ERR_CAPACITY;
+    }
     if (j->tool == SGK_TOOL_EVENT) return sgk_event_status(j->d_ws.p, &j->ev_status, j->st);
     if (j->tool == SGK_TOOL_QTS && j->flags == SGK_SIGNAL_SVBZD) {
-        const uint64_t total = j->h_out[2].as<uint64_t>()[0];
+        const uint64_t total = j->h_out[1].as<uint64_t>()[j->n_reads];
         int rc;
         if ((rc = d2h(j->h_out[0], j->d_out[0], (size_t)total, j->st)) != SGK_OK) return rc;
         SGK_HIP_TRY(hipStreamSynchronize(j->st));
@@ -429,7 +500,7 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
             out->pa = j->h_out[0].as<float>();
             break;
         case SGK_TOOL_EVENT:
-            out->slots = j->h_slots.as<uint64_t>();
+            out->slots = j->h_doffs.as<uint64_t>();
             out->counts = j->h_cnt.as<uint32_t>();
             out->ev_start = j->h_out[0].as<uint32_t>();
             out->ev_length = j->h_out[1].as<uint32_t>();
@@ -440,7 +511,7 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
             out->event_status = j->ev_status;
             break;
         case SGK_TOOL_JNN:
-            out->slots = j->h_slots.as<uint64_t>();
+            out->slots = j->h_doffs.as<uint64_t>();
             out->counts = j->h_cnt.as<uint32_t>();
             out->seg_x = j->h_out[0].as<int32_t>();
             out->seg_y = j->h_out[1].as<int32_t>();
