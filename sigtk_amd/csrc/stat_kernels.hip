@@ -7,11 +7,16 @@
 //     The lanes of a wave stream 64 different reads through the LDS row stager (row_stream.h),
 //     so global loads are still whole 128-byte line segments.
 //   * medians are order statistics (rank n/2, src/stat.h:56-73 + ksort.h:233-259): any exact
-//     selection works -> one 256-thread workgroup per read, two-level radix select on the
-//     int16 keys with LDS histograms; pA median = pA(raw order statistic) because the
-//     int16 -> pA map is monotone (non-increasing when range/digitisation < 0).
+//     selection works -> one 256-thread workgroup per read; whole reads take ONE pass (an LDS
+//     histogram with a bin per raw value over a window centred on the read's mean, which the
+//     moments kernel has just written; the same pass can write the pA values: fused stat + pa),
+//     regions and pathological reads a two-level radix select on the int16 keys; pA median =
+//     pA(raw order statistic) because the int16 -> pA map is monotone (non-increasing when
+//     range/digitisation < 0).
 //   * jnn_core (src/jnn.c:190-278) and jnnv2 (src/jnn.c:99-179) are serial automata with
-//     thresholds derived from those sequential float moments: one read per lane as well.
+//     thresholds derived from those sequential float moments: one read per lane as well.  Their
+//     per-sample work is integer: mask algebra for jnn_core, integer rolling totals with the exact
+//     constant division (tstat_math.h) and integer thresholds for jnnv2's run finder.
 #include "row_stream.h"
 #include "sgk_common.h"
 #include "stat_args.h"
