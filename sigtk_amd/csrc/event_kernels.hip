@@ -1052,7 +1052,12 @@ __device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *s
     const bool active = (int64_t)c * K < (int64_t)n;
     snap->init[c] = det_fresh(0);
     snap->at_e[c] = det_fresh(0);
-    int lead = (W1 == 7) ? SGK_LEAD_RNA : LEAD;  // RNA events are ~5x longer: states converge later
+    // speculative warm-up before every chunk.  RNA events are ~5x longer, so the automata converge later: with 64
+    // samples ~1.4 % of the chunk boundaries need a re-run, with 256 about 0.002 %.  A re-run costs the wave one
+    // more pass over a chunk (K samples), the warm-up costs `lead` samples per lane: short reads (small K) are
+    // better off with a short warm-up and the occasional re-run, long reads with a long one.
+    int lead = LEAD;
+    if (W1 == 7) lead = K <= 128 ? 64 : (K <= 512 ? 128 : SGK_LEAD_RNA);
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
         if constexpr (USE_LDS_HISTORY(W1)) pass_fast_lds<W1, T, FLAGGED>(rc, hist_lds, lead, run, s, e, K, snap, rep);
