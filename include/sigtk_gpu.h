@@ -291,7 +291,9 @@ int sgk_prefix_host(const sgk_host_batch_t *batch, int rna, int pore, sgk_prefix
  *     ... reader threads copy blob r to in.blobs + in.blob_offsets[r], fill in.digitisation[r] ...
  *     sgk_job_submit(job, SGK_TOOL_EVENT, rna, pore, 0);       // returns at once
  *     ... (another thread) sgk_job_wait(job); sgk_job_output(job, &out); format rows ...
- * begin/submit/wait may be called from different threads, one at a time per job. */
+ * begin/submit/wait may be called from different threads, one at a time per job.  After a call on a job has
+ * returned an error other than SGK_ERR_FORMAT / SGK_ERR_CAPACITY (which describe the data, the job stays usable),
+ * destroy the job: work may still be queued on its stream. */
 typedef struct sgk_job sgk_job_t;
 
 #define SGK_TOOL_PA 0
