@@ -10,7 +10,7 @@ static const char B5_EOF_MARK[5] = {'5', 'W', 'O', 'L', 'B'};
 
 static int grow(uint8_t **p, uint64_t *cap, uint64_t need) {
     if (*cap >= need) return 0;
-    uint64_t c = *cap ? *cap : 4096;
+    uint64_t c = *cap ? *cap : 512;
     while (c < need) c *= 2;
     uint8_t *q = (uint8_t *)realloc(*p, c);
     if (!q) return B5_ERR_MEM;
@@ -293,7 +293,7 @@ int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t 
     const uint8_t *p = raw;
     uint64_t n = size;
     if (f->record_press == 1) {
-        uint64_t want = *scratch_cap ? *scratch_cap : size * 4 + 4096;
+        uint64_t want = *scratch_cap ? *scratch_cap : size * 4 + 256;  /* grown on Z_BUF_ERROR; kept small: one per record slot */
         for (;;) {
             const int rc = grow(scratch, scratch_cap, want);
             if (rc) return rc;
