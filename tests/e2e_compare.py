@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end CLI comparison on the GPU box: sigtk-amd vs the real reference binary
 (oracle/_ref/sigtk_ref) on a synthetic BLOW5 -- byte-compare stdout and report wall times.
-    python tools/e2e_compare.py [--reads 500] [--read-len 100000] [--kind 0]"""
+    python tests/e2e_compare.py [--reads 500] [--read-len 100000] [--kind 0]"""
 import argparse
 import json
 import os

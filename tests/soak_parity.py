@@ -2,7 +2,7 @@
 """Randomised differential test: every subtool through the job API (svb-zd and int16 input alternating) against
 the oracle, on batches of reads with random lengths, kinds, seeds and scalings (incl. negative range, fractional
 offsets, tiny digitisation), with a few adversarial reads mixed in (constant, saturated, alternating extremes).
-    python tools/soak_parity.py [--minutes 3] [--seed 1]"""
+    python tests/soak_parity.py [--minutes 3] [--seed 1]"""
 import argparse
 import json
 import os
