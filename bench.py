@@ -7,7 +7,8 @@ in HBM when the timed region starts.  One "step" = one pass of the event path (d
 -> exact fallback) over the whole batch.  With --gpus N every rank processes its own batch of the
 same size (reads shard embarrassingly; no data-path collective) -> weak scaling.
 
-Prints ONE JSON line on rank 0 (see the driver contract): value = total samples/s over all
+The oracle is used only in the CPU-baseline leg (rank 0, N=1): as the checker of the benched output and as the
+timed baseline.  Prints ONE JSON line on rank 0 (see the driver contract): value = total samples/s over all
 ranks; `roofline` = algorithmic HBM bytes of one step (2*S + 16*E + 40*R) over the
 HIP-event-measured duration of the path's kernels; `cpu_baseline` = the real reference
 (oracle/_ref/libsigtk_ref.so, kind "reference") or the oracle restatement (kind "port") timed
@@ -75,29 +76,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup (untimed) + parity spot-check of the benched path against the oracle
+    # ---- warmup (untimed)
     for _ in range(max(args.warmup, 1)):
         device.event(batch, arena, args.rna)
     torch.cuda.synchronize()
     st = arena.status()
     E = int(st.n_events_total)
     parity = None
-    if rank == 0:
-        from oracle.oracle import Oracle
-        orc = Oracle()
-        ok = True
-        for r in (0, R // 2, R - 1):
-            o = int(batch.offsets_host[r]); n = int(batch.lengths_host[r])
-            raw = batch.samples[o:o + n].cpu().numpy()
-            exp = orc.event_raw(raw, float(batch.dig[r]), float(batch.off[r]), float(batch.rng[r]), args.rna)
-            got = arena.read_events(r)
-            ok &= (got.start.size == exp.start.size and np.array_equal(got.start.astype(np.uint64), exp.start)
-                   and np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
-                   and np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32)))
-        parity = bool(ok)
-        if not ok:
-            raise SystemExit("bench: GPU event output differs from the oracle -- refusing to time it")
-
     # ---- timed region: exactly K steps
     L = api.load_library()
     L.sgk_profile_reset()
@@ -164,7 +149,22 @@ def main():
             coffs = np.zeros(nb + 1, dtype=np.uint64)
             np.cumsum(lens, out=coffs[1:])
             dig = batch.dig[:nb].cpu().numpy(); off = batch.off[:nb].cpu().numpy(); rng = batch.rng[:nb].cpu().numpy()
+            # the CPU leg is the only place the oracle is touched: first as the checker of the benched output
+            # (three reads, bit for bit), then as the timed single-thread baseline
             from oracle.oracle import Oracle, RefLib
+            orc = Oracle()
+            ok = True
+            for r in (0, nb // 2, nb - 1):
+                o = int(batch.offsets_host[r]); n = int(batch.lengths_host[r])
+                raw = batch.samples[o:o + n].cpu().numpy()
+                exp = orc.event_raw(raw, float(batch.dig[r]), float(batch.off[r]), float(batch.rng[r]), args.rna)
+                got = arena.read_events(r)
+                ok &= (got.start.size == exp.start.size and np.array_equal(got.start.astype(np.uint64), exp.start)
+                       and np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+                       and np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32)))
+            parity = bool(ok)
+            if not ok:
+                raise SystemExit("bench: GPU event output differs from the oracle -- the timing above is void")
             try:
                 os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
             except Exception:
