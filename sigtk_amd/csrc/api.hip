@@ -63,6 +63,9 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
     const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
     uint64_t nb = nr < 256 ? nr : 256;  // persistent fallback blocks (each owns a scratch region)
+    // default sizing: keep the scratch under 2 GiB even for multi-million-sample reads (fewer, still >= 1, blocks)
+    const uint64_t budget = (2ull << 30) / per_block;
+    if (nb > budget) nb = budget ? budget : 1;
     if (available) {
         const size_t room = available > o ? available - o : 0;
         uint64_t fit = room / per_block;
