@@ -153,43 +153,93 @@ static inline void sbuf_str(sbuf_t *b, const char *s, size_t len) {
     b->n += len;
 }
 
-/* parallel for with dynamic scheduling: fn(ctx, i, tid) for i in [0, n) on up to nthreads threads */
+/* parallel for with dynamic scheduling on a persistent pool: fn(ctx, i, tid) for i in [0, n).  A pool belongs to
+ * one caller thread (the loader and the writer each own one); its workers sleep between calls. */
 typedef void (*pfor_fn)(void *ctx, uint32_t i, int tid);
 typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    pthread_t *th;
+    int nworkers;        /* threads besides the caller */
+    uint64_t epoch;      /* bumped for every pfor call */
+    int running;         /* workers still inside the current call */
+    int quit;
     pfor_fn fn;
     void *ctx;
-    uint32_t n;
-    uint32_t *next;
+    uint32_t n, next;
+} pool_t;
+typedef struct {
+    pool_t *pool;
     int tid;
-} pfor_arg_t;
-static void *pfor_main(void *a_) {
-    pfor_arg_t *a = (pfor_arg_t *)a_;
+} pool_worker_t;
+
+static void pool_drain(pool_t *p, int tid) {
     for (;;) {
-        const uint32_t i = __atomic_fetch_add(a->next, 1u, __ATOMIC_RELAXED);
-        if (i >= a->n) break;
-        a->fn(a->ctx, i, a->tid);
+        const uint32_t i = __atomic_fetch_add(&p->next, 1u, __ATOMIC_RELAXED);
+        if (i >= p->n) break;
+        p->fn(p->ctx, i, tid);
     }
+}
+static void *pool_worker(void *a_) {
+    pool_worker_t *w = (pool_worker_t *)a_;
+    pool_t *p = w->pool;
+    uint64_t seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->quit && p->epoch == seen) pthread_cond_wait(&p->go, &p->mu);
+        if (p->quit) break;
+        seen = p->epoch;
+        pthread_mutex_unlock(&p->mu);
+        pool_drain(p, w->tid);
+        pthread_mutex_lock(&p->mu);
+        if (--p->running == 0) pthread_cond_signal(&p->done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    free(w);
     return NULL;
 }
-static void pfor(int nthreads, uint32_t n, pfor_fn fn, void *ctx) {
-    if (n == 0) return;
-    if ((uint32_t)nthreads > n) nthreads = (int)n;
-    if (nthreads < 1) nthreads = 1;
-    uint32_t next = 0;
-    pfor_arg_t *args = (pfor_arg_t *)calloc((size_t)nthreads, sizeof *args);
-    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
-    if (!args || !th) die_mem();
-    for (int t = 0; t < nthreads; t++) {
-        args[t].fn = fn; args[t].ctx = ctx; args[t].n = n; args[t].next = &next; args[t].tid = t;
-        if (t > 0 && pthread_create(&th[t], NULL, pfor_main, &args[t]) != 0) {
-            ERROR("pfor", "%s", "cannot create thread");
+static pool_t *pool_create(int nthreads) {
+    pool_t *p = (pool_t *)calloc(1, sizeof *p);
+    if (!p) die_mem();
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->go, NULL);
+    pthread_cond_init(&p->done, NULL);
+    p->nworkers = nthreads > 1 ? nthreads - 1 : 0;
+    p->th = (pthread_t *)calloc((size_t)p->nworkers + 1, sizeof(pthread_t));
+    if (!p->th) die_mem();
+    for (int t = 0; t < p->nworkers; t++) {
+        pool_worker_t *w = (pool_worker_t *)malloc(sizeof *w);
+        if (!w) die_mem();
+        w->pool = p;
+        w->tid = t + 1;
+        if (pthread_create(&p->th[t], NULL, pool_worker, w) != 0) {
+            ERROR("pool", "%s", "cannot create thread");
             exit(EXIT_FAILURE);
         }
     }
-    pfor_main(&args[0]);
-    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
-    free(args);
-    free(th);
+    return p;
+}
+static void pool_destroy(pool_t *p) {
+    pthread_mutex_lock(&p->mu);
+    p->quit = 1;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+    for (int t = 0; t < p->nworkers; t++) pthread_join(p->th[t], NULL);
+    free(p->th);
+    free(p);
+}
+static void pfor(pool_t *p, uint32_t n, pfor_fn fn, void *ctx) {
+    if (n == 0) return;
+    pthread_mutex_lock(&p->mu);
+    p->fn = fn; p->ctx = ctx; p->n = n; p->next = 0;
+    p->running = p->nworkers;
+    p->epoch++;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+    pool_drain(p, 0);
+    pthread_mutex_lock(&p->mu);
+    while (p->running > 0) pthread_cond_wait(&p->done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
 }
 
 /* ------------------------------------------------------------------ batches and the pipeline
@@ -269,6 +319,7 @@ typedef struct {
     /* qts */
     int q_bits, q_method;
     FILE *out_fp;    /* rows / records go here (stdout except for qts) */
+    pool_t *load_pool; /* the loader's worker pool (the writer creates its own) */
     double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
     uint64_t n_reads, n_samples;
 } pipe_t;
@@ -326,7 +377,7 @@ static void load_stage(void *ctx_, uint32_t i, int tid) {
 static void batch_launch(pipe_t *P, batch_t *b) {
     lctx_t c = {P, b};
     double t0 = realtime();
-    pfor(P->nthreads, b->n, load_parse, &c);
+    pfor(P->load_pool, b->n, load_parse, &c);
     for (uint32_t i = 0; i < b->n; i++) {
         if (b->recs[i].err) {
             fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
@@ -343,7 +394,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
     int rc = sgk_job_begin(b->job, b->n, b->lengths, b->svb ? SGK_SIGNAL_SVBZD : SGK_SIGNAL_INT16, b->blob_bytes,
                            &b->in);
     if (rc != SGK_OK) gpu_fail("sgk_job_begin", rc);
-    pfor(P->nthreads, b->n, load_stage, &c);
+    pfor(P->load_pool, b->n, load_stage, &c);
     for (uint32_t i = 0; i < b->n; i++) {
         if (b->recs[i].err) {
             fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
@@ -620,6 +671,8 @@ static void *writer_main(void *arg) {
     sbuf_t *chunk = NULL;
     uint32_t *chunk_lo = NULL;
     uint32_t chunk_cap = 0;
+    const int wthreads = P->nthreads > 32 ? 32 : P->nthreads;  /* formatting is light: fewer threads */
+    pool_t *wpool = pool_create(wthreads);
     for (;;) {
         batch_t *b = q_pop(&P->ready_q);
         if (b->last) break;
@@ -634,7 +687,6 @@ static void *writer_main(void *arg) {
         double t1 = realtime();
         P->t_wait += t1 - t0;
         /* contiguous chunks of reads with about equal sample counts; a few per thread for balance */
-        const int wthreads = P->nthreads > 32 ? 32 : P->nthreads;  /* formatting is light: fewer threads, less start-up */
         uint32_t nchunks = (uint32_t)wthreads * 4;
         if (nchunks > b->n) nchunks = b->n;
         if (nchunks > chunk_cap) {
@@ -656,7 +708,7 @@ static void *writer_main(void *arg) {
         while (k < nchunks) chunk_lo[++k] = b->n;
         c.chunk = chunk;
         c.chunk_lo = chunk_lo;
-        pfor(wthreads, nchunks, write_chunk, &c);
+        pfor(wpool, nchunks, write_chunk, &c);
         double t2 = realtime();
         P->t_format += t2 - t1;
         for (uint32_t i = 0; i < nchunks; i++)
@@ -669,6 +721,7 @@ static void *writer_main(void *arg) {
         b->raw_len = 0;
         q_push(&P->free_q, b);
     }
+    pool_destroy(wpool);
     for (uint32_t i = 0; i < chunk_cap; i++) free(chunk[i].p);
     free(chunk);
     free(chunk_lo);
@@ -739,6 +792,7 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
         q_push(&P->free_q, &pool[i]);
     }
     const double t_jobs = realtime() - t_jobs0;
+    P->load_pool = pool_create(P->nthreads);
     pthread_t wth, rth;
     if (pthread_create(&wth, NULL, writer_main, P) != 0 || pthread_create(&rth, NULL, reader_main, P) != 0) {
         ERROR("cmain", "%s", "cannot create the pipeline threads");
@@ -757,6 +811,7 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
     pool[nbatch].last = 1;
     q_push(&P->ready_q, &pool[nbatch]);
     pthread_join(wth, NULL);
+    pool_destroy(P->load_pool);
     if (getenv("SGK_CLI_TIMING"))
         fprintf(stderr,
                 "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
