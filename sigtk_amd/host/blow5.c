@@ -3,6 +3,8 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 static const uint8_t B5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', 1};
@@ -50,6 +52,7 @@ b5_file_t *b5_open(const char *path) {
 
 void b5_close(b5_file_t *f) {
     if (!f) return;
+    if (f->map) munmap((void *)f->map, (size_t)f->map_len);
     if (f->fp) fclose(f->fp);
     for (uint64_t i = 0; i < f->n_idx; i++) free(f->idx[i].id);
     free(f->idx);
@@ -358,4 +361,34 @@ int b5_svb_zd_decode(const uint8_t *blob, uint64_t nbytes, int16_t *dst, uint32_
         dst[i] = (int16_t)prev;
     }
     return data == end ? 0 : B5_ERR_PRESS;
+}
+
+/* ------------------------------------------------------------------ zero-copy sequential access */
+
+int b5_map(b5_file_t *f) {
+    if (f->map) return 0;
+    struct stat st;
+    if (fstat(fileno(f->fp), &st) != 0 || st.st_size <= 0) return B5_ERR_IO;
+    void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f->fp), 0);
+    if (m == MAP_FAILED) return B5_ERR_IO;
+    f->map = (const uint8_t *)m;
+    f->map_len = (uint64_t)st.st_size;
+    f->map_pos = f->first_rec;
+    return 0;
+}
+
+int b5_next_ref(b5_file_t *f, const uint8_t **ptr, uint64_t *size) {
+    if (!f->map) return B5_ERR_IO;
+    const uint64_t left = f->map_len > f->map_pos ? f->map_len - f->map_pos : 0;
+    const uint8_t *p = f->map + f->map_pos;
+    if (left >= 5 && memcmp(p, B5_EOF_MARK, 5) == 0) return left == 5 ? B5_EOF : B5_ERR_FORMAT;
+    if (left < 8) return B5_ERR_IO;
+    uint64_t sz;
+    memcpy(&sz, p, 8);
+    if (sz == 0 || sz > (1ull << 36)) return B5_ERR_FORMAT;
+    if (sz > left - 8) return B5_ERR_IO;
+    *ptr = p + 8;
+    *size = sz;
+    f->map_pos += 8 + sz;
+    return 0;
 }

@@ -40,6 +40,8 @@ typedef struct {
     uint64_t first_rec;   /* file offset of the first record */
     b5_idx_entry_t *idx;  /* built lazily by b5_index (sorted by id) */
     uint64_t n_idx;
+    const uint8_t *map;   /* the whole file mapped read-only (b5_map), or NULL */
+    uint64_t map_len, map_pos;
 } b5_file_t;
 
 #define B5_EOF (-1)
@@ -81,6 +83,11 @@ typedef struct {
  * *size receives their length.  0 ok, B5_EOF, or an error. */
 int b5_next_raw(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size);
 int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size);
+/* Zero-copy variant of b5_next_raw: maps the file once (b5_map; returns non-zero if that is not possible, the
+ * caller then stays with b5_next_raw) and hands out pointers into the mapping, valid until b5_close.  The pages
+ * are first touched by whoever parses the record, i.e. by the thread pool rather than by the reader. */
+int b5_map(b5_file_t *f);
+int b5_next_ref(b5_file_t *f, const uint8_t **ptr, uint64_t *size);
 /* inflates (if the file uses zlib records) into *scratch (realloc'd as needed) and parses; the view points
  * into *scratch or into raw.  Re-entrant: touches no state of f besides its compression settings. */
 int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,

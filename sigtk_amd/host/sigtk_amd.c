@@ -257,7 +257,8 @@ static void pfor(pool_t *p, uint32_t n, pfor_fn fn, void *ctx) {
  * every output row depends on one record only, src/cmain.c:118-120, so there is no collective). */
 
 typedef struct {
-    uint64_t raw_off, raw_size; /* the record's on-disk bytes inside batch_t.raw */
+    uint64_t raw_off, raw_size; /* the record's on-disk bytes inside batch_t.raw ... */
+    const uint8_t *raw_ptr;     /* ... or, when the file is mapped, in the mapping */
     uint8_t *scratch;           /* inflated record (kept per slot; grows only) */
     uint64_t scratch_cap;
     b5_view_t v;
@@ -271,6 +272,7 @@ typedef struct batch {
     uint32_t n, cap;
     uint8_t *raw;
     uint64_t raw_len, raw_cap;
+    uint64_t bytes;  /* on-disk bytes gathered so far (the batch limit applies to it) */
     uint32_t *lengths, *blob_bytes;
     int svb;        /* signal staged as svb-zd blobs (GPU decode) */
     int last;       /* sentinel: no more batches */
@@ -329,7 +331,7 @@ static void gpu_fail(const char *what, int rc) {
     exit(EXIT_FAILURE);
 }
 
-static void batch_add_record(batch_t *b, uint64_t size) {
+static void batch_add_record(batch_t *b, uint64_t size, const uint8_t *ref) {
     if (b->n == b->cap) {
         const uint32_t nc = b->cap ? b->cap * 2 : 1024;
         b->recs = (lrec_t *)realloc(b->recs, sizeof(lrec_t) * nc);
@@ -341,6 +343,8 @@ static void batch_add_record(batch_t *b, uint64_t size) {
     }
     b->recs[b->n].raw_off = b->raw_len - size;
     b->recs[b->n].raw_size = size;
+    b->recs[b->n].raw_ptr = ref;
+    b->bytes += size;
     b->n++;
 }
 
@@ -353,7 +357,8 @@ static void load_parse(void *ctx_, uint32_t i, int tid) {
     (void)tid;
     lctx_t *c = (lctx_t *)ctx_;
     lrec_t *r = &c->b->recs[i];
-    r->err = b5_parse_raw(c->P->f, c->b->raw + r->raw_off, r->raw_size, &r->scratch, &r->scratch_cap, &r->v);
+    r->err = b5_parse_raw(c->P->f, r->raw_ptr ? r->raw_ptr : c->b->raw + r->raw_off, r->raw_size, &r->scratch,
+                          &r->scratch_cap, &r->v);
 }
 /* phase 2 (parallel): stage record i's signal and scaling into the job's pinned buffers */
 static void load_stage(void *ctx_, uint32_t i, int tid) {
@@ -719,6 +724,7 @@ static void *writer_main(void *arg) {
         P->t_write += realtime() - t2;
         b->n = 0;
         b->raw_len = 0;
+        b->bytes = 0;
         q_push(&P->free_q, b);
     }
     pool_destroy(wpool);
@@ -737,14 +743,16 @@ static void *reader_main(void *arg) {
     batch_t *b = q_pop(&P->free_q);
     int ret = 0;
     if (P->n_ids == 0) {
+        const int mapped = b5_map(f) == 0;  /* zero-copy: the pool touches the pages when it inflates the records */
         for (;;) {
             uint64_t size = 0;
+            const uint8_t *ref = NULL;
             const double t0 = realtime();
-            ret = b5_next_raw(f, &b->raw, &b->raw_len, &b->raw_cap, &size);
+            ret = mapped ? b5_next_ref(f, &ref, &size) : b5_next_raw(f, &b->raw, &b->raw_len, &b->raw_cap, &size);
             P->t_read += realtime() - t0;
             if (ret < 0) break;
-            batch_add_record(b, size);
-            if (b->raw_len >= P->limit_bytes) {
+            batch_add_record(b, size, ref);
+            if (b->bytes >= P->limit_bytes) {
                 q_push(&P->filled_q, b);
                 b = q_pop(&P->free_q);
             }
@@ -765,8 +773,8 @@ static void *reader_main(void *arg) {
                 ERROR("cmain", "%s", "Error when fetching the read");
                 exit(EXIT_FAILURE);
             }
-            batch_add_record(b, size);
-            if (b->raw_len >= P->limit_bytes) {
+            batch_add_record(b, size, NULL);
+            if (b->bytes >= P->limit_bytes) {
                 q_push(&P->filled_q, b);
                 b = q_pop(&P->free_q);
             }
@@ -1099,6 +1107,7 @@ static int dumpmain(int argc, char *argv[]) {
     const char *path = NULL;
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--split") == 0) split = 1;
+        else if (strcmp(argv[i], "--map") == 0) split = 2;  /* split API over the mapped file (b5_map / b5_next_ref) */
         else path = argv[i];
     }
     if (!path) return 1;
@@ -1113,9 +1122,14 @@ static int dumpmain(int argc, char *argv[]) {
         uint8_t *raw = NULL, *scratch = NULL;
         uint64_t raw_len = 0, raw_cap = 0, scratch_cap = 0, size = 0, sig_cap = 0;
         int16_t *sig = NULL;
-        while ((ret = b5_next_raw(f, &raw, &raw_len, &raw_cap, &size)) >= 0) {
+        if (split == 2 && b5_map(f) != 0) {
+            ERROR("dumpmain", "%s", "cannot map the file");
+            return 1;
+        }
+        const uint8_t *ref = NULL;
+        while ((ret = split == 2 ? b5_next_ref(f, &ref, &size) : b5_next_raw(f, &raw, &raw_len, &raw_cap, &size)) >= 0) {
             b5_view_t v;
-            ret = b5_parse_raw(f, raw + raw_len - size, size, &scratch, &scratch_cap, &v);
+            ret = b5_parse_raw(f, split == 2 ? ref : raw + raw_len - size, size, &scratch, &scratch_cap, &v);
             if (ret < 0) break;
             raw_len = 0;
             if (v.n_samples > sig_cap) {

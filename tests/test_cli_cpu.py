@@ -57,6 +57,8 @@ def _check_dump(cli, path, reads):
     # the pipelined reader's split API (next_raw + parse_raw + svb decode) sees the same records
     q = run(cli, "_dump", "--split", path)
     assert q.returncode == 0 and q.stdout == p.stdout
+    q = run(cli, "_dump", "--map", path)                 # ... and so does the zero-copy reader over the mapped file
+    assert q.returncode == 0 and q.stdout == p.stdout
     rows = [ln.split("\t") for ln in p.stdout.strip().split("\n")[1:]]
     assert len(rows) == len(reads)
     for row, r in zip(rows, reads):
@@ -107,7 +109,7 @@ def test_truncated_file_is_an_error(cli, tmp_path):
     data = open(os.path.join(GOLDEN, "sp1_dna.blow5"), "rb").read()
     path = str(tmp_path / "cut.blow5")
     open(path, "wb").write(data[: len(data) // 2])
-    for extra in ([], ["--split"]):
+    for extra in ([], ["--split"], ["--map"]):
         p = run(cli, "_dump", *extra, path)
         assert p.returncode == 1
 
@@ -131,6 +133,6 @@ def test_reader_survives_corrupt_input(cli, tmp_path):
             i = rnd.randrange(60, len(d) - 8)
             d[i:i + 8] = bytes(rnd.getrandbits(8) for _ in range(8))
         open(path, "wb").write(bytes(d))
-        for extra in ([], ["--split"]):
+        for extra in ([], ["--split"], ["--map"]):
             p = subprocess.run([cli, "_dump", *extra, path], capture_output=True, timeout=60)
             assert p.returncode in (0, 1), (it, extra, p.returncode, p.stderr[-300:])
