@@ -309,6 +309,17 @@ static batch_t *q_pop(queue_t *q) {
     return b;
 }
 
+static batch_t *q_try_pop(queue_t *q) {
+    pthread_mutex_lock(&q->mu);
+    batch_t *b = q->head;
+    if (b) {
+        q->head = b->next;
+        if (!q->head) q->tail = NULL;
+    }
+    pthread_mutex_unlock(&q->mu);
+    return b;
+}
+
 typedef struct {
     b5_file_t *f;
     int mode, nthreads, host_decode;
@@ -322,6 +333,9 @@ typedef struct {
     int q_bits, q_method;
     FILE *out_fp;    /* rows / records go here (stdout except for qts) */
     pool_t *load_pool; /* the loader's worker pool (the writer creates its own) */
+    struct batch *pool; /* all batch slots; [0, n_created) have a job */
+    int n_created, n_max, n_gpus;
+    uint64_t batches_read;
     double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
     uint64_t n_reads, n_samples;
 } pipe_t;
@@ -737,10 +751,24 @@ static void *writer_main(void *arg) {
 /* ------------------------------------------------------------------ reader thread
  * Pulls the records' bytes off the file (sequentially, or by read id) into free batches and hands each full batch
  * to the loader, so that file reads overlap with inflating / staging the previous batch. */
+/* the reader's next empty batch: a free one, else a new one if the input has earned it, else wait */
+static batch_t *take_free_batch(pipe_t *P) {
+    batch_t *b = q_try_pop(&P->free_q);
+    if (!b && P->n_created < P->n_max && P->batches_read >= 4u * (uint64_t)P->n_created) {
+        b = &P->pool[P->n_created];
+        const int rc = sgk_job_create(P->n_created % P->n_gpus, &b->job);
+        if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
+        P->n_created++;
+    }
+    if (!b) b = q_pop(&P->free_q);
+    P->batches_read++;
+    return b;
+}
+
 static void *reader_main(void *arg) {
     pipe_t *P = (pipe_t *)arg;
     b5_file_t *f = P->f;
-    batch_t *b = q_pop(&P->free_q);
+    batch_t *b = take_free_batch(P);
     int ret = 0;
     if (P->n_ids == 0) {
         const int mapped = b5_map(f) == 0;  /* zero-copy: the pool touches the pages when it inflates the records */
@@ -754,7 +782,7 @@ static void *reader_main(void *arg) {
             batch_add_record(b, size, ref);
             if (b->bytes >= P->limit_bytes) {
                 q_push(&P->filled_q, b);
-                b = q_pop(&P->free_q);
+                b = take_free_batch(P);
             }
         }
         if (ret != B5_EOF) {
@@ -776,7 +804,7 @@ static void *reader_main(void *arg) {
             batch_add_record(b, size, NULL);
             if (b->bytes >= P->limit_bytes) {
                 q_push(&P->filled_q, b);
-                b = q_pop(&P->free_q);
+                b = take_free_batch(P);
             }
         }
     }
@@ -790,11 +818,19 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
     q_init(&P->free_q);
     q_init(&P->filled_q);
     q_init(&P->ready_q);
-    const int nbatch = n_gpus + 3;  /* one being read, one being inflated/staged, n_gpus in flight, one being written */
+    /* Up to n_gpus + 3 batches (one being read, one being inflated/staged, n_gpus in flight, one being written),
+     * but only two to begin with: a job's pinned and device buffers cost tens of milliseconds to set up, which a
+     * small input never earns back.  The reader adds a batch when it would otherwise wait and the input has
+     * already run to several batches per existing one (take_free_batch). */
+    const int nbatch = n_gpus + 3;
     batch_t *pool = (batch_t *)calloc((size_t)nbatch + 1, sizeof(batch_t));
     if (!pool) die_mem();
     const double t_jobs0 = realtime();
-    for (int i = 0; i < nbatch; i++) {
+    P->pool = pool;
+    P->n_max = nbatch;
+    P->n_gpus = n_gpus;
+    P->n_created = nbatch < 2 ? nbatch : 2;
+    for (int i = 0; i < P->n_created; i++) {
         const int rc = sgk_job_create(i % n_gpus, &pool[i].job);
         if (rc != SGK_OK) gpu_fail("sgk_job_create", rc);
         q_push(&P->free_q, &pool[i]);
@@ -826,7 +862,7 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
                 "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s | HIP init %.3f s, job create %.3f s\n",
                 (unsigned long)P->n_reads, (unsigned long)P->n_samples, P->nthreads, n_gpus, P->t_read, P->t_parse,
                 P->t_stage, P->t_wait, P->t_format, P->t_write, t_init, t_jobs);
-    for (int i = 0; i < nbatch; i++) {
+    for (int i = 0; i < P->n_created; i++) {
         sgk_job_destroy(pool[i].job);
         for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
         free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
