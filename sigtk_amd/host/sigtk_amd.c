@@ -888,7 +888,10 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     int8_t hdr = 1;
     opt_t opt = {0, 0, 0, 0};
     int n_gpus = 1, nthreads = 0, host_decode = 0;
-    uint64_t batch_samples = 64ull << 20;
+    /* default batch: small (16 M samples) where the GPU stage is short -- a job's buffers are then cheap to set up
+     * and the host stages overlap sooner; 64 M for jnn / prefix, whose one-read-per-lane kernels take as long for
+     * a small batch as for a large one */
+    uint64_t batch_samples = (strcmp(mode_s, "jnn") == 0 || strcmp(mode_s, "prefix") == 0) ? 64ull << 20 : 16ull << 20;
 
     while ((c = getopt_long(argc, argv, optstring, long_options, &longindex)) >= 0) {
         if (c == 'V') {
@@ -929,7 +932,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         fprintf(fp_help, "   -c                         compact output\n");
         fprintf(fp_help, "   --version                  print version\n");
         fprintf(fp_help, "   --gpus INT                 number of GPUs; whole batches go round-robin [1]\n");
-        fprintf(fp_help, "   --batch-samples INT        approximate raw samples per batch [67108864]\n");
+        fprintf(fp_help, "   --batch-samples INT        approximate raw samples per batch [16777216; jnn, prefix: 67108864]\n");
         fprintf(fp_help, "   -t, --threads INT          host threads for inflating records / formatting rows [auto]\n");
         fprintf(fp_help, "   --host-decode              decode svb-zd signals on the host instead of the GPU\n");
         exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
@@ -1027,7 +1030,7 @@ static int qtsmain(int argc, char *argv[]) {
     char *out_fn = NULL;
     int b = 1, n_gpus = 1, nthreads = 0;
     const char *method = "round";
-    uint64_t batch_samples = 64ull << 20;
+    uint64_t batch_samples = 16ull << 20; /* small batches: the buffers of a job are cheap to set up, the host stages overlap sooner */
     while ((c = getopt_long(argc, argv, optstring, qts_long_options, &longindex)) >= 0) {
         if (c == 'V') {
             fprintf(stdout, "sigtk %s\n", SIGTK_VERSION);
