@@ -107,7 +107,7 @@ def main():
         value = S * world / (elapsed / args.steps)
         # per-step device time of each kernel (HIP events on the stream it was launched on, summed over
         # its launches in a step) and of the whole path ("path:event": first launch -> last kernel done;
-        # the builder overlaps the detector on a side stream, so the path is shorter than the sum)
+        # detector, builder and the rare fallback run back to back on one stream)
         kern = {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("path:")}
         path_ms = prof["path:event"][0] / args.steps if "path:event" in prof else sum(kern.values())
         dominant = max(kern, key=kern.get) if kern else None

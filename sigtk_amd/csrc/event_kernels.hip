@@ -34,6 +34,7 @@
 // multiple of 2^g (g = lowest bit of the smallest non-zero |x|) and all partial sums are below
 // 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29  for x and for the
 // float squares; reads failing the check take the fallback kernel.
+#include <type_traits>
 #include <utility>
 
 #include "event_args.h"
@@ -1166,7 +1167,10 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     uint32_t rank = 0, prevp = 0;
     double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary
     double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
-    float mn = FLT_MAX, mx = 0.0f;     // exactness guard: min non-zero |x| and max |x| over the read
+    // exactness guard: min non-zero |x| and max |x| over the read, tracked on the bit patterns (non-negative
+    // floats order like unsigned integers; zero - 1 wraps to the top, so it never wins the minimum; inf / nan
+    // end up above every finite value and fail the guard)
+    uint32_t mnb = 0xffffffffu, mxb = 0u;
     constexpr int NV = BT * (int)sizeof(T) / 16;
     // tile loader: this lane's 32 samples and its 32 bitmap bits.  The next tile is fetched while the
     // current one is processed (register double buffer).
@@ -1204,28 +1208,38 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         const int incl = wave_incl_scan_i(cnt);
         const int excl = incl - cnt;
         const int total = wave_last_i(incl);
-        // walk: lane-relative prefix sums, boundary records
+        // walk: lane-relative prefix sums, boundary records.  Only the last tile of a read can hold lanes with
+        // fewer than BT samples: every other tile skips the per-sample validity select.
         double S = 0.0, S2 = 0.0;
-        int idx = excl;
+        auto walk = [&](auto full_tag, auto checked_tag) {
+            constexpr bool FULL = decltype(full_tag)::value, CHECKED = decltype(checked_tag)::value;
+            int off = excl * 4;  // byte offset of the next record in p[]; twice that in S[] and S2[]
+            char *const rp = reinterpret_cast<char *>(L->p), *const rs = reinterpret_cast<char *>(L->S),
+                        *const rs2 = reinterpret_cast<char *>(L->S2);
 #pragma unroll
-        for (int k = 0; k < BT; ++k) {
-            float x = to_pa(buf[k], rc.sc);
-            if (k >= nvalid) x = 0.0f;
-            const float xq = x * x;
-            const float ax = fabsf(x);
-            mx = fmaxf(mx, ax);
-            mn = (ax != 0.0f) ? fminf(mn, ax) : mn;
-            if ((bits >> k) & 1u) {
-                if (idx < BREC) {
-                    L->p[idx] = (uint32_t)(pos0 + k);
-                    L->S[idx] = S;
-                    L->S2[idx] = S2;
+            for (int k = 0; k < BT; ++k) {
+                float x = to_pa(buf[k], rc.sc);
+                if (!FULL && k >= nvalid) x = 0.0f;
+                const float xq = x * x;
+                const uint32_t ab = __float_as_uint(x) & 0x7fffffffu;
+                mxb = ab > mxb ? ab : mxb;
+                mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
+                if ((bits >> k) & 1u) {
+                    if (!CHECKED || off < BREC * 4) {
+                        *reinterpret_cast<uint32_t *>(rp + off) = (uint32_t)(pos0 + k);
+                        *reinterpret_cast<double *>(rs + 2 * off) = S;
+                        *reinterpret_cast<double *>(rs2 + 2 * off) = S2;
+                    }
+                    off += 4;
                 }
-                ++idx;
+                S = S + (double)x;
+                S2 = S2 + (double)xq;
             }
-            S = S + (double)x;
-            S2 = S2 + (double)xq;
-        }
+        };
+        // a bitmap written by the detector never holds more than BREC peaks per tile (peaks are >= 3 apart); anything
+        // else (a caller's own bitmap) takes the bounds-checked walk and is reported as an overflow below
+        if (tb + 64 * BT <= n && total <= BREC) walk(std::true_type{}, std::false_type{});
+        else walk(std::false_type{}, std::true_type{});
         const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
         L->pt[l] = inS - S;
         L->pt2[l] = inS2 - S2;
@@ -1263,9 +1277,14 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         __syncthreads();
     }
     // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
-    mn = wave_min_f(mn);
-    mx = wave_max_f(mx);
-    const bool flagged = !guard_ok(mn, mx, n) || a.flags[r] == 2;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)mnb, d, 64), o2 = (uint32_t)__shfl_xor((int)mxb, d, 64);
+        mnb = o1 < mnb ? o1 : mnb;
+        mxb = o2 > mxb ? o2 : mxb;
+    }
+    const float mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u), mx = __uint_as_float(mxb);
+    const bool flagged = mxb >= 0x7f800000u || !guard_ok(mn, mx, n) || a.flags[r] == 2;
     if (l == 0) {
         a.flags[r] = flagged ? 1 : 0;
         if (flagged) {
