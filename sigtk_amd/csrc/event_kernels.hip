@@ -1141,7 +1141,7 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
 }
 
 #ifndef SGK_BT
-#define SGK_BT 16
+#define SGK_BT 32
 #endif
 constexpr int BT = SGK_BT;                       // samples per lane per builder tile (16 or 32)
 constexpr int BREC = 64 * ((BT + 2) / 3);        // max boundaries per tile (peaks are >= 3 apart)
