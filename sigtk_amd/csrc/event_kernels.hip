@@ -1144,14 +1144,21 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
 #define SGK_BT 32
 #endif
 constexpr int BT = SGK_BT;                       // samples per lane per builder tile (16 or 32)
-constexpr int BREC = 64 * ((BT + 2) / 3);        // max boundaries per tile (peaks are >= 3 apart)
+#ifndef SGK_BREC
+#define SGK_BREC 512
+#endif
+// Boundary records per tile in LDS (18 bytes each; 10 KB per wave with the lane prefixes: 16 waves per CU).  The detector can emit a boundary every 3 samples (64 * 11 per
+// tile), but sizing LDS for that costs occupancy; a tile with more than BREC boundaries (events shorter than 4
+// samples on average over 2048 samples) sends its read to k_event_fallback instead, which has no such limit.
+constexpr int BREC = SGK_BREC;
 struct BuildLds {
     double S[BREC];
     double S2[BREC];
     double pt[64];
     double pt2[64];
-    uint32_t p[BREC];
+    uint16_t p[BREC];  // tile-relative sample index of the boundary
 };
+static_assert(64 * BT <= 65536 && sizeof(BuildLds) <= 10240, "builder LDS budget: 16 waves per CU");
 
 template <typename T>
 __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L) {
@@ -1163,7 +1170,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
-    bool overflow = false;
+    bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
     double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary
     double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
@@ -1213,7 +1220,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         double S = 0.0, S2 = 0.0;
         auto walk = [&](auto full_tag, auto checked_tag) {
             constexpr bool FULL = decltype(full_tag)::value, CHECKED = decltype(checked_tag)::value;
-            int off = excl * 4;  // byte offset of the next record in p[]; twice that in S[] and S2[]
+            int off = excl * 2;  // byte offset of the next record in p[]; four times that in S[] and S2[]
             char *const rp = reinterpret_cast<char *>(L->p), *const rs = reinterpret_cast<char *>(L->S),
                         *const rs2 = reinterpret_cast<char *>(L->S2);
 #pragma unroll
@@ -1225,19 +1232,18 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
                 mxb = ab > mxb ? ab : mxb;
                 mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
                 if ((bits >> k) & 1u) {
-                    if (!CHECKED || off < BREC * 4) {
-                        *reinterpret_cast<uint32_t *>(rp + off) = (uint32_t)(pos0 + k);
-                        *reinterpret_cast<double *>(rs + 2 * off) = S;
-                        *reinterpret_cast<double *>(rs2 + 2 * off) = S2;
+                    if (!CHECKED || off < BREC * 2) {
+                        *reinterpret_cast<uint16_t *>(rp + off) = (uint16_t)(l * BT + k);
+                        *reinterpret_cast<double *>(rs + 4 * off) = S;
+                        *reinterpret_cast<double *>(rs2 + 4 * off) = S2;
                     }
-                    off += 4;
+                    off += 2;
                 }
                 S = S + (double)x;
                 S2 = S2 + (double)xq;
             }
         };
-        // a bitmap written by the detector never holds more than BREC peaks per tile (peaks are >= 3 apart); anything
-        // else (a caller's own bitmap) takes the bounds-checked walk and is reported as an overflow below
+        // a tile with more than BREC boundaries takes the bounds-checked walk; its read is redone by the fallback
         if (tb + 64 * BT <= n && total <= BREC) walk(std::true_type{}, std::false_type{});
         else walk(std::false_type{}, std::true_type{});
         const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
@@ -1246,10 +1252,10 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         const double tileS = wave_last_d(inS), tileS2 = wave_last_d(inS2);
         __syncthreads();
         const int tot = total < BREC ? total : BREC;
-        if (total > BREC) overflow = true;
+        if (total > BREC) dense = true;
         for (int k = l; k < tot; k += 64) {
-            const uint32_t p = L->p[k];
-            const int ln = (int)((p - (uint32_t)tb) / BT);
+            const uint32_t pr = L->p[k], p = (uint32_t)tb + pr;
+            const int ln = (int)(pr / BT);
             const double G = G0 + (L->pt[ln] + L->S[k]);
             const double G2 = G20 + (L->pt2[ln] + L->S2[k]);
             uint32_t pp;
@@ -1257,17 +1263,18 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             if (k == 0) {
                 pp = prevp; Gp = Gprev; G2p = G2prev;
             } else {
-                pp = L->p[k - 1];
-                const int lp = (int)((pp - (uint32_t)tb) / BT);
+                const uint32_t ppr = L->p[k - 1];
+                pp = (uint32_t)tb + ppr;
+                const int lp = (int)(ppr / BT);
                 Gp = G0 + (L->pt[lp] + L->S[k - 1]);
                 G2p = G20 + (L->pt2[lp] + L->S2[k - 1]);
             }
             store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)k, pp, p, G - Gp, G2 - G2p, overflow);
         }
         if (tot > 0) {
-            const uint32_t p = L->p[tot - 1];
-            const int ln = (int)((p - (uint32_t)tb) / BT);
-            prevp = p;
+            const uint32_t pr = L->p[tot - 1];
+            const int ln = (int)(pr / BT);
+            prevp = (uint32_t)tb + pr;
             Gprev = G0 + (L->pt[ln] + L->S[tot - 1]);
             G2prev = G20 + (L->pt2[ln] + L->S2[tot - 1]);
             rank += (uint32_t)tot;
@@ -1284,7 +1291,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         mxb = o2 > mxb ? o2 : mxb;
     }
     const float mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u), mx = __uint_as_float(mxb);
-    const bool flagged = mxb >= 0x7f800000u || !guard_ok(mn, mx, n) || a.flags[r] == 2;
+    const bool flagged = dense || mxb >= 0x7f800000u || !guard_ok(mn, mx, n) || a.flags[r] == 2;
     if (l == 0) {
         a.flags[r] = flagged ? 1 : 0;
         if (flagged) {
@@ -1310,7 +1317,7 @@ __device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
-    bool overflow = false;
+    bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
     const int64_t nwords = (n + 31) >> 5;
     for (int64_t w0 = 0; w0 < nwords; w0 += 64) {
@@ -1444,7 +1451,7 @@ __global__ __launch_bounds__(64, 3) void k_event_detect(EvArgs a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void k_event_build(EvArgs a) {
+__global__ __launch_bounds__(64, 4) void k_event_build(EvArgs a) {
     __shared__ BuildLds L;
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);

@@ -67,8 +67,11 @@ def test_event_edge_signals(gpu, oracle):
     tiny = (rs.randint(400, 600, size=n)).astype(np.int16)
     tiny[1234] = -9                                                # raw = -offset+2 -> tiny |pA| -> fallback
     zeros = np.zeros(n, dtype=np.int16)
-    reads = [const, steps, noise, tiny, zeros]
-    dig = np.full(5, 8192.0); off = np.array([10.0, 3.0, 0.0, 11.0, 0.0]); rng = np.full(5, 1402.882324)
+    # a level change every 3 samples: the densest boundaries the detector can emit (> 512 per 2048 samples, so the
+    # builder needs more than one round of boundary records per tile)
+    dense = (np.repeat(np.tile([420, 610], n // 6 + 1), 3)[:n] + rs.randint(-2, 3, size=n)).astype(np.int16)
+    reads = [const, steps, noise, tiny, zeros, dense]
+    dig = np.full(6, 8192.0); off = np.array([10.0, 3.0, 0.0, 11.0, 0.0, 5.0]); rng = np.full(6, 1402.882324)
     for rna in (0, 1):
         got, status = gpu.event(reads, dig, off, rng, rna)
         _check_events(oracle, reads, dig, off, rng, rna, got)
