@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/r01c
+O=gpurun_out/${1:-r01c}
 mkdir -p $O
 timeout -s KILL 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout -s KILL 300 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>> $O/bench.err
@@ -9,8 +9,10 @@ timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_sq.log 2>&1
+if [ "$2" != "nosub" ]; then
 timeout -s KILL 600 python tools/bench_subtools.py --reads 125000 --rna 0 > $O/subtools_c4.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 50000 --rna 1 > $O/subtools_c3.json 2>> $O/bench.err
+fi
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
 tail -1 $O/bench.json
