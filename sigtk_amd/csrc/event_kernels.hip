@@ -1172,8 +1172,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
     bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
-    double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary
-    double G0 = 0.0, G20 = 0.0;        // prefix sums at the tile start
+    double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary, relative to the current tile start
     // exactness guard: min non-zero |x| and max |x| over the read, tracked on the bit patterns (non-negative
     // floats order like unsigned integers; zero - 1 wraps to the top, so it never wins the minimum; inf / nan
     // end up above every finite value and fail the guard)
@@ -1253,34 +1252,29 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         __syncthreads();
         const int tot = total < BREC ? total : BREC;
         if (total > BREC) dense = true;
-        for (int k = l; k < tot; k += 64) {
-            const uint32_t pr = L->p[k], p = (uint32_t)tb + pr;
+        // one event per lane per round.  Prefix sums are kept relative to the tile start (exact under the guard, so
+        // no absolute base is needed); the previous boundary of lane l is lane l-1's record, lane 0 takes the
+        // carry: the last record of the previous round / tile.
+        for (int k0 = 0; k0 < tot; k0 += 64) {
+            const int k = k0 + l;
+            const bool act = k < tot;
+            const int kk = act ? k : tot - 1;
+            const uint32_t pr = L->p[kk], p = (uint32_t)tb + pr;
             const int ln = (int)(pr / BT);
-            const double G = G0 + (L->pt[ln] + L->S[k]);
-            const double G2 = G20 + (L->pt2[ln] + L->S2[k]);
-            uint32_t pp;
-            double Gp, G2p;
-            if (k == 0) {
-                pp = prevp; Gp = Gprev; G2p = G2prev;
-            } else {
-                const uint32_t ppr = L->p[k - 1];
-                pp = (uint32_t)tb + ppr;
-                const int lp = (int)(ppr / BT);
-                Gp = G0 + (L->pt[lp] + L->S[k - 1]);
-                G2p = G20 + (L->pt2[lp] + L->S2[k - 1]);
-            }
-            store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)k, pp, p, G - Gp, G2 - G2p, overflow);
+            const double G = L->pt[ln] + L->S[kk];
+            const double G2 = L->pt2[ln] + L->S2[kk];
+            const uint32_t pp = (uint32_t)wave_shr1_i((int)p, (int)prevp);
+            const double Gp = wave_shr1_d(G, Gprev), G2p = wave_shr1_d(G2, G2prev);
+            if (act) store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)k, pp, p, G - Gp, G2 - G2p, overflow);
+            const int last = (tot - k0) < 64 ? (tot - k0 - 1) : 63;  // wave-uniform
+            prevp = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
+            Gprev = readlane_d(G, last);
+            G2prev = readlane_d(G2, last);
         }
-        if (tot > 0) {
-            const uint32_t pr = L->p[tot - 1];
-            const int ln = (int)(pr / BT);
-            prevp = (uint32_t)tb + pr;
-            Gprev = G0 + (L->pt[ln] + L->S[tot - 1]);
-            G2prev = G20 + (L->pt2[ln] + L->S2[tot - 1]);
-            rank += (uint32_t)tot;
-        }
-        G0 = G0 + tileS;
-        G20 = G20 + tileS2;
+        rank += (uint32_t)tot;
+        // rebase the carry to the next tile's start
+        Gprev = Gprev - tileS;
+        G2prev = G2prev - tileS2;
         __syncthreads();
     }
     // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
@@ -1298,7 +1292,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
             a.flag_list[k] = r;
         } else {
-            store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, G0 - Gprev, G20 - G2prev, overflow);
+            store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
             a.n_events[r] = rank + 1;
             atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
         }

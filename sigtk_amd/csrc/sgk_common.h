@@ -92,6 +92,19 @@ __device__ inline double wave_last_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// value of lane l-1 (wave shift right by one lane, DPP wave_shr:1); lane 0 receives `first`
+__device__ inline int wave_shr1_i(int v, int first) {
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+__device__ inline double wave_shr1_d(double v, double first) {
+    const int lo = wave_shr1_i(__double2loint(v), __double2loint(first));
+    const int hi = wave_shr1_i(__double2hiint(v), __double2hiint(first));
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_d(double v, int lane) {  // lane must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ inline float wave_min_f(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
