@@ -101,9 +101,12 @@ __device__ inline void sweep_rows(RowPrefetch &rs, int skip, int64_t len, F f) {
         uint32_t w[32];
         rs.row(w);
         const int64_t j0 = (int64_t)t * TILE - skip;
-        // common case: the whole tile lies inside every lane's row -> no per-sample predicates
-        if (__all(j0 >= 0 && j0 + TILE <= len)) sweep_tile_full<0>(w, (int)j0, f);
-        else if (j0 + TILE > 0 && j0 < len) sweep_tile_elems<0>(w, j0, len, f);
+        // common case: the whole tile lies inside the row of every lane that still has samples (lanes whose row
+        // has ended, or has not begun, sit the tile out) -> no per-sample predicates
+        const bool inside = j0 >= 0 && j0 + TILE <= len, outside = j0 + TILE <= 0 || j0 >= len;
+        if (__all(inside || outside)) {
+            if (inside) sweep_tile_full<0>(w, (int)j0, f);
+        } else if (!outside) sweep_tile_elems<0>(w, j0, len, f);
         if (t + 1 < ntiles) rs.commit(t + 1);
     }
 }
@@ -140,8 +143,10 @@ __device__ inline void sweep_rows_parts(RowPrefetch &rs, int skip, int64_t len, 
             uint32_t w[P / 2];
             rs.row_part<P>(h, w);
             const int64_t j0 = (int64_t)t * TILE + h * P - skip;
-            if (__all(j0 >= 0 && j0 + P <= len)) sweep_part_full<0, P>(w, (int)j0, f);
-            else if (j0 + P > 0 && j0 < len) sweep_part_elems<0, P>(w, j0, len, f);
+            const bool inside = j0 >= 0 && j0 + P <= len, outside = j0 + P <= 0 || j0 >= len;
+            if (__all(inside || outside)) {  // see sweep_rows
+                if (inside) sweep_part_full<0, P>(w, (int)j0, f);
+            } else if (!outside) sweep_part_elems<0, P>(w, j0, len, f);
         }
         if (t + 1 < ntiles) rs.commit(t + 1);
     }
@@ -639,8 +644,13 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
                 for (int k = 0; k < PART / 2; ++k) wt[k] = 0u;
             }
             const int il0 = t * TILE + h * PART - skip;
-            if (__all(il0 >= ADW && il0 + PART < n32)) rolling_full<0>(wl, wt, il0 - ADW + 1, tot, f);
-            else if (n > ADW) rolling_elems<0>(wl, wt, (int64_t)il0, n, tot, f);
+            // lanes whose read has ended (or is too short, or has not begun) sit the part out; the predicated form
+            // is only needed while some lane crosses the start, the first full window or the end of its read
+            const bool inside = il0 >= ADW && il0 + PART < n32;
+            const bool outside = n32 <= ADW || il0 >= n32 || il0 + PART <= 0;
+            if (__all(inside || outside)) {
+                if (inside) rolling_full<0>(wl, wt, il0 - ADW + 1, tot, f);
+            } else if (!outside) rolling_elems<0>(wl, wt, (int64_t)il0, n, tot, f);
         }
         if (t + 1 < ntiles) lead.commit(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.commit(t + 1 - LAG);
