@@ -621,8 +621,12 @@ __device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], con
         rolling_full<K + 1>(wl, wt, i0, tot, f);
     }
 }
-template <typename F>
-__device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int skip, int64_t n, F f) {
+struct NeverStop {
+    __device__ bool operator()() const { return false; }
+};
+// `stop` is asked once per tile (this lane has nothing more to learn); the sweep ends early when every lane says so
+template <typename F, typename S = NeverStop>
+__device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int skip, int64_t n, F f, S stop = S()) {
     const int maxq = wave_max_i((int)(n > ADW ? skip + n : 0));
     const int ntiles = (maxq + TILE - 1) / TILE;
     if (ntiles == 0) return;
@@ -652,6 +656,7 @@ __device__ inline void sweep_rolling(RowPrefetch &lead, RowPrefetch &trail, int 
                 if (inside) rolling_full<0>(wl, wt, il0 - ADW + 1, tot, f);
             } else if (!outside) rolling_elems<0>(wl, wt, (int64_t)il0, n, tot, f);
         }
+        if (__all(stop())) break;
         if (t + 1 < ntiles) lead.commit(t + 1);
         if (t + 1 >= LAG && t + 1 < ntiles) trail.commit(t + 1 - LAG);
     }
@@ -702,7 +707,9 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
     RunFinder F;
     const float bot = mn - sd * std_scale;
     F.init(roll_threshold(bot, false), roll_threshold(bot, true), 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
-    sweep_rolling(lead, trail, skip, n, [&](int i, int tot) { F.step(i, tot); });
+    // the answer is the first qualifying segment (the reference breaks out of its segment list, src/jnn.c:154-167),
+    // and a segment is final once a later one has started without merging into it: nothing after that changes it
+    sweep_rolling(lead, trail, skip, n, [&](int i, int tot) { F.step(i, tot); }, [&]() { return !run || F.found != 0; });
     F.finish();
     if (!valid) return;
     sgk_prefix_rec_t *o = a.prefix + r;
