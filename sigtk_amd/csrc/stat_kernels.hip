@@ -611,14 +611,25 @@ __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[PART / 2], co
         rolling_elems<K + 1>(wl, wt, il0, n, tot, f);
     }
 }
-// all PART lead indices are in [ADW, n-1): no predicates
+// all PART lead indices are in [ADW, n-1): no predicates.  Two samples per packed 16-bit instruction for the outlier
+// clamp and the lead - trail difference (|difference| <= 1200 fits int16).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
+    s16x2 v = __builtin_bit_cast(s16x2, w);
+    v = __builtin_elementwise_max(v, (s16x2){0, 0});
+    return __builtin_elementwise_min(v, (s16x2){1200, 1200});
+}
 template <int K, typename F>
 __device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2], int i0,
                                              int &tot, F &f) {
     if constexpr (K < PART) {
-        tot += clampi_raw(RowPrefetch::sample_part<K>(wl)) - clampi_raw(RowPrefetch::sample_part<K>(wt));
+        static_assert(K % 2 == 0, "pairs");
+        const s16x2 d = clamp_raw2(wl[K / 2]) - clamp_raw2(wt[K / 2]);
+        tot += (int)d.x;
         f(i0 + K, tot);
-        rolling_full<K + 1>(wl, wt, i0, tot, f);
+        tot += (int)d.y;
+        f(i0 + K + 1, tot);
+        rolling_full<K + 2>(wl, wt, i0, tot, f);
     }
 }
 struct NeverStop {
