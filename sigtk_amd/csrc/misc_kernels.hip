@@ -9,39 +9,46 @@ namespace sgk {
 // lane per step: purely streaming, 6 B/sample.
 constexpr int PA_SLAB = 8192;
 
+// A launch holds at most SLAB_GRID_MAX workgroups (gridDim.x * 256 threads must stay below 2^32, and a ragged batch
+// with one very long read has n_reads * slabs_per_read far beyond that): every kernel of this shape strides over the
+// (read, slab) pairs.
+constexpr uint32_t SLAB_GRID_MAX = 1u << 22;
+
 __global__ __launch_bounds__(256) void k_pa(const int16_t *samples, const uint64_t *offsets,
                                             const uint32_t *lengths, const double *dig,
                                             const double *off, const double *rng, uint32_t n_reads,
                                             uint32_t slabs_per_read, float *out) {
-    const uint32_t r = blockIdx.x / slabs_per_read;
-    const uint32_t slab = blockIdx.x % slabs_per_read;
-    if (r >= n_reads) return;
-    const uint64_t o0 = offsets[r];
-    const uint64_t n = lengths[r];
-    const uint64_t b = (uint64_t)slab * PA_SLAB;
-    if (b >= n) return;
-    const uint64_t e = (b + PA_SLAB < n) ? b + PA_SLAB : n;
-    const Scale sc = make_scale(dig[r], off[r], rng[r]);
-    const int16_t *src = samples + o0;
-    float *dst = out + o0;
-    const bool vec = ((reinterpret_cast<uintptr_t>(src + b) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + b) & 15u) == 0);
-    if (vec) {
-        for (uint64_t p = b + (uint64_t)threadIdx.x * 8; p < e; p += 256 * 8) {
-            if (p + 8 <= e) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(src + p);
-                int16_t s[8];
-                __builtin_memcpy(s, &q, 16);
-                float4 a, c;
-                a.x = to_pa(s[0], sc); a.y = to_pa(s[1], sc); a.z = to_pa(s[2], sc); a.w = to_pa(s[3], sc);
-                c.x = to_pa(s[4], sc); c.y = to_pa(s[5], sc); c.z = to_pa(s[6], sc); c.w = to_pa(s[7], sc);
-                *reinterpret_cast<float4 *>(dst + p) = a;
-                *reinterpret_cast<float4 *>(dst + p + 4) = c;
-            } else {
-                for (uint64_t k = p; k < e; ++k) dst[k] = to_pa(src[k], sc);
+    const uint64_t total = (uint64_t)n_reads * slabs_per_read;
+    for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const uint32_t r = (uint32_t)(w / slabs_per_read);
+        const uint32_t slab = (uint32_t)(w % slabs_per_read);
+        const uint64_t o0 = offsets[r];
+        const uint64_t n = lengths[r];
+        const uint64_t b = (uint64_t)slab * PA_SLAB;
+        if (b >= n) continue;
+        const uint64_t e = (b + PA_SLAB < n) ? b + PA_SLAB : n;
+        const Scale sc = make_scale(dig[r], off[r], rng[r]);
+        const int16_t *src = samples + o0;
+        float *dst = out + o0;
+        const bool vec = ((reinterpret_cast<uintptr_t>(src + b) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + b) & 15u) == 0);
+        if (vec) {
+            for (uint64_t p = b + (uint64_t)threadIdx.x * 8; p < e; p += 256 * 8) {
+                if (p + 8 <= e) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(src + p);
+                    int16_t s[8];
+                    __builtin_memcpy(s, &q, 16);
+                    float4 a, c;
+                    a.x = to_pa(s[0], sc); a.y = to_pa(s[1], sc); a.z = to_pa(s[2], sc); a.w = to_pa(s[3], sc);
+                    c.x = to_pa(s[4], sc); c.y = to_pa(s[5], sc); c.z = to_pa(s[6], sc); c.w = to_pa(s[7], sc);
+                    *reinterpret_cast<float4 *>(dst + p) = a;
+                    *reinterpret_cast<float4 *>(dst + p + 4) = c;
+                } else {
+                    for (uint64_t k = p; k < e; ++k) dst[k] = to_pa(src[k], sc);
+                }
             }
+        } else {
+            for (uint64_t p = b + threadIdx.x; p < e; p += 256) dst[p] = to_pa(src[p], sc);
         }
-    } else {
-        for (uint64_t p = b + threadIdx.x; p < e; p += 256) dst[p] = to_pa(src[p], sc);
     }
 }
 
@@ -50,10 +57,10 @@ int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st) {
     const uint32_t spr = (b->max_read_len + PA_SLAB - 1) / PA_SLAB;
     if (spr == 0) return SGK_OK;
     const uint64_t blocks = (uint64_t)b->n_reads * spr;
-    if (blocks > 0x7fffffffull) return SGK_ERR_ARG;
+    const uint32_t grid = blocks < SLAB_GRID_MAX ? (uint32_t)blocks : SLAB_GRID_MAX;
     {
         ProfScope ps("k_pa", st);
-        hipLaunchKernelGGL(k_pa, dim3((uint32_t)blocks), dim3(256), 0, st, b->samples, b->offsets, b->lengths, b->digitisation,
+        hipLaunchKernelGGL(k_pa, dim3(grid), dim3(256), 0, st, b->samples, b->offsets, b->lengths, b->digitisation,
                            b->offset, b->range, b->n_reads, spr, out);
     }
     SGK_HIP_TRY(hipGetLastError());
@@ -65,20 +72,22 @@ __global__ __launch_bounds__(256) void k_synth(int16_t *samples, const uint64_t 
                                                double *dig, double *off,
                                                double *rng, uint32_t n_reads, uint32_t slabs_per_read,
                                                uint64_t first_read, uint64_t seed, int kind) {
-    const uint32_t r = blockIdx.x / slabs_per_read;
-    const uint32_t slab = blockIdx.x % slabs_per_read;
-    if (r >= n_reads) return;
-    const uint64_t o0 = offsets[r];
-    const int64_t n = (int64_t)lengths[r];
-    const sgk_synth_read_t R = sgk_synth_read_init(seed, first_read + r, n, kind);
-    if (slab == 0 && threadIdx.x == 0) {
-        dig[r] = SGK_SYNTH_DIGITISATION;
-        off[r] = (double)R.offset;
-        rng[r] = SGK_SYNTH_RANGE;
+    const uint64_t total = (uint64_t)n_reads * slabs_per_read;
+    for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const uint32_t r = (uint32_t)(w / slabs_per_read);
+        const uint32_t slab = (uint32_t)(w % slabs_per_read);
+        const uint64_t o0 = offsets[r];
+        const int64_t n = (int64_t)lengths[r];
+        const sgk_synth_read_t R = sgk_synth_read_init(seed, first_read + r, n, kind);
+        if (slab == 0 && threadIdx.x == 0) {
+            dig[r] = SGK_SYNTH_DIGITISATION;
+            off[r] = (double)R.offset;
+            rng[r] = SGK_SYNTH_RANGE;
+        }
+        const int64_t b = (int64_t)slab * PA_SLAB;
+        const int64_t e = (b + PA_SLAB < n) ? b + PA_SLAB : n;
+        for (int64_t i = b + threadIdx.x; i < e; i += 256) samples[o0 + i] = sgk_synth_sample(R, i);
     }
-    const int64_t b = (int64_t)slab * PA_SLAB;
-    const int64_t e = (b + PA_SLAB < n) ? b + PA_SLAB : n;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) samples[o0 + i] = sgk_synth_sample(R, i);
 }
 
 int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
@@ -87,8 +96,8 @@ int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *leng
     if (n_reads == 0) return SGK_OK;
     const uint32_t spr = (max_read_len + PA_SLAB - 1) / PA_SLAB;
     const uint64_t blocks = (uint64_t)n_reads * (spr ? spr : 1);
-    if (blocks > 0x7fffffffull) return SGK_ERR_ARG;
-    hipLaunchKernelGGL(k_synth, dim3((uint32_t)blocks), dim3(256), 0, st, samples, offsets, lengths, dig, off, rng, n_reads,
+    const uint32_t grid = blocks < SLAB_GRID_MAX ? (uint32_t)blocks : SLAB_GRID_MAX;
+    hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, st, samples, offsets, lengths, dig, off, rng, n_reads,
                        spr ? spr : 1, first_read, seed, kind);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;

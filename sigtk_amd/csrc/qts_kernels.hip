@@ -180,15 +180,17 @@ __device__ inline int16_t qts_apply(int16_t v, int b, int method) {
 
 __global__ __launch_bounds__(256) void k_qts(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths,
                                              uint32_t n_reads, uint32_t slabs_per_read, int bits, int method) {
-    const uint32_t r = blockIdx.x / slabs_per_read;
-    const uint32_t slab = blockIdx.x % slabs_per_read;
-    if (r >= n_reads) return;
-    const uint64_t n = lengths[r];
-    const uint64_t b0 = (uint64_t)slab * 8192u;
-    if (b0 >= n) return;
-    const uint64_t e = b0 + 8192u < n ? b0 + 8192u : n;
-    int16_t *x = samples + offsets[r];
-    for (uint64_t p = b0 + threadIdx.x; p < e; p += 256) x[p] = qts_apply(x[p], bits, method);
+    const uint64_t total = (uint64_t)n_reads * slabs_per_read;
+    for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {  // bounded grid, see sgk_qts
+        const uint32_t r = (uint32_t)(w / slabs_per_read);
+        const uint32_t slab = (uint32_t)(w % slabs_per_read);
+        const uint64_t n = lengths[r];
+        const uint64_t b0 = (uint64_t)slab * 8192u;
+        if (b0 >= n) continue;
+        const uint64_t e = b0 + 8192u < n ? b0 + 8192u : n;
+        int16_t *x = samples + offsets[r];
+        for (uint64_t p = b0 + threadIdx.x; p < e; p += 256) x[p] = qts_apply(x[p], bits, method);
+    }
 }
 
 }  // namespace sgk
@@ -205,11 +207,12 @@ int sgk_qts(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, 
     const uint32_t spr = (max_read_len + 8191u) / 8192u;
     if (spr == 0) return SGK_OK;
     const uint64_t blocks = (uint64_t)n_reads * spr;
-    if (blocks > 0x7fffffffull) return SGK_ERR_ARG;
+    // gridDim.x * 256 threads must stay below 2^32: a bounded grid strides over the (read, slab) pairs
+    const uint32_t grid = blocks < (1u << 22) ? (uint32_t)blocks : (1u << 22);
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         ProfScope ps("k_qts", st);
-        hipLaunchKernelGGL(k_qts, dim3((uint32_t)blocks), dim3(256), 0, st, samples, offsets, lengths, n_reads, spr, bits, method);
+        hipLaunchKernelGGL(k_qts, dim3(grid), dim3(256), 0, st, samples, offsets, lengths, n_reads, spr, bits, method);
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;

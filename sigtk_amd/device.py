@@ -68,10 +68,12 @@ def alloc_reads(lengths: np.ndarray, device: torch.device, align: int = 64) -> D
 
 
 def synth_reads(n_reads: int, read_len: int, seed: int, kind: int, device: torch.device,
-                first_read: int = 0) -> DeviceReads:
-    """Synthetic reads generated on the device (same generator as api.synth_reads_host)."""
+                first_read: int = 0, lengths=None) -> DeviceReads:
+    """Synthetic reads generated on the device (same generator as api.synth_reads_host); `lengths` (one per read)
+    replaces the common `read_len`."""
     L = api.load_library()
-    b = alloc_reads(np.full(n_reads, read_len, dtype=np.int64), device)
+    lens = np.full(n_reads, read_len, dtype=np.int64) if lengths is None else np.asarray(lengths, dtype=np.int64)
+    b = alloc_reads(lens, device)
     api.check(L.sgk_synth_reads(_ptr(b.samples), _ptr(b.offsets), _ptr(b.lengths), _ptr(b.dig), _ptr(b.off),
                                 _ptr(b.rng), b.n_reads, b.max_read_len, first_read, seed, kind, _stream_ptr()),
               "sgk_synth_reads")

@@ -187,3 +187,35 @@ def test_gap_content_never_matters(gpu, oracle, kind, fill):
             assert np.array_equal(got.start.astype(np.uint64), exp.start)
             assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
             assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+def test_many_short_reads_next_to_one_very_long_read(gpu):
+    """pa / qts / the synthetic generator launch one workgroup per (read, 8192-sample slab) pair with the slab count
+    of the LONGEST read: 70 000 short reads next to one 2 000 000-sample read are 17 million pairs, more than one
+    launch can hold (gridDim.x * 256 threads < 2^32) -- every pair must still be processed"""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    lens = np.full(70001, 100, dtype=np.int64)
+    lens[12345] = 2_000_000
+    assert len(lens) * ((int(lens.max()) + 8191) // 8192) * 256 >= 2 ** 32
+    b = device.synth_reads(len(lens), 100, seed=9, kind=0, device=dev, lengths=lens)
+    torch.cuda.synchronize()
+    dig = b.dig[:b.n_reads].cpu().numpy(); off = b.off[:b.n_reads].cpu().numpy(); rng = b.rng[:b.n_reads].cpu().numpy()
+    assert (dig > 0).all() and (rng > 0).all()          # the generator reached every read
+    out = torch.zeros(b.n_samples, dtype=torch.float32, device=dev)
+    device.pa(b, out)
+    torch.cuda.synchronize()
+    raw_all = b.samples.cpu().numpy()
+    got_all = out.cpu().numpy()
+    for r in (0, 1, 12344, 12345, 12346, 35000, 69999, 70000):
+        o = int(b.offsets_host[r]); n = int(b.lengths_host[r])
+        raw = raw_all[o:o + n].astype(np.float32)
+        exp = (raw + np.float32(off[r])) * np.float32(rng[r] / dig[r])
+        assert np.array_equal(exp.view(np.uint32), got_all[o:o + n].view(np.uint32)), "pa, read %d" % r
+    device.qts(b, 3, 0)                                  # floor: clear the low 3 bits
+    torch.cuda.synchronize()
+    q_all = b.samples.cpu().numpy()
+    for r in (0, 12345, 70000):
+        o = int(b.offsets_host[r]); n = int(b.lengths_host[r])
+        assert np.array_equal(q_all[o:o + n], (raw_all[o:o + n] >> 3) << 3), "qts, read %d" % r

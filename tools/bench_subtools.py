@@ -19,13 +19,24 @@ def main():
     ap.add_argument("--rna", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--pipeline", type=int, default=0, help="1: also time the config-5 pa->event->stat pipeline")
+    ap.add_argument("--ragged", type=float, default=0.0, help="sigma of log-normal read lengths with mean --read-len "
+                    "(0: all reads --read-len samples)")
+    ap.add_argument("--sorted", type=int, default=0, help="1: ragged reads laid out longest first")
     args = ap.parse_args()
     import torch
     from sigtk_amd import api, device
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     L = api.load_library()
-    b = device.synth_reads(args.reads, args.read_len, seed=2, kind=args.rna, device=dev)
+    lens = None
+    if args.ragged > 0:
+        import numpy as np
+        rs = np.random.RandomState(5)
+        lens = args.read_len * np.exp(rs.normal(-0.5 * args.ragged ** 2, args.ragged, size=args.reads))
+        lens = np.clip(lens, 2500, 16 * args.read_len).astype(np.int64)
+        if args.sorted:
+            lens = np.sort(lens)[::-1].copy()
+    b = device.synth_reads(args.reads, args.read_len, seed=2, kind=args.rna, device=dev, lengths=lens)
     S, R = b.total_samples, b.n_reads
     pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=dev)
     segs = device.SegArena(b)
