@@ -132,7 +132,9 @@ int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengt
                  size_t workspace_bytes, void *stream);
 
 typedef struct sgk_event_status {
-    uint32_t n_fallback_reads;   /* reads re-done by the sequential-prefix exact path     */
+    uint32_t n_fallback_reads;   /* reads re-done by the sequential-prefix exact path (no room around the read,
+                                  * the exactness guard on the sample magnitudes failed, inf/nan samples, or
+                                  * more than 512 event boundaries within 2048 samples): same results, slower */
     uint32_t n_rerun_passes;     /* speculative chunk boundaries that needed a re-run     */
     uint32_t n_capacity_overflow;/* reads whose events did not fit their slot range       */
     uint32_t reserved;
