@@ -492,6 +492,22 @@ struct Lead16<float> {
 };
 typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Samples in front of a read (the speculative warm-up of its first chunks reaches there) are whatever the caller's
+// buffer holds.  No t-statistic that sees them is used, but they pass through the RUNNING window sums, and a value
+// far larger than the read's own samples (a neighbour scaled with this read's offset/range) would leave a rounding
+// residue in those double sums for the rest of the chunk.  Every position before the read therefore takes the
+// value of the read's first sample: inside the magnitude range the exactness guard checks.  Rare (first lanes of a
+// read, first blocks only), kept out of line.
+template <typename T>
+__device__ __attribute__((noinline)) Lead16<T> lead_fix_head(Lead16<T> g, int pos, T first) {
+    T tmp[16];
+    __builtin_memcpy(tmp, g.w, sizeof(tmp));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tmp[k] = (pos + k < 0) ? first : tmp[k];
+    __builtin_memcpy(g.w, tmp, sizeof(tmp));
+    return g;
+}
+
 // ---- repair context of a read that failed the exactness guard (fallback kernel only) ----------
 // The reference's window sums are differences of its sequentially rounded prefix arrays.  They equal
 // the exact sums the fast pass forms EXCEPT where an inexact addition of the sequential scan ("event"
@@ -576,9 +592,11 @@ struct FastPass {
     int next_t;      // FLAGGED only: smallest event position that can still matter
 
     // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are
-    // redirected to the nearest readable group: whatever finite value a position yields is used
+    // redirected to the nearest readable group: whatever value a position yields is used
     // consistently when it enters and when it leaves a window, and no t-statistic whose window
-    // reaches outside [0, n) is ever used (events.c:332-338), so only memory safety matters.
+    // reaches outside [0, n) is ever used (events.c:332-338).  Positions before the read are
+    // replaced by the read's first sample (lead_fix_head); positions behind it only ever enter the
+    // leading windows after their last used t-statistic.
     __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
         int p = pos > hi - 16 ? hi - 16 : pos;
         p = p < lo ? lo : p;
@@ -588,6 +606,7 @@ struct FastPass {
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = src[k];
         __builtin_memcpy(dst.w, v, sizeof(dst.w));
+        if (pos < 0) dst = lead_fix_head<T>(dst, pos, base[0]);
     }
 
     // phase 1: window sums and both t-statistics of index ib+U; advance the rings
@@ -719,7 +738,7 @@ __device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool a
         for (int k = 0; k < 4 * W1; ++k) {
             int p = i_begin - W2 + k;
             p = p > f.hi - 1 ? f.hi - 1 : p;
-            p = p < f.lo ? f.lo : p;
+            p = p < 0 ? 0 : p;  // positions before the read: its first sample (see lead_fix_head)
             w[k] = to_pa(f.base[p], f.sc);
         }
         double a = 0.0, aq = 0.0;
@@ -839,6 +858,7 @@ struct FastPassL {
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = src[k];
         __builtin_memcpy(dst.w, v, sizeof(dst.w));
+        if (pos < 0) dst = lead_fix_head<T>(dst, pos, base[0]);
     }
     __device__ __forceinline__ T raw_hist(int pos) const {  // stored sample at pos (within the resident window)
         return *reinterpret_cast<const T *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
