@@ -137,7 +137,8 @@ typedef struct sgk_event_status {
                                   * more than 512 event boundaries within 2048 samples): same results, slower */
     uint32_t n_rerun_passes;     /* speculative chunk boundaries that needed a re-run     */
     uint32_t n_capacity_overflow;/* reads whose events did not fit their slot range       */
-    uint32_t reserved;
+    uint32_t n_long_replays;     /* lanes (chunks) in which a run of the lazily evaluated long detector could not be
+                                  * proven silent and was re-played exactly (diagnostic)  */
     uint64_t n_events_total;
 } sgk_event_status_t;
 /* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.

@@ -5,6 +5,9 @@
 //   3. sgk_tstat_tail  == (float)(fabs((double)d)/sqrt((double)v)) with the hardware rsqrt modelled
 //      as 1/sqrt(v) perturbed by up to 2^-22 relative (robustness of the run-time certificate)
 //   4. sgk_tstat_fast<W> == sgk_tstat_ref<W> on window sums of pA-like data
+//   5. sgk_tail_f32 (f32 error-free-transformation tail, v_rsq_f32 modelled with 2^-22 relative error): certified => equal
+//   6. sgk_tstat_try_ab<W> (A side ringed, B side fresh; what LazyPass evaluates): certified => equal to sgk_tstat_ref<W>
+//   7. sgk_long_cold<W> true => sgk_tstat_ref<W> <= 9.0 (the lazy long detector's bound), incl. values steered to ~9
 // Build/run:  g++ -O2 -mfma -ffp-contract=off -fopenmp -o /tmp/verify_math oracle/verify_math.cpp && /tmp/verify_math [quick]
 #include <cstdint>
 #include <cstdio>
@@ -26,6 +29,14 @@ static inline double perturbed_rsq(double v) {
     return (1.0 / sqrt(v)) * (1.0 + u * 2.384185791015625e-07);                     // 2^-22
 }
 #define SGK_RSQ64(v) perturbed_rsq(v)
+// v_rsq_f32 model: correctly rounded 1/sqrt perturbed by up to 2^-22 relative; every 4th call sits on the edge of that band
+static inline float perturbed_rsq32(float v) {
+    const uint64_t r = rng_next(g_pert_state);
+    double u = ((double)(int64_t)(r >> 11) / 9007199254740992.0) * 2.0 - 1.0;  // [-1,1)
+    if ((r & 3) == 0) u = (r & 4) ? 1.0 : -1.0;
+    return (float)((1.0 / sqrt((double)v)) * (1.0 + u * 2.384185791015625e-07));
+}
+#define SGK_RSQ32(v) perturbed_rsq32(v)
 #include "../sigtk_amd/csrc/tstat_math.h"
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -134,6 +145,127 @@ static uint64_t check_full(uint64_t count) {
     return bad;
 }
 
+
+// 5. sgk_tail_f32: whenever it certifies, the value equals the reference tail; reports how often it does not certify
+static uint64_t check_tail32(uint64_t count, double *uncert_frac) {
+    uint64_t bad = 0, slow = 0, tot = 0;
+#pragma omp parallel for reduction(+ : bad, slow, tot) schedule(static)
+    for (int64_t t = 0; t < 64; ++t) {
+        uint64_t s = 0x5151BDFULL * (t + 3);
+        g_pert_state = 4242 + t;
+        for (uint64_t k = 0; k < count / 64; ++k) {
+            const uint64_t r = rng_next(s), r2 = rng_next(s);
+            float d, v;
+            switch (k & 7) {
+                // the domain the kernels guarantee (range guard: non-zero |x| in [2^-20, 2^20]; cv > 2^-90):
+                // |delta| = 0 or in [2^-69, 2^21), cvw in [2^-94, 2^41)
+                case 0: d = u2f((uint32_t)((r & 0x807FFFFF) | ((uint32_t)(127 - 69 + (r >> 40) % 90) << 23)));
+                        v = u2f((uint32_t)((r2 & 0x007FFFFF) | ((uint32_t)(127 - 94 + (r2 >> 40) % 135) << 23))); break;
+                case 1: d = 0.0f; v = u2f((uint32_t)((r2 & 0x007FFFFF) | ((uint32_t)(127 - 94 + (r2 >> 40) % 135) << 23))); break;
+                case 2: {  // quotient close to a power of two (binade edge of the result)
+                    v = u2f((uint32_t)((r2 & 0x007FFFFF) | ((uint32_t)(110 + (r2 >> 40) % 30) << 23)));
+                    const double q = ldexp(1.0, (int)(r % 20) - 6) * (1.0 + ((double)(int64_t)((r >> 8) % 65) - 32.0) * 5.9604644775390625e-08);
+                    d = (float)(q * sqrt((double)v));
+                    break;
+                }
+                default: d = u2f((uint32_t)((r & 0x807FFFFF) | ((uint32_t)(110 + (r >> 40) % 30) << 23)));
+                         v = u2f((uint32_t)((r2 & 0x007FFFFF) | ((uint32_t)(105 + (r2 >> 40) % 40) << 23)));
+            }
+            if (!(v > 0.0f) || !std::isfinite(v) || !std::isfinite(d)) continue;
+            const float want = (float)(fabs((double)d) / sqrt((double)v));
+            bool ok;
+            const float got = sgk_tail_f32(d, v, ok);
+            tot++;
+            if (!ok) { slow++; continue; }
+            if (f2u(want) != f2u(got)) bad++;
+        }
+    }
+    *uncert_frac = (double)slow / (double)(tot ? tot : 1);
+    return bad;
+}
+
+// pA-like (or wide-range) adjacent windows -> exact sums
+template <int W>
+static inline void make_windows(uint64_t &s, uint64_t k, double &A, double &A2, double &B, double &B2) {
+    const float unit = 1402.882324f / 8192.0f;
+    const uint64_t r = rng_next(s);
+    const int base = 200 + (int)(r % 600), jump = (int)((r >> 20) % 200) - 100, noise = 1 + (int)((r >> 40) % 12);
+    const float off = (float)((r >> 52) % 20) + (((r >> 57) & 1) ? 0.25f : 0.0f);
+    // every 16th case: a wild scale (still inside the read-level range guard 2^-40..2^40)
+    const float scale = ((k & 15) == 7) ? ldexpf(1.0f, (int)((r >> 58) % 60) - 30) : 1.0f;
+    A = A2 = B = B2 = 0.0;
+    for (int j = 0; j < 2 * W; ++j) {
+        const uint64_t q = rng_next(s);
+        int raw = base + (j >= W ? jump : 0) + (int)(q % (uint64_t)(2 * noise + 1)) - noise;
+        if ((k % 97) == 0) raw = base;  // exactly constant window -> variance floor
+        if ((k % 89) == 0 && j == 1) raw = -(int)off;  // a zero (or tiny) sample
+        const float x = (((float)raw + off) * unit) * scale;
+        const float xq = x * x;
+        if (j < W) { A += (double)x; A2 += (double)xq; } else { B += (double)x; B2 += (double)xq; }
+    }
+}
+
+// 6. sgk_tstat_try_ab<W>: certified values equal the reference expression
+template <int W>
+static uint64_t check_try_ab(uint64_t count, double *uncert_frac) {
+    uint64_t bad = 0, slow = 0;
+#pragma omp parallel for reduction(+ : bad, slow) schedule(static)
+    for (int64_t t = 0; t < 64; ++t) {
+        uint64_t s = 0x77AA33ULL * (t + 5) + W;
+        g_pert_state = 31337 + t;
+        for (uint64_t k = 0; k < count / 64; ++k) {
+            double A, A2, B, B2;
+            make_windows<W>(s, k, A, A2, B, B2);
+            const float want = sgk_tstat_ref<W>(A, A2, B, B2);
+            const SgkARole ar = sgk_arole<W>(A, A2);
+            bool ok;
+            const float got = sgk_tstat_try_ab<W>(B, B2, ar, ok);
+            if (!ok) { slow++; continue; }
+            if (f2u(want) != f2u(got)) bad++;
+        }
+    }
+    *uncert_frac = (double)slow / (double)count;
+    return bad;
+}
+
+// 7. sgk_long_cold<W> == true  =>  the reference t-statistic is <= 9.0; reports how often the test says "hot" when
+//    the reference value is in fact <= 8 (its slack)
+template <int W>
+static uint64_t check_long_cold(uint64_t count, double *false_hot) {
+    uint64_t bad = 0, fh = 0, low = 0;
+#pragma omp parallel for reduction(+ : bad, fh, low) schedule(static)
+    for (int64_t t = 0; t < 64; ++t) {
+        uint64_t s = 0x99BB11ULL * (t + 7) + W;
+        for (uint64_t k = 0; k < count / 64; ++k) {
+            double A, A2, B, B2;
+            make_windows<W>(s, k, A, A2, B, B2);
+            if ((k & 3) == 1) {
+                // steer the statistic to the neighbourhood of 9: shift window B by the right amount
+                const float t0 = sgk_tstat_ref<W>(A, A2, B, B2);
+                if (t0 > 0.5f && t0 < 1e6f) {
+                    const double target = 9.0 * (1.0 + ((double)(int64_t)(rng_next(s) % 2001) - 1000.0) * 1e-5);
+                    const float dx = (float)((B - A) / W * (target / t0 - 1.0));
+                    const float unit = 1402.882324f / 8192.0f;
+                    const float dq = roundf(dx / unit) * unit;
+                    // shifting every sample of B by dq changes the mean, not the variance (to first order)
+                    double nB = 0, nB2 = 0;
+                    const float mb = (float)(B / W);
+                    for (int j = 0; j < W; ++j) { const float x = mb + dq + (float)(j - W / 2) * unit; nB += (double)x; nB2 += (double)(x * x); }
+                    (void)nB; (void)nB2;  // keep the original variance structure: only move the sums consistently
+                    B2 = B2 + 2.0 * (double)dq * B + (double)W * (double)dq * (double)dq;
+                    B = B + (double)W * (double)dq;
+                }
+            }
+            const float ref = sgk_tstat_ref<W>(A, A2, B, B2);
+            const bool cold = sgk_long_cold<W>(sgk_lside<W>(A, A2), sgk_lside<W>(B, B2));
+            if (cold && !(ref <= 9.0f)) bad++;
+            if (ref <= 8.0f) { low++; if (!cold) fh++; }
+        }
+    }
+    *false_hot = (double)fh / (double)(low ? low : 1);
+    return bad;
+}
+
 int main(int argc, char **argv) {
     const bool quick = argc > 1 && strcmp(argv[1], "quick") == 0;
     const uint32_t step = quick ? 257 : 1;
@@ -154,6 +286,12 @@ int main(int argc, char **argv) {
     b = check_full<6>(n64 / 4);  printf("tstat_fast<6>  mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_full<7>(n64 / 4);  printf("tstat_fast<7>  mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_full<14>(n64 / 4); printf("tstat_fast<14> mismatches: %llu\n", (unsigned long long)b); bad += b;
+    double uf;
+    b = check_tail32(n64, &uf);        printf("tail_f32     mismatches: %llu (uncertified %.3g)\n", (unsigned long long)b, uf); bad += b;
+    b = check_try_ab<3>(n64 / 4, &uf); printf("tstat_try_ab<3>  mismatches: %llu (uncertified %.3g)\n", (unsigned long long)b, uf); bad += b;
+    b = check_try_ab<7>(n64 / 4, &uf); printf("tstat_try_ab<7>  mismatches: %llu (uncertified %.3g)\n", (unsigned long long)b, uf); bad += b;
+    b = check_long_cold<6>(n64 / 4, &uf);  printf("long_cold<6>  violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
+    b = check_long_cold<14>(n64 / 4, &uf); printf("long_cold<14> violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
     printf("%s\n", bad ? "FAILED" : "ALL EXACT");
     return bad ? 1 : 0;
 }

@@ -39,7 +39,7 @@ class HostBatch(C.Structure):
 
 class EventStatus(C.Structure):
     _fields_ = [("n_fallback_reads", C.c_uint32), ("n_rerun_passes", C.c_uint32),
-                ("n_capacity_overflow", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_capacity_overflow", C.c_uint32), ("n_long_replays", C.c_uint32),
                 ("n_events_total", C.c_uint64)]
 
 

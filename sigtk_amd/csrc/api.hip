@@ -247,7 +247,7 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     out->n_fallback_reads = h.n_flagged;
     out->n_rerun_passes = h.n_rerun;
     out->n_capacity_overflow = h.n_overflow;
-    out->reserved = 0;
+    out->n_long_replays = h.n_hot_runs;
     out->n_events_total = h.n_events_total;
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
 }

@@ -10,7 +10,8 @@ struct EvHeader {
     uint32_t n_overflow;  // reads whose events did not fit their slot range
     uint32_t fb_next;     // work counter of the persistent fallback kernel
     unsigned long long n_events_total;
-    uint32_t pad[10];
+    uint32_t n_hot_runs;  // lanes that replayed long-detector runs exactly (lazy long detector)
+    uint32_t pad[9];
 };
 static_assert(sizeof(EvHeader) == 64, "header is one 64-byte block");
 

@@ -2,85 +2,52 @@
 //
 // One wavefront (64 lanes) per read.  Three kernels:
 //
-//   k_event_detect   window sums -> two t-statistics -> short/long peak detector.
-//                    Lane c owns chunk c of the read (K samples, K a multiple of 64);
-//                    samples are staged global -> LDS in 64-sample row tiles (128-byte row
-//                    segments, 16 bytes per lane), each lane slides its four window sums in
-//                    registers (double; exact), evaluates the reference's mixed float/double
-//                    t-statistic expression tree (events.c:338-361) and steps both detector
-//                    automata (events.c:383-440).  The automaton is serial in the reference;
-//                    here every chunk starts SPECULATIVELY from the fresh state LEAD samples
-//                    before its chunk, and the speculation is verified: chunk c is accepted
-//                    iff its state at its chunk start equals chunk c-1's state at that
-//                    position; mismatching chunks are re-run from the true state until a
-//                    fixed point (exact in the general case; re-runs are counted in the
-//                    status block).  Output: one bit per sample (peak positions) in a
-//                    workspace bitmap.
+//   k_event_detect   window sums -> t-statistics -> short/long peak detector (LazyPass, below).
+//                    Lane c owns chunk c of the read (K samples, K a multiple of 64).  Each lane slides a
+//                    running double prefix sum through a register ring, evaluates the reference's mixed
+//                    float/double t-statistic expression tree (events.c:338-361) for the short window in
+//                    certified fast arithmetic, steps the short detector automaton (events.c:383-440) as
+//                    lane-mask algebra, and runs the long detector lazily (exact only where a rigorous bound
+//                    cannot exclude a peak).  The automaton is serial in the reference; here every chunk
+//                    starts SPECULATIVELY from the fresh state LEAD samples before its chunk, and the
+//                    speculation is verified: chunk c is accepted iff its state at its chunk start equals
+//                    chunk c-1's state at that position; mismatching chunks are re-run from the true state
+//                    until a fixed point (exact in the general case; re-runs are counted in the status
+//                    block).  Output: one bit per sample (peak positions) in a workspace bitmap.
 //
-//   k_event_build    bitmap + samples -> event table (events.c:457-504).  Lane-local double
-//                    prefix sums, wave scan across lanes, boundary records compacted in LDS,
-//                    then one event per lane per round with coalesced SoA stores of
-//                    (start, length, mean, stdv).
+//   k_event_build    bitmap + samples -> event table (events.c:457-504).  Lane-local double prefix sums,
+//                    wave scan across lanes, boundary records compacted in LDS, then one event per lane per
+//                    round with coalesced SoA stores of (start, length, mean, stdv).
 //
-//   k_event_fallback persistent kernel over the reads that fail the exactness guard: lane 0
-//                    reproduces compute_sum_sumsq's sequential double prefix scan
-//                    (events.c:293-303) into workspace scratch, then the same detector and
-//                    builder run with window/event sums taken as differences of those arrays,
-//                    exactly as the reference does.
+//   k_event_fallback persistent kernel over the reads that fail the exactness guard: lane 0 reproduces
+//                    compute_sum_sumsq's sequential double prefix scan (events.c:293-303) into workspace
+//                    scratch, then the same detector and builder run with window/event sums taken as
+//                    differences of those arrays, exactly as the reference does.
 //
-// Exactness guard: the reference accumulates double prefix sums sequentially and uses their
-// differences; the fast path forms window sums and event sums directly.  Both give the
-// real-number sums (hence identical bits) whenever no prefix sum can round: every sample is a
-// multiple of 2^g (g = lowest bit of the smallest non-zero |x|) and all partial sums are below
-// 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29  for x and for the
-// float squares; reads failing the check take the fallback kernel.
+// Exactness guard: the reference accumulates double prefix sums sequentially and uses their differences; the
+// fast path forms window sums and event sums directly.  Both give the real-number sums (hence identical bits)
+// whenever no prefix sum can round: every sample is a multiple of 2^g (g = lowest bit of the smallest non-zero
+// |x|) and all partial sums are below 2^(g+53).  Per read we check  ilogb(n*max|x|) - ilogb(min|x|!=0) <= 29
+// for x and for the float squares, and that every non-zero |x| lies in [2^-20, 2^20] (the range in which the
+// certified fast arithmetic of tstat_math.h has no subnormal intermediate); reads failing the check take the
+// fallback kernel.
 #include <type_traits>
 #include <utility>
 
 #include "event_args.h"
-#include "row_stream.h"
 #include "sgk_common.h"
 #include "tstat_math.h"
 
 namespace sgk {
 
-#ifndef SGK_LDS_HISTORY_DNA
-#define SGK_LDS_HISTORY_DNA 0
-#endif
-// which fast-pass variant a preset uses: register ring (DNA, W1 = 3) or LDS history (RNA, W1 = 7)
-#define USE_LDS_HISTORY(W1) ((W1) == 7 || SGK_LDS_HISTORY_DNA)
 #ifndef SGK_LEAD_RNA
 #define SGK_LEAD_RNA 256
 #endif
 constexpr int LEAD = 64;   // speculative warm-up (samples); multiple of 64
-constexpr int BACK = 32;   // row margin before the pass start (>= W2 + 1)
 
 __device__ inline uint32_t chunk_len(int64_t n) {
     const int64_t k = (n + 4095) / 4096;
     return (uint32_t)(k < 1 ? 64 : 64 * k);
-}
-
-// ---------------------------------------------------------------- t-statistic
-// src/events.c:338-361, one rounding per C operator (FLT_EVAL_METHOD 0, no contraction).
-template <int W>
-__device__ inline float tstat_from_sums(double A, double A2, double B, double B2) {
-    const float wf = (float)W;
-    const float sum2 = (float)B;
-    const float sumsq2 = (float)B2;
-    const float mean1 = (float)(A / (double)wf);
-    const float mean2 = sum2 / wf;
-    const float m1sq = mean1 * mean1;
-    const float m2sq = mean2 * mean2;
-    const float q2 = sumsq2 / wf;
-    double acc = A2 / (double)wf;
-    acc = acc - (double)m1sq;
-    acc = acc + (double)q2;
-    acc = acc - (double)m2sq;
-    float cv = (float)acc;
-    cv = fmaxf(cv, FLT_MIN);
-    const float delta = mean2 - mean1;
-    const float cvw = cv / wf;
-    return (float)(fabs((double)delta) / sqrt((double)cvw));
 }
 
 // ---------------------------------------------------------------- detector state
@@ -120,13 +87,6 @@ __device__ inline DetState det_shfl_up(const DetState &a) {
     r.lmask = __shfl_up(a.lmask, 1, 64);
     return r;
 }
-
-// per-lane state snapshots of one read's chunks, kept in LDS
-struct DetSnap {
-    DetState init[64];  // state a chunk's accepted run started from (at its chunk start)
-    DetState at_e[64];  // state at the chunk end
-    DetState st0[64];   // start state handed to a re-run
-};
 
 template <int W1>
 struct DetParam;
@@ -230,53 +190,22 @@ __device__ inline ReadCtx<T> make_ctx(const EvArgs &a, uint32_t r) {
     return rc;
 }
 
-// One pass of the detector over the wave's chunks.
+// One pass of the GENERIC detector over the wave's chunks: every window sum is a difference of the reference's
+// prefix arrays (rc.P / rc.P2), both detectors step on every index.  Slow (uncoalesced loads of the prefix arrays,
+// library division and sqrt); only the fallback kernel uses it, for reads the fast pass cannot take.
 //   lead   : samples each lane starts before its chunk start (LEAD: speculative pass, 0: re-run)
 //   active : whether this lane runs in this pass
 //   st     : state at the pass start (lead == 0 only; the speculative pass starts fresh)
 //   at_s   : out, normalised state when the lane reaches its chunk start s (speculative pass)
 //   at_e   : out, normalised state when the lane reaches its chunk end e (written only when reached)
-//   mn/mx  : min non-zero |x| / max |x| over the lane's own chunk (guard), speculative pass only
-template <int W1, typename T, bool PREFIX>
-__device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char *lds, int lead, bool active,
-                                                      int64_t s, int64_t e, uint32_t K, DetState st,
-                                                      DetState &at_s, DetState &at_e, float &mn, float &mx) {
+template <int W1, typename T>
+__device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, int lead, bool active, int64_t s,
+                                                      int64_t e, uint32_t K, DetState st, DetState &at_s,
+                                                      DetState &at_e) {
     constexpr int W2 = 2 * W1;
     const int64_t n = rc.n;
     const int64_t i_begin = s - lead;
-    RowStream<T, 2> rs;
-    rs.lds = lds;
-    rs.base = rc.base;
-    rs.lo = rc.lo;
-    rs.hi = rc.hi;
-    rs.rb = i_begin - BACK;
-    rs.base_al = rc.vec_ok;
-    const unsigned long long rowmask = __ballot(active);
-    if (rowmask == 0ull) return;
-
-    double A1 = 0, A1q = 0, B1 = 0, B1q = 0, A2 = 0, A2q = 0, B2 = 0, B2q = 0;
-    if (!PREFIX) {
-        rs.load_tile(0, rowmask);
-        rs.load_tile(1, rowmask);
-        if (active) {
-            // direct summation of the four windows around i_begin (row index BACK)
-#pragma unroll
-            for (int k = 1; k <= W2; ++k) {
-                const float x = to_pa(rs.get(BACK - k), rc.sc);
-                const float xq = x * x;
-                A2 = A2 + (double)x; A2q = A2q + (double)xq;
-                if (k <= W1) { A1 = A1 + (double)x; A1q = A1q + (double)xq; }
-            }
-#pragma unroll
-            for (int k = 0; k < W2; ++k) {
-                const float x = to_pa(rs.get(BACK + k), rc.sc);
-                const float xq = x * x;
-                B2 = B2 + (double)x; B2q = B2q + (double)xq;
-                if (k < W1) { B1 = B1 + (double)x; B1q = B1q + (double)xq; }
-            }
-        }
-    }
-
+    if (!__any(active)) return;
     DetState d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : st;
     // bitmap register window: wcur = word of the current index, wprev = the word before it
     unsigned long long wcur = 0ull, wprev = 0ull;
@@ -284,15 +213,10 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
     bool done = !active;
     const int main_steps = lead + (int)K;
     const bool t1_ok = n >= 2 * W1, t2_ok = n >= 2 * W2;
-
     int j = 0;
     for (;; ++j) {
         if (j >= main_steps && !__any(!done)) break;
         const int64_t i = i_begin + j;
-        const int q = j + BACK;
-        if (!PREFIX) {
-            if (((q + W2) & 63) == 0 && j > 0) rs.load_tile((q + W2) >> 6, rowmask);
-        }
         if ((j & 63) == 0 && j > 0 && active) {
             // entering bitmap word (i>>6): retire the word two back
             const int64_t wr = (i >> 6) - 2;
@@ -310,20 +234,15 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
             }
             if (!done) {
                 float v1 = 0.0f, v2 = 0.0f;
-                if (PREFIX) {
-                    if (t1_ok && i >= W1 && i <= n - W1) {
-                        const double p0 = rc.P[i], q0 = rc.P2[i];
-                        v1 = sgk_tstat_fast<W1>(p0 - rc.P[i - W1], q0 - rc.P2[i - W1], rc.P[i + W1] - p0,
-                                                rc.P2[i + W1] - q0);
-                    }
-                    if (t2_ok && i >= W2 && i <= n - W2) {
-                        const double p0 = rc.P[i], q0 = rc.P2[i];
-                        v2 = sgk_tstat_fast<W2>(p0 - rc.P[i - W2], q0 - rc.P2[i - W2], rc.P[i + W2] - p0,
-                                                rc.P2[i + W2] - q0);
-                    }
-                } else {
-                    if (t1_ok && i >= W1 && i <= n - W1) v1 = tstat_from_sums<W1>(A1, A1q, B1, B1q);
-                    if (t2_ok && i >= W2 && i <= n - W2) v2 = tstat_from_sums<W2>(A2, A2q, B2, B2q);
+                if (t1_ok && i >= W1 && i <= n - W1) {
+                    const double p0 = rc.P[i], q0 = rc.P2[i];
+                    v1 = sgk_tstat_ref<W1>(p0 - rc.P[i - W1], q0 - rc.P2[i - W1], rc.P[i + W1] - p0,
+                                           rc.P2[i + W1] - q0);
+                }
+                if (t2_ok && i >= W2 && i <= n - W2) {
+                    const double p0 = rc.P[i], q0 = rc.P2[i];
+                    v2 = sgk_tstat_ref<W2>(p0 - rc.P[i - W2], q0 - rc.P2[i - W2], rc.P[i + W2] - p0,
+                                           rc.P2[i + W2] - q0);
                 }
                 int es, el;
                 det_step<W1>(d, (int)i, v1, v2, es, el);
@@ -340,26 +259,6 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
                 }
             }
         }
-        if (!PREFIX) {
-            if (active) {
-                // slide the four windows from index i to i+1 (exact in double)
-                const float xm2 = to_pa(rs.get(q - W2), rc.sc);
-                const float xm1 = to_pa(rs.get(q - W1), rc.sc);
-                const float x0 = to_pa(rs.get(q), rc.sc);
-                const float xp1 = to_pa(rs.get(q + W1), rc.sc);
-                const float xp2 = to_pa(rs.get(q + W2), rc.sc);
-                const double d0 = (double)x0, d0q = (double)(x0 * x0);
-                A1 = (A1 + d0) - (double)xm1;  A1q = (A1q + d0q) - (double)(xm1 * xm1);
-                A2 = (A2 + d0) - (double)xm2;  A2q = (A2q + d0q) - (double)(xm2 * xm2);
-                B1 = (B1 + (double)xp1) - d0;  B1q = (B1q + (double)(xp1 * xp1)) - d0q;
-                B2 = (B2 + (double)xp2) - d0;  B2q = (B2q + (double)(xp2 * xp2)) - d0q;
-                if (lead > 0 && i >= s && i < e) {
-                    const float ax = fabsf(x0);
-                    mx = fmaxf(mx, ax);
-                    if (ax != 0.0f) mn = fminf(mn, ax);
-                }
-            }
-        }
     }
     if (active) {
         // the last processed index is i_begin + j - 1; the register window holds its word and
@@ -371,80 +270,73 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, char
 }
 
 
-// ================================================================ fast detector pass
-// Same semantics as detect_pass<.., false>, restructured for issue rate:
-//  * window sums come from a register ring of W(p) = sum x[p..p+W1) (and of the float squares):
-//      A1 = W(i-W1), B1 = W(i), A2 = W(i-2W1)+W(i-W1), B2 = W(i)+W(i+W1)        (W2 == 2*W1)
-//    one new W per index: W(i+W1+1) = W(i+W1) + x[i+2W1] - x[i+W1]; the loop is unrolled by the
-//    ring length so every ring index is a compile-time constant (registers, no scratch);
-//  * only the leading sample x[i+2W1] is read from LDS per index (one row tile resident);
-//  * t-statistics use the exact constant-division / certified-rsqrt forms of tstat_math.h;
-//  * the automaton is written with selects (the reference's if/else ladder diverges on every lane);
-//  * all indices are 32-bit (a read has < 2^31 samples, src/misc.c:20).
+// ================================================================ fast detector pass (round 2: "LazyPass")
+// Same semantics as detect_pass, restructured around what the instruction stream costs on gfx950
+// (tools/valu_rate.hip, profiles/r02_valu_rate.txt: plain f32 add/mul/fma, logic and int add issue in 2.3 cycles per
+// wave64 instruction; everything f64, conversions, v_cmp, v_cndmask, v_max/min and packed f32 take 4.45):
+//  * window sums are differences of a RUNNING double prefix sum kept in a register ring (P(i) .. P(i+W2+1)): one
+//    conversion and one addition per sample for the sums and for the float squares, one subtraction per window;
+//    exact under the read-level guard, like every sum of this path;
+//  * the A side of a t-statistic (mean1, sumsq1/w - mean1^2) is what the B side's window sum yields W indices later:
+//    it is evaluated once per window position and ringed (SgkARole), not re-derived from sums;
+//  * the tail |delta| / sqrt(cv/w) is evaluated in f32 with error-free transformations and certified
+//    (sgk_tail_f32); uncertified evaluations (2^-12) are redone with the reference expression;
+//  * the SHORT detector (events.c:383-440, k = 0) runs on every index, written as lane-mask algebra: the
+//    comparisons produce wave masks (scalar registers), the boolean state (in a peak / valid / strong) lives in
+//    masks, only peak_value and peak_pos are selected in vector registers;
+//  * the LONG detector (k = 1) is LAZY.  It is reset whenever the short detector sits in a strong peak
+//    (events.c:414-422) and can only emit if, since that reset, some t-statistic it saw exceeded thr2.  Per index
+//    the kernel proves from cheap f32 estimates that the long window's statistic cannot exceed thr2
+//    (sgk_long_cold); a run (reset .. next reset) in which the proof fails is recorded (2e-4 of the indices on
+//    nanopore data) and re-played with exact arithmetic after the pass (replay_long_runs);
+//  * emitted peaks go to a per-lane 512-position bitmap ring in LDS and leave as whole words.
+// Positions inside a pass are BLOCK-relative (the 16-step unrolled block's first index = 0), so every position the
+// automaton writes is an inline constant; they are rebased once per block.
 template <int W1>
-struct RingCfg {
-    static constexpr int R = (W1 == 3) ? 16 : 32;  // >= 3*W1+1, power of two, divides 64
-    static constexpr int XR = (W1 == 3) ? 4 : 8;   // >= W1+1, power of two
+struct LzCfg {
+    static constexpr int W2 = 2 * W1;
+    static constexpr int R = 16;                    // unroll (multiple of every ring length)
+    static constexpr int NP = (W1 == 3) ? 8 : 16;   // prefix ring >= W2 + 2
+    static constexpr int NA = (W1 == 3) ? 4 : 8;    // short A-side ring >= W1
+    static constexpr int NL = (W1 == 3) ? 8 : 16;   // long side ring >= W2
+    static constexpr int H1 = W1 / 2;
 };
+static_assert(LzCfg<3>::NP >= 8 && LzCfg<7>::NP >= 16, "prefix ring holds P(i) .. P(i+W2+1)");
 
-template <int W1>
-__device__ __forceinline__ int det_step_sel(DetState &d, int i, float v1, float v2) {
-    // Pure boolean algebra on the comparison results (they stay in scalar mask registers) and one
-    // select per state variable; no data-dependent branches.
-    constexpr int W2 = 2 * W1;
-    constexpr float ph = DetParam<W1>::ph, thr1 = DetParam<W1>::thr1, thr2 = DetParam<W1>::thr2;
-    int emit;
-    {   // short detector (masked_to == 0: only index 0 is skipped)
-        const bool on = i > 0;
-        const bool inpk = d.sp >= 0;
-        const bool lower = v1 < d.sv;
-        const bool rise = (v1 - d.sv) > ph;
-        const bool higher = v1 > d.sv;
-        const bool c1 = on & !inpk;   // no peak recorded yet
-        const bool c2 = on & inpk;    // in a peak
-        const bool upd = (c2 & higher) | (c1 & (lower | rise));
-        const bool pos = (c2 & higher) | (c1 & !lower & rise);
-        const float sv = upd ? v1 : d.sv;
-        const int sp = pos ? i : d.sp;
-        const bool strong = sv > thr1;
-        const bool dom = c2 & strong;  // events.c:414-422: the short detector dominates the long one
-        d.lmask = dom ? sp + W1 : d.lmask;
-        d.lp = dom ? -1 : d.lp;
-        d.lv = dom ? FLT_MAX : d.lv;
-        const int lvalid0 = dom ? 0 : d.lvalid;
-        const bool val = (d.svalid != 0) | (c2 & ((sv - v1) > ph) & strong);
-        const bool em = c2 & val & ((i - sp) > W1 / 2);
-        emit = em ? sp : -1;
-        d.sp = em ? -1 : sp;
-        d.sv = em ? v1 : sv;
-        d.svalid = (val & !em) ? 1 : 0;
-        d.lvalid = lvalid0;
-    }
-    {   // long detector
-        const bool on = !(d.lmask >= i);
-        const bool inpk = d.lp >= 0;
-        const bool lower = v2 < d.lv;
-        const bool rise = (v2 - d.lv) > ph;
-        const bool higher = v2 > d.lv;
-        const bool c1 = on & !inpk;
-        const bool c2 = on & inpk;
-        const bool upd = (c2 & higher) | (c1 & (lower | rise));
-        const bool pos = (c2 & higher) | (c1 & !lower & rise);
-        const float lv = upd ? v2 : d.lv;
-        const int lp = pos ? i : d.lp;
-        const bool val = (d.lvalid != 0) | (c2 & ((lv - v2) > ph) & (lv > thr2));
-        const bool em = c2 & val & ((i - lp) > W2 / 2);
-        emit = em ? lp : emit;
-        d.lp = em ? -1 : lp;
-        d.lv = em ? v2 : lv;
-        d.lvalid = (val & !em) ? 1 : 0;
-    }
-    return emit;
+constexpr int LZ_NONE = -(1 << 29);   // "no mask" / far in the past (block-relative positions drift by -16 per block)
+constexpr int LZ_NREC = 8;            // hot long-detector runs a lane can record per pass (more: read -> exact fallback)
+constexpr int LZ_RING_WORDS = 16;     // per-lane bitmap ring: 512 positions
+
+// detector state at a block boundary, absolute (read-relative) positions: what chunks hand over / compare
+struct LzSnapState {
+    int sp;         // short peak_pos, -1 when not in a peak
+    float sv;       // short peak_value
+    int lm;         // long masked_to (= short peak_pos at the last reset + W1), LZ_NONE when it no longer masks
+    int r0;         // index of the last reset of the long detector (pass start of a speculative pass)
+    uint32_t bits;  // 1: in a peak, 2: valid, 4: strong, 8: hot (long run since r0 needs the exact replay)
+};
+struct LzSnap {
+    LzSnapState init[64];  // state a chunk's accepted run started from (at its chunk start)
+    LzSnapState at_e[64];  // state at the chunk end
+    LzSnapState st0[64];   // start state handed to a re-run
+};
+__device__ inline bool lz_equal(const LzSnapState &a, const LzSnapState &b) {
+    return a.sp == b.sp && __float_as_int(a.sv) == __float_as_int(b.sv) && a.lm == b.lm && a.r0 == b.r0 &&
+           a.bits == b.bits;
 }
+struct LzRun {
+    int a, b;  // exact replay of the long detector over [a, b) from the fresh state
+};
+struct LzLds {
+    uint32_t ring[64][LZ_RING_WORDS];
+    LzSnap snap;
+    LzRun runs[64][LZ_NREC];
+    int nrec[64];
+};
 
 // Exact (reference-expression) t-statistic at index i of a read, window sums formed directly from
 // the samples in global memory.  Out of line: only reached when a fast evaluation's certificate
-// fails (about 2^-13 of the evaluations).
+// fails (about 2^-12 of the evaluations) and in the long detector's replay.
 __device__ unsigned long long g_exact_redo_count = 0;  // diagnostics: uncertified evaluations redone
 
 template <typename T>
@@ -477,23 +369,17 @@ struct Lead16<int16_t> {
         const float shifted = (float)v + sc.offf;
         return shifted * sc.unit;
     }
-    template <int U>
-    __device__ __forceinline__ int16_t raw() const {
-        return (int16_t)((U & 1) ? (w[U / 2] >> 16) : (w[U / 2] & 0xffffu));
-    }
 };
 template <>
 struct Lead16<float> {
     float w[16];
     template <int U>
     __device__ __forceinline__ float get(const Scale &) const { return w[U]; }
-    template <int U>
-    __device__ __forceinline__ float raw() const { return w[U]; }
 };
 typedef uint32_t sgk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // Samples in front of a read (the speculative warm-up of its first chunks reaches there) are whatever the caller's
-// buffer holds.  No t-statistic that sees them is used, but they pass through the RUNNING window sums, and a value
+// buffer holds.  No t-statistic that sees them is used, but they pass through the RUNNING prefix sums, and a value
 // far larger than the read's own samples (a neighbour scaled with this read's offset/range) would leave a rounding
 // residue in those double sums for the rest of the chunk.  Every position before the read therefore takes the
 // value of the read's first sample: inside the magnitude range the exactness guard checks.  Rare (first lanes of a
@@ -513,7 +399,8 @@ __device__ __attribute__((noinline)) Lead16<T> lead_fix_head(Lead16<T> g, int po
 // the exact sums the fast pass forms EXCEPT where an inexact addition of the sequential scan ("event"
 // at sample t: prefix[t+1] != prefix[t] + y_t exactly) lies inside the window, i.e. for the indices
 // i in [t-w+1, t+w].  The fast pass therefore runs unchanged on such reads and only those indices
-// (plus uncertified evaluations) are re-evaluated from the scratch prefix arrays.
+// (plus uncertified evaluations) are re-evaluated from the scratch prefix arrays; for the long window they
+// count as "hot" (the run is re-played from the prefix arrays).
 constexpr int REP_MAX_EVENTS = 32;
 struct RepairCtx {
     const double *P, *P2;   // reference prefix arrays (n+1 entries each)
@@ -531,7 +418,7 @@ __device__ __attribute__((noinline)) float tstat_prefix_at(const double *P, cons
     return sgk_tstat_ref<14>(A, A2, B, B2);
 }
 
-// marks (as "redo exactly") the indices q0..q0+3 that lie within a window length of an event
+// marks (as "redo exactly" / "hot") the indices q0..q0+3 that lie within a window length of an event
 template <int W1>
 __device__ __forceinline__ void repair_mark(const RepairCtx &rep, int &next_t, int q0, unsigned cnt1, unsigned cnt2,
                                             unsigned &bad1, unsigned &bad2) {
@@ -559,44 +446,108 @@ __device__ __forceinline__ void repair_mark(const RepairCtx &rep, int &next_t, i
     next_t = nt;
 }
 
-// State of one fast pass.  Every ring access uses a compile-time index (U is a template parameter
-// and the pass starts on a multiple of the ring length), so the arrays live in registers; the R
-// steps of one loop iteration are expanded with fold expressions, four at a time:
-// t-statistics of 4 indices -> (rare, rolled, out of line) exact redo of uncertified ones ->
-// both automata on those 4 indices.
-//
-// Samples are NOT staged through LDS here: each lane loads the 16 leading samples of the next
-// block (x[i+2*W1], 32 bytes) straight from global memory one block ahead.  A wave touches 64
-// different 128-byte lines per load instruction; each line is consumed over 4 consecutive blocks
-// and stays in L2 meanwhile, so HBM traffic remains one pass over the samples and there are no
-// barriers or cooperative loads in the loop.
-template <int W1, typename T, bool FLAGGED>
-struct FastPass {
-    static constexpr int W2 = 2 * W1, R = RingCfg<W1>::R, XR = RingCfg<W1>::XR;
-    static constexpr int NL = R / 16;  // 16-sample lead groups per block
-    double Ws[R], Wq[R];
-    float xs[XR], xq[XR];
-    float t1[4], t2[4];
-    Lead16<T> cur[NL];  // x[ib + W2 .. ib + W2 + R)
-    DetState d;
-    unsigned long long wcur, wprev;
-    unsigned long long *bm;
-    const T *base;
-    int lo, hi;  // legal read-relative load range
-    Scale sc;
-    int n, s, e, ib, wb;
-    unsigned cnt1, cnt2;
-    unsigned bad1, bad2;
-    bool done;
-    RepairCtx rep;   // FLAGGED only
-    int next_t;      // FLAGGED only: smallest event position that can still matter
+// out of line (rare): a peak whose bitmap word may have left the lane's ring, or that lies before the pass
+__device__ __attribute__((noinline)) void lz_emit_slow(uint32_t *ring, unsigned long long *bm, int flushed,
+                                                       int i_begin, int s, int e, int p) {
+    if (p >= flushed && p >= 0) {
+        atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+    } else {
+        const int pa = i_begin + p;
+        if (pa >= s && pa < e) atomicOr(reinterpret_cast<uint32_t *>(bm) + (pa >> 5), 1u << (pa & 31));
+    }
+}
+// out of line (rare): a hot long-detector run [a, b) ended at the reset of index b (or at the read's end, b = n); the
+// lane whose chunk holds index b (for b = n: index n-1) replays it.  Lane c+1 meets the reset at its first index
+// with the state it shares with lane c, so exactly one lane records every run.
+__device__ __attribute__((noinline)) int lz_record(LzRun *runs, int nrec, int a, int b, int s, int e, int n) {
+    if ((b >= s && b < e) || (b == n && e == n && s < n)) {
+        if (nrec < LZ_NREC) {
+            runs[nrec].a = a;
+            runs[nrec].b = b;
+        }
+        ++nrec;
+    }
+    return nrec;
+}
 
-    // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are
-    // redirected to the nearest readable group: whatever value a position yields is used
-    // consistently when it enters and when it leaves a window, and no t-statistic whose window
-    // reaches outside [0, n) is ever used (events.c:332-338).  Positions before the read are
-    // replaced by the read's first sample (lead_fix_head); positions behind it only ever enter the
-    // leading windows after their last used t-statistic.
+// out of line (rare): the uncertified t-statistics of a quad, redone with the reference expression
+struct Redo4 {
+    float v[4];
+};
+template <int W1, typename T, bool FLAGGED>
+__device__ __attribute__((noinline)) Redo4 redo_quad(const T *base, Scale sc, const double *P, const double *P2, int i0,
+                                                     unsigned cnt1, unsigned bits, float t0, float t1, float t2,
+                                                     float t3) {
+    Redo4 r;
+    r.v[0] = t0; r.v[1] = t1; r.v[2] = t2; r.v[3] = t3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((bits >> k) & 1u) {
+            const int i = i0 + k;
+            float v = 0.0f;
+            if ((unsigned)(i - W1) < cnt1) {
+                if constexpr (FLAGGED) v = tstat_prefix_at(P, P2, i, W1);
+                else v = tstat_exact_at<T>(base, sc, i, W1);
+            }
+            r.v[k] = v;
+        }
+    }
+    return r;
+}
+
+typedef unsigned long long lmask_t;  // one bit per lane: lives in a scalar register pair, combined on the scalar unit
+// mask -> per-lane predicate without vector work: selects become v_cndmask with the mask as its condition operand,
+// branches become s_and_saveexec
+__device__ __forceinline__ bool lane_of(lmask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// State of one fast pass.  Every ring access uses a compile-time index (U is a template parameter and the pass
+// starts on a multiple of the unroll length), so the rings live in registers; the 16 steps of one loop iteration
+// are expanded with fold expressions, four at a time: t-statistics of 4 indices -> (rare, rolled, out of line)
+// exact redo of uncertified ones -> the automaton on those 4 indices.
+//
+// Samples are NOT staged through LDS: each lane loads the 16 leading samples of the next block (x[i+W2], 32 bytes)
+// straight from global memory one block ahead.  A wave touches 64 different 128-byte lines per load instruction;
+// each line is consumed over 4 consecutive blocks and stays in L2 meanwhile, so HBM traffic remains one pass over
+// the samples and there are no barriers or cooperative loads in the loop.
+template <int W1, typename T, bool FLAGGED>
+struct LazyPass {
+    using C = LzCfg<W1>;
+    static constexpr int W2 = C::W2, R = C::R, NP = C::NP, NA = C::NA, NL = C::NL, H1 = C::H1;
+    // rings
+    double Ps[NP], Pq[NP];        // running prefix sums of x and of fl(x*x); slot of P(k) = k mod NP
+    SgkARole ar[NA];              // short A side of window position p at slot p mod NA
+    SgkLSide ls[NL];              // long-window estimates of window position p at slot p mod NL
+    float t1[4];                  // t-statistics of the current quad
+    lmask_t nk[4];                // lanes whose t-statistic of the quad's k-th index is not certified
+    lmask_t hc[4];                // lanes whose long window may exceed thr2 at the quad's k-th index
+    Lead16<T> cur;                // x[ib + W2 .. ib + W2 + 16)
+    // short detector (block-relative positions); boolean state as lane masks
+    float sv;
+    int sp;
+    lmask_t inpk, val, strong;
+    lmask_t ph1, ph2, ph3;        // lanes whose peak_pos was set 1, 2, 3 indices ago
+    // lazy long detector
+    int lm, r0;                   // short peak position at the last reset (masked while i <= lm + W1); last reset
+    lmask_t hot;
+    int nrec;
+    // geometry
+    uint32_t *ring;               // this lane's bitmap ring in LDS
+    LzRun *runs;
+    const T *base;
+    int lo, hi;                   // legal read-relative load range
+    Scale sc;
+    int n, s, e, i_begin, ib, jb, flushed;
+    unsigned cnt1, cnt2;
+    lmask_t done;                 // lanes that have nothing left to do (past their chunk, no pending peak)
+    bool slow;                    // wave-uniform: this block takes the predicated steps (read's ends, very old peak)
+    unsigned long long *bm;       // read's bitmap (global)
+    RepairCtx rep;                // FLAGGED only
+    int next_t;                   // FLAGGED only
+
+    // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are redirected to the
+    // nearest readable group: whatever value a position yields is used consistently (it enters the prefix sum once),
+    // and no t-statistic whose window reaches outside [0, n) is ever used (events.c:332-338).  Positions before the
+    // read are replaced by the read's first sample (lead_fix_head).
     __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
         int p = pos > hi - 16 ? hi - 16 : pos;
         p = p < lo ? lo : p;
@@ -609,401 +560,276 @@ struct FastPass {
         if (pos < 0) dst = lead_fix_head<T>(dst, pos, base[0]);
     }
 
-    // phase 1: window sums and both t-statistics of index ib+U; advance the rings
+    // phase 1 of index ib+U: advance the prefix ring, form the window sums, the short window's t-statistic and the
+    // long window's bound.  No predicates: what a block near the read's ends needs is patched per quad (slow_fix).
     template <int U>
     __device__ __forceinline__ void tstep() {
-        const int i = ib + U;
-        const float xn = cur[U / 16].template get<U % 16>(sc);  // leading sample x[i + 2*W1]
+        const float xn = cur.template get<U>(sc);  // x[i + W2]
         const float xqn = xn * xn;
-        const double a1 = Ws[(U - W1) & (R - 1)], a1q = Wq[(U - W1) & (R - 1)];
-        const double b1 = Ws[U & (R - 1)], b1q = Wq[U & (R - 1)];
-        const double a2 = Ws[(U - W2) & (R - 1)] + a1, a2q = Wq[(U - W2) & (R - 1)] + a1q;
-        const double b2 = b1 + Ws[(U + W1) & (R - 1)], b2q = b1q + Wq[(U + W1) & (R - 1)];
-        bool ok1, ok2;
-        float v1, v2;
-        sgk_tstat_try_pair<W1>(a1, a1q, b1, b1q, a2, a2q, b2, b2q, v1, v2, ok1, ok2);
-        const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
-        t1[U & 3] = in1 ? v1 : 0.0f;
-        t2[U & 3] = in2 ? v2 : 0.0f;
-        bad1 |= (in1 && !ok1) ? (1u << (U & 3)) : 0u;
-        bad2 |= (in2 && !ok2) ? (1u << (U & 3)) : 0u;
-        Ws[(U + W1 + 1) & (R - 1)] = (Ws[(U + W1) & (R - 1)] + (double)xn) - (double)xs[(U + W1) & (XR - 1)];
-        Wq[(U + W1 + 1) & (R - 1)] = (Wq[(U + W1) & (R - 1)] + (double)xqn) - (double)xq[(U + W1) & (XR - 1)];
-        xs[(U + W2) & (XR - 1)] = xn;
-        xq[(U + W2) & (XR - 1)] = xqn;
-        // keep the evaluations from being interleaved: their live ranges would otherwise add up
-        // to far more than the register budget; latency is hidden across waves instead
-        __builtin_amdgcn_sched_barrier(0);
+        // P(i+W2+1) = P(i+W2) + x[i+W2]; it replaces P(i-1)
+        Ps[(U + W2 + 1) % NP] = Ps[(U + W2) % NP] + (double)xn;
+        Pq[(U + W2 + 1) % NP] = Pq[(U + W2) % NP] + (double)xqn;
+        const double p0 = Ps[U % NP], q0 = Pq[U % NP];
+        const double b1 = Ps[(U + W1) % NP] - p0, b1q = Pq[(U + W1) % NP] - q0;
+        const double b2 = Ps[(U + W2) % NP] - p0, b2q = Pq[(U + W2) % NP] - q0;
+        // short window: its A side was ringed W1 indices ago
+        bool ok;
+        const float v = sgk_tstat_try_ab<W1>(b1, b1q, ar[(U + NA - W1) % NA], ok);
+        if constexpr (FLAGGED) ok = ok && sgk_try_domain<W1>(b1, b1q, ar[(U + NA - W1) % NA]);
+        ar[U % NA] = sgk_arole<W1>(b1, b1q);
+        // long window: bound only
+        const SgkLSide lb = sgk_lside<W2>(b2, b2q);
+        bool cold = sgk_long_cold<W2>(ls[(U + NL - W2) % NL], lb);
+        if constexpr (FLAGGED) cold = cold && sgk_lside_domain(ls[(U + NL - W2) % NL]) && sgk_lside_domain(lb);
+        ls[U % NL] = lb;
+        t1[U & 3] = v;
+        nk[U & 3] = ~__ballot(ok);
+        hc[U & 3] = ~__ballot(cold);
     }
-    // phase 2: both automata at index ib+U
+
+    // One step of the short detector (events.c:383-440, k = 0) and of the lazy long detector's bookkeeping, on lane
+    // masks.  u: block-relative index (an inline constant in the fast form); live: lanes that take the step.
+    template <bool SLOW>
+    __device__ __forceinline__ void dstep_core(const int u, const float v, const lmask_t hck, const lmask_t live) {
+        constexpr float ph = DetParam<W1>::ph, thr1 = DetParam<W1>::thr1;
+        const float d1 = v - sv;
+        const float ee = lane_of(inpk) ? d1 : -d1;   // in a peak: v - peak_value; before one: peak_value - v
+        lmask_t P = __ballot(ee > 0.0f);             // v > peak_value (in a peak) / v < peak_value (before one)
+        lmask_t Q = __ballot(ee < -ph);              // peak_value - v > ph (in a peak) / v - peak_value > ph
+        const lmask_t Tt = __ballot(v > thr1);
+        if constexpr (SLOW) {
+            P &= live;
+            Q &= live;
+        }
+        const lmask_t ent = Q & ~inpk;                      // a peak starts here: peak_pos = i
+        const lmask_t pos = (inpk & P) | ent;               // peak_pos = i
+        strong = (pos & Tt) | (strong & ~pos);              // peak_value > threshold
+        lmask_t dom = inpk & strong;                        // events.c:414-422: the short detector dominates the long one
+        if constexpr (SLOW) dom &= live;
+        val = inpk & (val | (Q & strong));
+        // (i - peak_pos) > w/2  <=>  peak_pos was not set during the last w/2 indices (nor at this one: ~P)
+        lmask_t recent = ph1;
+        if constexpr (H1 >= 2) recent |= ph2;
+        if constexpr (H1 >= 3) recent |= ph3;
+        lmask_t em = val & ~P & ~recent;
+        if constexpr (SLOW) em &= live;
+        const lmask_t upd = P | ent | em;
+        if (lane_of(em)) {
+            const int p = jb + sp;  // pass-relative position of the emitted peak (in the past)
+            if constexpr (SLOW) lz_emit_slow(ring, bm, flushed, i_begin, s, e, p);
+            else atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+        }
+        sv = lane_of(upd) ? v : sv;
+        sp = lane_of(pos) ? u : sp;
+        inpk = (inpk & ~em) | ent;
+        val = val & ~em;
+        if constexpr (SLOW) {
+            // a frozen lane's history does not age
+            if constexpr (H1 >= 3) ph3 = (ph2 & live) | (ph3 & ~live);
+            if constexpr (H1 >= 2) ph2 = (ph1 & live) | (ph2 & ~live);
+            ph1 = pos | (ph1 & ~live);
+        } else {
+            if constexpr (H1 >= 3) ph3 = ph2;
+            if constexpr (H1 >= 2) ph2 = ph1;
+            ph1 = pos;
+        }
+        // lazy long detector: a reset starts a new run; the run that ends here is recorded if it was hot
+        const lmask_t rec = dom & hot;
+        if (rec != 0ull) {
+            if (lane_of(rec)) nrec = lz_record(runs, nrec, ib + max(r0, lm + W1 + 1), ib + u, s, e, n);
+        }
+        lm = lane_of(dom) ? sp : lm;
+        r0 = lane_of(dom) ? u : r0;
+        lmask_t on = __ballot(lm < u - W1);
+        if constexpr (SLOW) on &= live;
+        hot = (hot & ~dom) | (on & hck);
+    }
     template <int U>
     __device__ __forceinline__ void dstep() {
-        const int i = ib + U;
-        if (!done && (unsigned)i < (unsigned)n) {
-            const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
-            // record the emitted peak if this lane owns its position (selects; the store is the rare case
-            // of a peak older than the two bitmap words held in registers)
-            const bool own = (p >= s) & (p < e);
-            const int wi = p >> 6;
-            const unsigned long long bit = 1ull << (p & 63);
-            wcur |= (own & (wi == wb)) ? bit : 0ull;
-            wprev |= (own & (wi == wb - 1)) ? bit : 0ull;
-            if (own & (wi < wb - 1)) bm[wi] |= bit;  // already retired word, owned by this lane only
+        dstep_core<false>(U, t1[U & 3], hc[U & 3], ~0ull);
+    }
+    // the four steps of a quad in a block near the read's ends (or holding a very old peak): rolled, predicated
+    __device__ __forceinline__ void dsteps_slow(const int u0) {
+        for (int k = 0; k < 4; ++k) {
+            const float v = k == 0 ? t1[0] : (k == 1 ? t1[1] : (k == 2 ? t1[2] : t1[3]));
+            const lmask_t hck = k == 0 ? hc[0] : (k == 1 ? hc[1] : (k == 2 ? hc[2] : hc[3]));
+            // lanes that are done and indices behind the read's end are frozen
+            const lmask_t live = ~done & __ballot((unsigned)(ib + u0 + k) < (unsigned)n);
+            dstep_core<true>(u0 + k, v, hck, live);
         }
     }
+    // the statistic is defined as 0 at the read's first / last W1 indices (events.c:332-338)
+    __device__ __forceinline__ void slow_fix(const int u0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in1 = (unsigned)(ib + u0 + k - W1) < cnt1;
+            t1[k] = in1 ? t1[k] : 0.0f;
+            nk[k] &= __ballot(in1);
+        }
+    }
+
     // four indices U0..U0+3
     template <int U0>
     __device__ __forceinline__ void quad() {
-        bad1 = 0u;
-        bad2 = 0u;
         tstep<U0>();
         tstep<U0 + 1>();
         tstep<U0 + 2>();
         tstep<U0 + 3>();
-        if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
-        // rare: evaluations whose certificate failed are redone with the reference expression
-        if (__any((bad1 | bad2) != 0u))
-        while (__any((bad1 | bad2) != 0u)) {
-            if ((bad1 | bad2) != 0u) {
-                const bool first = bad1 != 0u;
-                const unsigned m = first ? bad1 : bad2;
-                const int u = __ffs((int)m) - 1;
-                float v;
-                if constexpr (FLAGGED) v = tstat_prefix_at(rep.P, rep.P2, ib + U0 + u, first ? W1 : W2);
-                else v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
+        if (slow) slow_fix(U0);
+        if constexpr (FLAGGED) {
+            unsigned bad1 = 0u, bad2 = 0u;
+            repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k == u) {
-                        if (first) t1[k] = v;
-                        else t2[k] = v;
-                    }
-                }
-                if (first) bad1 &= bad1 - 1u;
-                else bad2 &= bad2 - 1u;
+            for (int k = 0; k < 4; ++k) {
+                nk[k] |= __ballot(((bad1 >> k) & 1u) != 0u);
+                hc[k] |= __ballot(((bad2 >> k) & 1u) != 0u);
             }
         }
-        dstep<U0>();
-        dstep<U0 + 1>();
-        dstep<U0 + 2>();
-        dstep<U0 + 3>();
+        // rare: evaluations whose certificate failed are redone with the reference expression
+        const lmask_t anybad = (nk[0] | nk[1] | nk[2] | nk[3]) & ~done;
+        if (anybad != 0ull) {
+            if (lane_of(anybad)) {
+                const unsigned bits = (lane_of(nk[0]) ? 1u : 0u) | (lane_of(nk[1]) ? 2u : 0u) |
+                                      (lane_of(nk[2]) ? 4u : 0u) | (lane_of(nk[3]) ? 8u : 0u);
+                const Redo4 r4 = redo_quad<W1, T, FLAGGED>(base, sc, rep.P, rep.P2, ib + U0, cnt1, bits, t1[0], t1[1],
+                                                           t1[2], t1[3]);
+                t1[0] = r4.v[0]; t1[1] = r4.v[1]; t1[2] = r4.v[2]; t1[3] = r4.v[3];
+            }
+        }
+        if (slow) {
+            dsteps_slow(U0);
+        } else {
+            dstep<U0>();
+            dstep<U0 + 1>();
+            dstep<U0 + 2>();
+            dstep<U0 + 3>();
+        }
     }
+
+    // ---- ring initialisation: prefix sums from the origin o = i_begin - W2 over w[k] = x[o + k], k < 2*W2;
+    // A sides / long estimates of the window positions in front of the first index
+    template <int K>
+    __device__ __forceinline__ void init_step(double &ps, double &pq, const float (&w)[2 * W2], double (&hs)[W2 + 1],
+                                              double (&hq)[W2 + 1]) {
+        const float x = w[K];
+        ps = ps + (double)x;
+        pq = pq + (double)(x * x);
+        constexpr int k1 = K + 1;  // now ps = P(o + k1)
+        if constexpr (k1 <= W2) { hs[k1] = ps; hq[k1] = pq; }
+        if constexpr (k1 >= W2) { Ps[(k1 - W2) % NP] = ps; Pq[(k1 - W2) % NP] = pq; }  // P(i_begin + k1 - W2)
+        // short window position p = o + k1 - W1 in [i_begin - W1, i_begin): sums P(o + k1) - P(o + k1 - W1)
+        if constexpr (k1 >= W2 && k1 < W2 + W1) {
+            constexpr int pr = k1 - W1;
+            ar[((k1 - W1 - W2) % NA + NA) % NA] = sgk_arole<W1>(ps - hs[pr], pq - hq[pr]);
+        }
+        // long window position p = o + k1 - W2 in [i_begin - W2, i_begin)
+        if constexpr (k1 >= W2 && k1 < 2 * W2) {
+            constexpr int pr = k1 - W2;
+            ls[((k1 - 2 * W2) % NL + NL) % NL] = sgk_lside<W2>(ps - hs[pr], pq - hq[pr]);
+        }
+    }
+    template <int... Ks>
+    __device__ __forceinline__ void init_rings(const float (&w)[2 * W2], std::integer_sequence<int, Ks...>) {
+        double ps = 0.0, pq = 0.0;
+        double hs[W2 + 1], hq[W2 + 1];
+        hs[0] = 0.0;
+        hq[0] = 0.0;
+        (init_step<Ks>(ps, pq, w, hs, hq), ...);
+    }
+
     template <int... Qs>
     __device__ __forceinline__ void block(std::integer_sequence<int, Qs...>) {
         (quad<4 * Qs>(), ...);
     }
-
-    template <int K0>
-    __device__ __forceinline__ void init_w(double &a, double &aq, const float (&w)[4 * W1]) {
-        // W(p+1) from W(p), p = i_begin - 2*W1 + K0; w[k] = x[i_begin - 2*W1 + k]
-        const float xin = w[K0 + W1], xout = w[K0];
-        a = (a + (double)xin) - (double)xout;
-        aq = (aq + (double)(xin * xin)) - (double)(xout * xout);
-        Ws[(-W2 + K0 + 1) & (R - 1)] = a;
-        Wq[(-W2 + K0 + 1) & (R - 1)] = aq;
-    }
-    template <int... Ks>
-    __device__ __forceinline__ void init_ws(double &a, double &aq, const float (&w)[4 * W1],
-                                            std::integer_sequence<int, Ks...>) {
-        (init_w<Ks>(a, aq, w), ...);
-    }
 };
 
+// flush 8 ring words (the 256 positions starting at pass-relative position p0, a multiple of 256) of this lane to
+// the read's bitmap; only words inside the lane's own range [own_lo, own_hi) (pass-relative; multiples of 64, or the
+// read's end) are written -- every owned word is written exactly once per pass, zero or not
+__device__ __forceinline__ void lz_flush(uint32_t *ring, unsigned long long *bm, int i_begin, int p0, int own_lo,
+                                         int own_hi) {
+    uint32_t *bm32 = reinterpret_cast<uint32_t *>(bm);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int p = p0 + 32 * k;
+        const int wi = (p >> 5) & (LZ_RING_WORDS - 1);
+        const uint32_t w = ring[wi];
+        ring[wi] = 0u;
+        if (p >= own_lo && p < own_hi) bm32[(i_begin + p) >> 5] = w;
+    }
+}
+
+// One pass of the lazy detector over the wave's chunks.
+//   lead   : samples each lane starts before its chunk start (speculative pass), 0 for a re-run from snap.st0
+//   active : whether this lane runs in this pass
+// Writes the lane's bitmap words, its hot-run records and (speculative pass) snap.init / snap.at_e.
 template <int W1, typename T, bool FLAGGED>
-__device__ __forceinline__ void pass_fast(const ReadCtx<T> &rc, int lead, bool active, int s, int e, int K,
-                                          DetSnap *snap, const RepairCtx *rep) {
-    using FP = FastPass<W1, T, FLAGGED>;
-    constexpr int W2 = FP::W2, R = FP::R, XR = FP::XR, NL = FP::NL;
+__device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, int lead, bool active, int s, int e, int K,
+                                          LzLds *L, const RepairCtx *rep) {
+    using LP = LazyPass<W1, T, FLAGGED>;
+    constexpr int W2 = LP::W2, R = LP::R;
     if (!__any(active)) return;
-    FP f;
+    const int l = lane_id();
+    LP f;
     f.n = (int)rc.n;
-    f.s = s;
-    f.e = e;
+    // lanes that do not take part in the pass own nothing: nothing they emit or record can land anywhere
+    f.s = active ? s : 0x7fffffff;
+    f.e = active ? e : 0x7fffffff;
     f.bm = rc.bm;
     f.sc = rc.sc;
     f.base = rc.base;
     f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
     f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
+    f.ring = L->ring[l];
+    f.runs = L->runs[l];
     const int n = f.n;
     const int i_begin = s - lead;  // multiple of 64
-
-    // ring slots are addressed by (position - i_begin) & (R-1); i_begin is a multiple of R
+    f.i_begin = i_begin;
 #pragma unroll
-    for (int k = 0; k < R; ++k) { f.Ws[k] = 0.0; f.Wq[k] = 0.0; }
+    for (int k = 0; k < LZ_RING_WORDS; ++k) f.ring[k] = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.t2[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.nk[k] = 0ull; f.hc[k] = 0ull; }
     {
-        // x[i_begin - 2*W1 .. i_begin + 2*W1): W(i_begin-2*W1), then slide to W(i_begin+W1); x ring
-        float w[4 * W1];
+        // x[i_begin - W2 .. i_begin + W2): prefix sums from the origin i_begin - W2
+        float w[2 * W2];
 #pragma unroll
-        for (int k = 0; k < 4 * W1; ++k) {
+        for (int k = 0; k < 2 * W2; ++k) {
             int p = i_begin - W2 + k;
             p = p > f.hi - 1 ? f.hi - 1 : p;
             p = p < 0 ? 0 : p;  // positions before the read: its first sample (see lead_fix_head)
             w[k] = to_pa(f.base[p], f.sc);
         }
-        double a = 0.0, aq = 0.0;
 #pragma unroll
-        for (int k = 0; k < W1; ++k) {
-            a = a + (double)w[k];
-            aq = aq + (double)(w[k] * w[k]);
-        }
-        f.Ws[(-W2) & (R - 1)] = a;
-        f.Wq[(-W2) & (R - 1)] = aq;
-        f.init_ws(a, aq, w, std::make_integer_sequence<int, 3 * W1>{});
-#pragma unroll
-        for (int k = 0; k < XR; ++k) { f.xs[k] = 0.0f; f.xq[k] = 0.0f; }
-#pragma unroll
-        for (int k = 0; k < W1; ++k) {  // x[i_begin + W1 + k]
-            f.xs[(W1 + k) & (XR - 1)] = w[W2 + W1 + k];
-            f.xq[(W1 + k) & (XR - 1)] = w[W2 + W1 + k] * w[W2 + W1 + k];
-        }
+        for (int k = 0; k < LP::NP; ++k) { f.Ps[k] = 0.0; f.Pq[k] = 0.0; }
+        f.init_rings(w, std::make_integer_sequence<int, 2 * W2>{});
     }
-    // leading samples of the first block
-#pragma unroll
-    for (int g = 0; g < NL; ++g) f.load_lead(f.cur[g], i_begin + W2 + 16 * g);
-
-    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : snap->st0[lane_id()];
-    f.wcur = 0ull;
-    f.wprev = 0ull;
-    const int wlo = s >> 6, whi = (e + 63) >> 6;
-    f.done = !active;
-    if constexpr (FLAGGED) {
-        f.rep = *rep;
-        // first event whose influence [t-W2+1, t+W2] is not entirely before this pass' first index
-        f.next_t = 0x7fffffff;
-        for (int k = 0; k < f.rep.nev; ++k) {
-            const int t = f.rep.ev[k];
-            if (t + W2 >= i_begin && t < f.next_t) f.next_t = t;
-        }
-    }
-    const int main_steps = lead + K;
-    f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
-    f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
-
-    int jb = 0;
-    for (;; jb += R) {
-        if (jb >= main_steps && !__any(!f.done)) break;
-        const int ib = i_begin + jb;
-        const int wb = ib >> 6;  // bitmap word of every index of this block (R divides 64)
-        if ((jb & 63) == 0 && jb > 0 && active) {
-            const int wr = wb - 2;
-            if (wr >= wlo && wr < whi) f.bm[wr] = f.wprev;
-            f.wprev = f.wcur;
-            f.wcur = 0ull;
-        }
-        if (active) {
-            // state snapshots live in LDS (they are only needed after the pass): frees ~28 VGPRs
-            if (lead > 0 && jb == lead) snap->init[lane_id()] = det_norm(f.d, ib);
-            if (ib == e) snap->at_e[lane_id()] = det_norm(f.d, ib);
-            if (ib >= e) {
-                const bool pend = (f.d.sp >= 0 && f.d.sp < e) || (f.d.lp >= 0 && f.d.lp < e);
-                if (!pend || ib >= n) f.done = true;  // the reference's loop ends at n-1: pending peaks are dropped
-            }
-        }
-        f.ib = ib;
-        f.wb = wb;
-        // issue the loads of the NEXT block's leading samples now; consumed one iteration later
-        Lead16<T> nxt[NL];
-#pragma unroll
-        for (int g = 0; g < NL; ++g) f.load_lead(nxt[g], ib + R + W2 + 16 * g);
-        f.block(std::make_integer_sequence<int, R / 4>{});
-#pragma unroll
-        for (int g = 0; g < NL; ++g) f.cur[g] = nxt[g];
-    }
-    if (active) {
-        const int wbl = (i_begin + jb - 1) >> 6;  // word of the last processed index
-        if (wbl - 1 >= wlo && wbl - 1 < whi) f.bm[wbl - 1] = f.wprev;
-        if (wbl >= wlo && wbl < whi) f.bm[wbl] = f.wcur;
-    }
-}
-
-// ---------------------------------------------------------------- fast pass, LDS-history variant
-// Same contract as pass_fast.  Instead of a register ring of partial window sums (which needs a
-// 3*W1+1 deep ring and an unroll by its length: too much for W1 = 7), it keeps the eight running
-// window sums and reads the four trailing samples x[i-2W1], x[i-W1], x[i], x[i+W1] from a per-lane
-// history ring in LDS (64 raw samples per lane; the leading 16-sample group of each block is
-// written into it once).  16-step unroll for every window size.
-template <typename T>
-struct HistRing {
-    static constexpr int ROW_BYTES = 64 * (int)sizeof(T) + 4;  // odd dword stride: conflict-free lane-per-row
-    static constexpr int LDS_BYTES = 64 * ROW_BYTES;
-};
-
-template <int W1, typename T, bool FLAGGED>
-struct FastPassL {
-    static constexpr int W2 = 2 * W1;
-    double A1, A1q, B1, B1q, A2, A2q, B2, B2q;
-    float t1[4], t2[4];
-    Lead16<T> cur;
-    DetState d;
-    unsigned long long wcur, wprev;
-    unsigned long long *bm;
-    const T *base;
-    char *row;   // this lane's history row in LDS; ring index of position p is (p - W2) & 63
-    int lo, hi;
-    Scale sc;
-    int n, s, e, ib, wb;
-    unsigned cnt1, cnt2;
-    unsigned bad1, bad2;
-    bool done;
-    RepairCtx rep;   // FLAGGED only
-    int next_t;      // FLAGGED only: smallest event position that can still matter
-
-    __device__ __forceinline__ void load_lead(Lead16<T> &dst, int pos) const {
-        int p = pos > hi - 16 ? hi - 16 : pos;
-        p = p < lo ? lo : p;
-        constexpr int NV = 16 * (int)sizeof(T) / 16;
-        const sgk_u32x4_a4 *src = reinterpret_cast<const sgk_u32x4_a4 *>(base + p);
-        sgk_u32x4_a4 v[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = src[k];
-        __builtin_memcpy(dst.w, v, sizeof(dst.w));
-        if (pos < 0) dst = lead_fix_head<T>(dst, pos, base[0]);
-    }
-    __device__ __forceinline__ T raw_hist(int pos) const {  // stored sample at pos (within the resident window)
-        return *reinterpret_cast<const T *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
-    }
-    __device__ __forceinline__ float hist(int pos) const { return to_pa(raw_hist(pos), sc); }
-    __device__ __forceinline__ void store_group(const Lead16<T> &g, int pos) {  // x[pos..pos+16), pos-W2 multiple of 16
-        uint32_t *dst = reinterpret_cast<uint32_t *>(row + (((pos - W2) & 63) * (int)sizeof(T)));
-        constexpr int ND = 16 * (int)sizeof(T) / 4;
-        uint32_t tmp[ND];
-        __builtin_memcpy(tmp, g.w, sizeof(tmp));
-#pragma unroll
-        for (int k = 0; k < ND; ++k) dst[k] = tmp[k];
-    }
-
-    template <int U>
-    __device__ __forceinline__ void tstep() {
-        const int i = ib + U;
-        bool ok1, ok2;
-        float v1, v2;
-        sgk_tstat_try_pair<W1>(A1, A1q, B1, B1q, A2, A2q, B2, B2q, v1, v2, ok1, ok2);
-        const bool in1 = (unsigned)(i - W1) < cnt1, in2 = (unsigned)(i - W2) < cnt2;
-        t1[U & 3] = in1 ? v1 : 0.0f;
-        t2[U & 3] = in2 ? v2 : 0.0f;
-        bad1 |= (in1 && !ok1) ? (1u << (U & 3)) : 0u;
-        bad2 |= (in2 && !ok2) ? (1u << (U & 3)) : 0u;
-        // slide the four windows from index i to i+1 (exact in double); pA conversion and squares of
-        // the five samples involved on packed pairs
-        const f32x2 xm = to_pa2(raw_hist(i - W2), raw_hist(i - W1), sc);        // x[i-2W1], x[i-W1]
-        const f32x2 xp = to_pa2(raw_hist(i + W1), cur.template raw<U>(), sc);   // x[i+W1], x[i+2W1]
-        const float x0 = to_pa(raw_hist(i), sc);
-        const f32x2 xmq = xm * xm, xpq = xp * xp;
-        const double d0 = (double)x0, d0q = (double)(x0 * x0);
-        A1 = (A1 + d0) - (double)xm.y;  A1q = (A1q + d0q) - (double)xmq.y;
-        A2 = (A2 + d0) - (double)xm.x;  A2q = (A2q + d0q) - (double)xmq.x;
-        B1 = (B1 + (double)xp.x) - d0;  B1q = (B1q + (double)xpq.x) - d0q;
-        B2 = (B2 + (double)xp.y) - d0;  B2q = (B2q + (double)xpq.y) - d0q;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    template <int U>
-    __device__ __forceinline__ void dstep() {
-        const int i = ib + U;
-        if (!done && (unsigned)i < (unsigned)n) {
-            const int p = det_step_sel<W1>(d, i, t1[U & 3], t2[U & 3]);
-            // record the emitted peak if this lane owns its position (selects; the store is the rare case
-            // of a peak older than the two bitmap words held in registers)
-            const bool own = (p >= s) & (p < e);
-            const int wi = p >> 6;
-            const unsigned long long bit = 1ull << (p & 63);
-            wcur |= (own & (wi == wb)) ? bit : 0ull;
-            wprev |= (own & (wi == wb - 1)) ? bit : 0ull;
-            if (own & (wi < wb - 1)) bm[wi] |= bit;  // already retired word, owned by this lane only
-        }
-    }
-    template <int U0>
-    __device__ __forceinline__ void quad() {
-        bad1 = 0u;
-        bad2 = 0u;
-        tstep<U0>();
-        tstep<U0 + 1>();
-        tstep<U0 + 2>();
-        tstep<U0 + 3>();
-        if constexpr (FLAGGED) repair_mark<W1>(rep, next_t, ib + U0, cnt1, cnt2, bad1, bad2);
-        if (__any((bad1 | bad2) != 0u))
-        while (__any((bad1 | bad2) != 0u)) {
-            if ((bad1 | bad2) != 0u) {
-                const bool first = bad1 != 0u;
-                const unsigned m = first ? bad1 : bad2;
-                const int u = __ffs((int)m) - 1;
-                float v;
-                if constexpr (FLAGGED) v = tstat_prefix_at(rep.P, rep.P2, ib + U0 + u, first ? W1 : W2);
-                else v = tstat_exact_at<T>(base, sc, ib + U0 + u, first ? W1 : W2);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k == u) {
-                        if (first) t1[k] = v;
-                        else t2[k] = v;
-                    }
-                }
-                if (first) bad1 &= bad1 - 1u;
-                else bad2 &= bad2 - 1u;
-            }
-        }
-        dstep<U0>();
-        dstep<U0 + 1>();
-        dstep<U0 + 2>();
-        dstep<U0 + 3>();
-    }
-};
-
-template <int W1, typename T, bool FLAGGED>
-__device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_lds, int lead, bool active, int s,
-                                              int e, int K, DetSnap *snap, const RepairCtx *rep) {
-    using FP = FastPassL<W1, T, FLAGGED>;
-    constexpr int W2 = FP::W2, R = 16;
-    if (!__any(active)) return;
-    FP f;
-    f.n = (int)rc.n;
-    f.s = s;
-    f.e = e;
-    f.bm = rc.bm;
-    f.sc = rc.sc;
-    f.base = rc.base;
-    f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
-    f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
-    f.row = hist_lds + lane_id() * HistRing<T>::ROW_BYTES;
-    const int n = f.n;
-    const int i_begin = s - lead;  // multiple of 64
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.t2[k] = 0.0f; }
-    // history: x[i_begin - 2*W2 .. i_begin + W2) must be resident before the first block; fill the
-    // three 16-sample groups that cover it (ring indices (p - W2) & 63)
-#pragma unroll
-    for (int g = -3; g < 0; ++g) {
-        Lead16<T> tmp;
-        f.load_lead(tmp, i_begin + W2 + 16 * g);
-        f.store_group(tmp, i_begin + W2 + 16 * g);
-    }
+    // leading samples of the first block: x[i_begin + W2 .. +16)
     f.load_lead(f.cur, i_begin + W2);
-    __syncthreads();
-    // window sums at i_begin by direct summation from the history ring
-    f.A1 = f.A1q = f.B1 = f.B1q = f.A2 = f.A2q = f.B2 = f.B2q = 0.0;
-#pragma unroll
-    for (int k = 1; k <= W2; ++k) {
-        const float x = f.hist(i_begin - k);
-        const float xq = x * x;
-        f.A2 = f.A2 + (double)x; f.A2q = f.A2q + (double)xq;
-        if (k <= W1) { f.A1 = f.A1 + (double)x; f.A1q = f.A1q + (double)xq; }
-    }
-    // B windows: x[i_begin .. i_begin+W2) is the tail of the three groups just stored.  They MUST come from
-    // the ring as well: a group that load_lead had to redirect (chunk 0 of a read with exactly `lead` samples
-    // of head room) holds shifted samples, and every value has to leave a window sum as the same number it
-    // entered with -- the running sums never reset, so one mismatch would stay in them for the whole chunk.
-#pragma unroll
-    for (int k = 0; k < W2; ++k) {
-        const float x = f.hist(i_begin + k);
-        const float xq = x * x;
-        f.B2 = f.B2 + (double)x; f.B2q = f.B2q + (double)xq;
-        if (k < W1) { f.B1 = f.B1 + (double)x; f.B1q = f.B1q + (double)xq; }
-    }
 
-    f.d = (lead > 0) ? det_fresh(i_begin <= 0 ? 0 : -1) : snap->st0[lane_id()];
-    f.wcur = 0ull;
-    f.wprev = 0ull;
-    const int wlo = s >> 6, whi = (e + 63) >> 6;
-    f.done = !active;
+    // detector state
+    f.sv = FLT_MAX;
+    f.sp = 0;
+    f.inpk = 0ull; f.val = 0ull; f.strong = 0ull; f.hot = 0ull;
+    f.ph1 = 0ull; f.ph2 = 0ull; f.ph3 = 0ull;
+    f.lm = LZ_NONE;
+    f.r0 = i_begin < 0 ? -i_begin : 0;  // the (pseudo) reset a speculative pass starts from; index 0 for chunk 0
+    if (lead == 0) {
+        const LzSnapState st = L->snap.st0[l];
+        f.sv = st.sv;
+        f.inpk = __ballot((st.bits & 1u) != 0u);
+        f.val = __ballot((st.bits & 2u) != 0u);
+        f.strong = __ballot((st.bits & 4u) != 0u);
+        f.hot = __ballot((st.bits & 8u) != 0u);
+        f.sp = (st.bits & 1u) ? st.sp - i_begin : 0;
+        f.lm = st.lm == LZ_NONE ? LZ_NONE : st.lm - W1 - i_begin;  // handed over as masked_to; kept as the peak position
+        f.ph1 = __ballot((st.bits & 1u) && st.sp == i_begin - 1);
+        f.ph2 = __ballot((st.bits & 1u) && st.sp == i_begin - 2);
+        f.ph3 = __ballot((st.bits & 1u) && st.sp == i_begin - 3);
+        f.r0 = st.r0 - i_begin;
+    }
+    f.nrec = 0;
+    f.done = ~__ballot(active);
+    f.flushed = 0;
     if constexpr (FLAGGED) {
         f.rep = *rep;
         // first event whose influence [t-W2+1, t+W2] is not entirely before this pass' first index
@@ -1016,63 +842,137 @@ __device__ __forceinline__ void pass_fast_lds(const ReadCtx<T> &rc, char *hist_l
     const int main_steps = lead + K;
     f.cnt1 = (n - 2 * W1 + 1) > 0 ? (unsigned)(n - 2 * W1 + 1) : 0u;
     f.cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
+    // pass-relative range of the positions this lane owns (its bitmap words)
+    const int own_lo = lead, own_hi = active ? lead + (e - s) : lead;
+
+    auto snapshot = [&](int ib) -> LzSnapState {
+        // ib: absolute index of the block about to start (positions are relative to it)
+        LzSnapState st;
+        const bool ip = lane_of(f.inpk);
+        st.sv = f.sv;
+        st.sp = ip ? ib + f.sp : -1;
+        st.lm = (f.lm + W1 < 0) ? LZ_NONE : ib + f.lm + W1;  // normalised when it no longer masks
+        st.r0 = ib + f.r0;
+        st.bits = (ip ? 1u : 0u) | ((ip && lane_of(f.val)) ? 2u : 0u) | ((ip && lane_of(f.strong)) ? 4u : 0u) |
+                  (lane_of(f.hot) ? 8u : 0u);
+        return st;
+    };
 
     int jb = 0;
     for (;; jb += R) {
-        if (jb >= main_steps && !__any(!f.done)) break;
+        if (jb >= main_steps && f.done == ~0ull) break;
         const int ib = i_begin + jb;
-        const int wb = ib >> 6;
-        if ((jb & 63) == 0 && jb > 0 && active) {
-            const int wr = wb - 2;
-            if (wr >= wlo && wr < whi) f.bm[wr] = f.wprev;
-            f.wprev = f.wcur;
-            f.wcur = 0ull;
+        if ((jb & 255) == 0 && jb >= 512) {
+            lz_flush(f.ring, f.bm, i_begin, jb - 512, own_lo, own_hi);
+            f.flushed = jb - 256;
         }
-        if (active) {
-            if (lead > 0 && jb == lead) snap->init[lane_id()] = det_norm(f.d, ib);
-            if (ib == e) snap->at_e[lane_id()] = det_norm(f.d, ib);
-            if (ib >= e) {
-                const bool pend = (f.d.sp >= 0 && f.d.sp < e) || (f.d.lp >= 0 && f.d.lp < e);
-                if (!pend || ib >= n) f.done = true;
-            }
+        {
+            // state snapshots live in LDS (they are only needed after the pass)
+            if (active && lead > 0 && jb == lead) L->snap.init[l] = snapshot(ib);
+            if (active && ib == e) L->snap.at_e[l] = snapshot(ib);
+            const bool pend = lane_of(f.inpk) && (ib + f.sp) < e;
+            // the reference's loop ends at n-1: peaks still pending there are dropped
+            f.done |= __ballot(ib >= e && (!pend || ib >= n));
         }
+        // blocks that touch indices whose statistic is defined as 0, or the end of the read, take the predicated
+        // forms of the steps; so does a block in which some lane holds a peak older than the bitmap ring reaches
+        const bool lane_edge = ib < W1 || ib + R - 1 > n - W1;
+        const bool old_peak = f.sp < -(256 - 2 * R) || f.sp + jb < 0;
+        f.slow = ((__ballot(lane_edge) | (__ballot(old_peak) & f.inpk)) & ~f.done) != 0ull;
         f.ib = ib;
-        f.wb = wb;
-        // publish this block's leading group to the history ring (it becomes x[i+W1], x[i], ... later)
-        f.store_group(f.cur, ib + W2);
+        f.jb = jb;
+        // issue the loads of the NEXT block's leading samples now; consumed one iteration later
         Lead16<T> nxt;
         f.load_lead(nxt, ib + R + W2);
-        __syncthreads();
-        f.template quad<0>();
-        f.template quad<4>();
-        f.template quad<8>();
-        f.template quad<12>();
+        f.block(std::make_integer_sequence<int, R / 4>{});
         f.cur = nxt;
+        // rebase the block-relative positions
+        f.sp -= R;
+        f.lm = f.lm < LZ_NONE ? LZ_NONE : f.lm - R;
+        f.r0 -= R;
     }
-    if (active) {
-        const int wbl = (i_begin + jb - 1) >> 6;
-        if (wbl - 1 >= wlo && wbl - 1 < whi) f.bm[wbl - 1] = f.wprev;
-        if (wbl >= wlo && wbl < whi) f.bm[wbl] = f.wcur;
+    // the run still open at the end of the read is replayed by the lane that holds the read's last index
+    if (active && lane_of(f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, i_begin + jb + max(f.r0, f.lm + W1 + 1), n, s, e, n);
+    // remaining ring words
+    for (int p0 = f.flushed; p0 < jb; p0 += 256) lz_flush(f.ring, f.bm, i_begin, p0, own_lo, own_hi);
+    if (active) L->nrec[l] = f.nrec;
+}
+
+// Exact replay of the long detector (events.c:383-440, k = 1) over the recorded hot runs: from the fresh state a
+// reset leaves, over the indices of the run (inside a run masked_to does not change and every index is processed).
+template <int W1, typename T, bool FLAGGED>
+__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active) {
+    constexpr int W2 = 2 * W1;
+    constexpr float ph = DetParam<W1>::ph, thr2 = DetParam<W1>::thr2;
+    const int l = lane_id();
+    const int n = (int)rc.n;
+    const unsigned cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
+    const int nrec = active ? L->nrec[l] : 0;
+    uint32_t *bm32 = reinterpret_cast<uint32_t *>(rc.bm);
+    for (int k = 0; k < LZ_NREC; ++k) {
+        const bool has = k < nrec;
+        if (!__any(has)) break;
+        int i = has ? L->runs[l][k].a : 0;
+        const int b = has ? L->runs[l][k].b : 0;
+        int lp = -1;
+        float lv = FLT_MAX;
+        bool lvalid = false;
+        while (__any(has && i < b)) {
+            if (has && i < b) {
+                float v2 = 0.0f;
+                if ((unsigned)(i - W2) < cnt2) {
+                    if constexpr (FLAGGED) v2 = tstat_prefix_at(rep->P, rep->P2, i, W2);
+                    else v2 = tstat_exact_at<T>(rc.base, rc.sc, i, W2);
+                }
+                if (lp < 0) {
+                    if (v2 < lv) {
+                        lv = v2;
+                    } else if (v2 - lv > ph) {
+                        lv = v2;
+                        lp = i;
+                    }
+                } else {
+                    if (v2 > lv) {
+                        lv = v2;
+                        lp = i;
+                    }
+                    if (lv - v2 > ph && lv > thr2) lvalid = true;
+                    if (lvalid && (i - lp) > W2 / 2) {
+                        if (lp > 0 && lp < n) atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
+                        lp = -1;
+                        lv = v2;
+                        lvalid = false;
+                    }
+                }
+                ++i;
+            }
+        }
     }
 }
 
-// speculative pass + verification / re-run loop (one inlined copy of pass_fast)
+// speculative pass + verification / re-run loop + replay of the hot long-detector runs.
+// Returns 0 when the read is done, 1 when the fast pass cannot take it (alignment / room around the read), 2 when
+// a lane met more hot runs than it can record (pathological signal: constant stretches, tiny variances).
 template <int W1, typename T, bool FLAGGED>
-__device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *snap, char *hist_lds,
-                                 const RepairCtx *rep) {
+__device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep) {
     const int n = (int)rc.n;
-    if (n <= 0) return true;
-    // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 64 readable samples
+    if (n <= 0) return 0;
+    // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs `lead` readable samples
     // before the read (speculative warm-up of chunk 0) and 16 after it; other reads (e.g. a read at
     // the very start of a caller's buffer) take the exact fallback
-    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -((W1 == 7) ? SGK_LEAD_RNA : LEAD) || rc.hi < (int64_t)n + 16) return false;
+    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -((W1 == 7) ? SGK_LEAD_RNA : LEAD) || rc.hi < (int64_t)n + 16) return 1;
     const int K = (int)chunk_len(n);
     const int c = lane_id();
     const int s = c * K;
     const int e = (s + K < n) ? s + K : n;
     const bool active = (int64_t)c * K < (int64_t)n;
-    snap->init[c] = det_fresh(0);
-    snap->at_e[c] = det_fresh(0);
+    {
+        LzSnapState z;
+        z.sp = -1; z.sv = FLT_MAX; z.lm = LZ_NONE; z.r0 = 0; z.bits = 0u;
+        L->snap.init[c] = z;
+        L->snap.at_e[c] = z;
+        L->nrec[c] = 0;
+    }
     // speculative warm-up before every chunk.  RNA events are ~5x longer, so the automata converge later: with 64
     // samples ~1.4 % of the chunk boundaries need a re-run, with 256 about 0.002 %.  A re-run costs the wave one
     // more pass over a chunk (K samples), the warm-up costs `lead` samples per lane: short reads (small K) are
@@ -1081,30 +981,39 @@ __device__ bool detect_read_fast(const ReadCtx<T> &rc, EvHeader *hdr, DetSnap *s
     if (W1 == 7) lead = K <= 128 ? 64 : (K <= 512 ? 128 : SGK_LEAD_RNA);
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
-        if constexpr (USE_LDS_HISTORY(W1)) pass_fast_lds<W1, T, FLAGGED>(rc, hist_lds, lead, run, s, e, K, snap, rep);
-        else pass_fast<W1, T, FLAGGED>(rc, lead, run, s, e, K, snap, rep);
+        pass_lazy<W1, T, FLAGGED>(rc, lead, run, s, e, K, L, rep);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
-        const DetState pe = snap->at_e[c > 0 ? c - 1 : 0];
-        const DetState mine = snap->init[c];
-        const bool bad = active && c > 0 && !det_equal(pe, mine);
+        const LzSnapState pe = L->snap.at_e[c > 0 ? c - 1 : 0];
+        const LzSnapState mine = L->snap.init[c];
+        const bool bad = active && c > 0 && !lz_equal(pe, mine);
         const unsigned long long badmask = __ballot(bad);
         if (badmask == 0ull) break;
         __syncthreads();
         if (bad) {
-            snap->init[c] = pe;
-            snap->st0[c] = pe;
+            L->snap.init[c] = pe;
+            L->snap.st0[c] = pe;
         }
         run = bad;
         lead = 0;
         if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
         __syncthreads();
     }
-    return true;
+    if (__any(active && L->nrec[c] > LZ_NREC)) return 2;
+    const unsigned long long hotm = __ballot(active && L->nrec[c] > 0);
+    if (hotm != 0ull) {
+        if (c == 0) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
+        __threadfence_block();
+        __syncthreads();  // every lane's bitmap words are in memory before the replay ORs into them
+        replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active);
+    }
+    return 0;
 }
 
 __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
     if (!(mx > 0.0f)) return true;  // all samples zero
+    // range in which the certified arithmetic of tstat_math.h (sgk_tstat_try_ab) has no subnormal intermediates
+    if (mn < 9.5367431640625e-07f || mx > 1048576.0f) return false;
     const int eb = ilogb((double)n * (double)mx), em = ilogb((double)mn);
     if (eb - em > 29) return false;
     const float mnq = mn * mn, mxq = mx * mx;
@@ -1113,12 +1022,11 @@ __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
     return ebq - emq <= 29;
 }
 
-// Detector over one read by one wave.  Returns true when the exactness guard fails
-// (fast path only).
-template <int W1, typename T, bool PREFIX>
-__device__ bool detect_read(const ReadCtx<T> &rc, char *lds, EvHeader *hdr) {
+// Generic detector over one read by one wave (prefix arrays required).
+template <int W1, typename T>
+__device__ void detect_read(const ReadCtx<T> &rc, EvHeader *hdr) {
     const int64_t n = rc.n;
-    if (n <= 0) return false;
+    if (n <= 0) return;
     const uint32_t K = chunk_len(n);
     const int c = lane_id();
     const int64_t s = (int64_t)c * K;
@@ -1126,8 +1034,7 @@ __device__ bool detect_read(const ReadCtx<T> &rc, char *lds, EvHeader *hdr) {
     const bool active = s < n;
     const DetState fresh = det_fresh(0);
     DetState at_s = fresh, at_e = fresh;
-    float mn = FLT_MAX, mx = 0.0f;
-    detect_pass<W1, T, PREFIX>(rc, lds, LEAD, active, s, e, K, fresh, at_s, at_e, mn, mx);
+    detect_pass<W1, T>(rc, LEAD, active, s, e, K, fresh, at_s, at_e);
     DetState init = at_s;
     for (int iter = 0; iter < 64; ++iter) {
         const DetState pe = det_shfl_up(at_e);
@@ -1135,12 +1042,10 @@ __device__ bool detect_read(const ReadCtx<T> &rc, char *lds, EvHeader *hdr) {
         const unsigned long long badmask = __ballot(bad);
         if (badmask == 0ull) break;
         if (bad) init = pe;
-        float mn2 = FLT_MAX, mx2 = 0.0f;
         DetState unused = fresh;
-        detect_pass<W1, T, PREFIX>(rc, lds, 0, bad, s, e, K, pe, unused, at_e, mn2, mx2);
+        detect_pass<W1, T>(rc, 0, bad, s, e, K, pe, unused, at_e);
         if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
     }
-    return false;
 }
 
 // ---------------------------------------------------------------- event builder
@@ -1454,14 +1359,15 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 // ---------------------------------------------------------------- kernels
 
+// DNA preset: 155 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): ~200 VGPRs -> 2 (two waves already saturate
+// the vector issue, tools/valu_rate.hip)
 template <int W1, typename T>
-__global__ __launch_bounds__(64, 3) void k_event_detect(EvArgs a) {
-    __shared__ DetSnap snap;
-    __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
+__global__ __launch_bounds__(64, (W1 == 3 ? 3 : 2)) void k_event_detect(EvArgs a) {
+    __shared__ LzLds L;
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const bool ok = detect_read_fast<W1, T, false>(rc, a.hdr, &snap, hist, nullptr);
-    if (lane_id() == 0) a.flags[r] = ok ? 0 : 2;  // 2: declined by the fast pass -> exact fallback
+    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L, nullptr);
+    if (lane_id() == 0) a.flags[r] = rcode ? 2 : 0;  // 2: declined by the fast pass -> exact fallback
 }
 
 template <typename T>
@@ -1475,9 +1381,8 @@ __global__ __launch_bounds__(64, 4) void k_event_build(EvArgs a) {
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
     __shared__ PrefixLds L;
-    __shared__ DetSnap snap;
+    __shared__ LzLds Lz;
     __shared__ EventList events;
-    __shared__ __attribute__((aligned(16))) char hist[USE_LDS_HISTORY(W1) ? HistRing<T>::LDS_BYTES : 16];
     double *P = a.scratch + (uint64_t)blockIdx.x * a.scratch_stride;
     double *P2 = P + a.scratch_stride / 2;
     const uint32_t nf = a.hdr->n_flagged;
@@ -1499,8 +1404,8 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
         rep.ev = events.ev;
         rep.nev = events.count < REP_MAX_EVENTS ? events.count : REP_MAX_EVENTS;
         rep.all_dirty = events.count > REP_MAX_EVENTS;
-        const bool fast = detect_read_fast<W1, T, true>(rc, a.hdr, &snap, hist, &rep);
-        if (!fast) detect_read<W1, T, true>(rc, nullptr, a.hdr);
+        const int rcode = detect_read_lazy<W1, T, true>(rc, a.hdr, &Lz, &rep);
+        if (rcode) detect_read<W1, T>(rc, a.hdr);
         __threadfence();
         __syncthreads();
         build_read_prefix<T>(a, rc, r);

@@ -178,6 +178,153 @@ SGK_TM void sgk_tstat_try_pair(double A1, double A1q, double B1, double B1q, dou
 #endif
 }
 
+// ================================================================ round-2 forms (event_kernels.hip: LazyPass)
+// Measured issue costs on gfx950 (tools/valu_rate.hip, profiles/r02_valu_rate.txt): plain f32 add/sub/mul/fma,
+// logic and int add run at 2.3 cycles per wave64 instruction; everything f64, every conversion, v_cmp, v_cndmask,
+// v_max/min and the packed f32 forms take 4.45; v_rsq_f32 8.5; v_rsq_f64 16.2.  The forms below keep the f64 work to
+// what exactness needs (window sums, the two constant divisions of the A side, the three-term accumulation) and do
+// the tail in f32 with error-free transformations on the fast FMA.
+
+#ifndef SGK_RSQ32
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGK_RSQ32(v) __builtin_amdgcn_rsqf(v)
+#else
+#define SGK_RSQ32(v) ((float)(1.0 / sqrt((double)(v))))
+#endif
+#endif
+
+// (float)( fabs((double)delta) / sqrt((double)cvw) ) in f32 arithmetic, with a certificate.
+// Domain (guaranteed by the callers: cv > 2^-90 and the read-level range guard, non-zero |x| in [2^-20, 2^20]):
+// delta == 0 or |delta| in [2^-69, 2^21), cvw in [2^-94, 2^41) -- no intermediate below is subnormal there.
+//   y0 = rsq(c) (relative error eta <= 2^-22, checked exhaustively on the hardware by tests/test_gpu_math.py)
+//   sqrt(c) = s0 + sl,  s0 = RN(c*y0),  sl = RN((c - s0^2) * y0/2)       relative error <= 2.5 (eta+u)^2
+//   q = |d| / sqrt(c) = q0 + ql,  q0 = RN(|d|*y0),  ql = RN((|d| - q0*(s0+sl)) * y0)   relative error < 2^-41
+// (residuals by FMA).  The reference value is RN32 of a double within 2^-51 of the true quotient.  m = 2^-37 q0:
+// if RN(q0 + (ql - m)) == RN(q0 + (ql + m)) no float rounding boundary lies within the error band, so that common
+// value IS the reference's float (rounding is monotone); otherwise (probability ~2^-12) the caller evaluates the
+// reference expression.  NaN anywhere fails the equality and takes the exact path as well.
+SGK_TM float sgk_tail_f32(float delta, float cvw, bool &ok) {
+    const float ad = fabsf(delta);
+    const float y0 = SGK_RSQ32(cvw);
+    const float s0 = cvw * y0;
+    const float e = fmaf(-s0, s0, cvw);
+    const float yh = 0.5f * y0;
+    const float sl = e * yh;
+    const float q0 = ad * y0;
+    const float r1 = fmaf(-q0, s0, ad);
+    const float rho = fmaf(-q0, sl, r1);
+    const float ql = rho * y0;
+    const float m = q0 * 7.275957614183426e-12f;  // 2^-37
+    const float lo = q0 + (ql - m);
+    const float hi = q0 + (ql + m);
+    ok = lo == hi;
+    return lo;
+}
+
+// The A side of compute_tstat for one window position: mean1 and (sumsq1/w - mean1*mean1) as the reference
+// rounds them (events.c:341-352); computed when the window sum is formed and used W indices later.
+struct SgkARole {
+    float mean1;
+    double va;
+};
+template <int W>
+SGK_TM SgkARole sgk_arole(double S, double Sq) {
+    SgkARole a;
+    a.mean1 = (float)sgk_div_f64<W>(S);
+    const float m1sq = a.mean1 * a.mean1;
+    a.va = sgk_div_f64<W>(Sq) - (double)m1sq;
+    return a;
+}
+#define SGK_CV_MIN 8.0779356694631609e-28f /* 2^-90: below it (variance floor included) the exact path runs */
+
+// One t-statistic from the B-side window sums (S, Sq: exact) and the ringed A side.  ok == false: evaluate the
+// reference expression instead.  Preconditions (read-level guard, event_kernels.hip): every non-zero |x| in
+// [2^-20, 2^20], so window sums are 0 or >= 2^-43, the f32 constant divisions below never see a non-zero dividend
+// under 2^-100, and a non-zero delta is >= 2^-69.
+template <int W>
+SGK_TM float sgk_tstat_try_ab(double S, double Sq, const SgkARole &a, bool &ok) {
+    const float sum2 = (float)S;
+    const float sumsq2 = (float)Sq;
+    const float mean2 = sgk_div_f32<W>(sum2);
+    const float m2sq = mean2 * mean2;
+    const float q2 = sgk_div_f32<W>(sumsq2);
+    double acc = a.va + (double)q2;
+    acc = acc - (double)m2sq;
+    const float cv = (float)acc;
+    const bool cv_ok = cv > SGK_CV_MIN;  // also false for NaN
+    const float delta = mean2 - a.mean1;
+    const float cvw = sgk_div_f32<W>(cv);
+    bool tail_ok;
+    const float v = sgk_tail_f32(delta, cvw, tail_ok);
+    ok = cv_ok & tail_ok;
+    return v;
+}
+
+// Fallback kernel only (reads outside the range guard): are this evaluation's intermediates inside the domain the
+// certificates above assume?  (Same expressions as sgk_tstat_try_ab: the compiler merges them.)
+SGK_TM uint32_t sgk_f2u(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return u;
+}
+SGK_TM bool sgk_band60(float x) {  // x == 0 or 2^-60 <= |x| < 2^60
+    const uint32_t e = (sgk_f2u(x) >> 23) & 0xffu;
+    return x == 0.0f || (e - 67u) < 120u;
+}
+template <int W>
+SGK_TM bool sgk_try_domain(double S, double Sq, const SgkARole &a) {
+    const float sum2 = (float)S;
+    const float sumsq2 = (float)Sq;
+    const float mean2 = sgk_div_f32<W>(sum2);
+    const float m2sq = mean2 * mean2;
+    const float q2 = sgk_div_f32<W>(sumsq2);
+    double acc = a.va + (double)q2;
+    acc = acc - (double)m2sq;
+    const float cv = (float)acc;
+    const float delta = mean2 - a.mean1;
+    const uint32_t ed = (sgk_f2u(delta) >> 23) & 0xffu;
+    const bool d_ok = delta == 0.0f || (ed - 67u) < 100u;  // 0 or 2^-60 <= |delta| < 2^40
+    return sgk_band60(sum2) & sgk_band60(sumsq2) & d_ok & (cv < 1152921504606846976.0f);  // cv < 2^60
+}
+
+// ---- lazy long detector: a rigorous "cannot exceed thr2" test ----------------------------------------
+// The long detector (events.c:371-443 with the second window) can only emit a peak when some t-statistic it saw
+// since its last reset exceeded thr2 = 9.0 (valid_peak needs peak_value > threshold).  On nanopore data it is reset
+// by the short detector every few samples and that almost never happens (2e-4 of the indices), so the kernel
+// evaluates the long window exactly only inside such runs and otherwise proves, per index, that the reference's
+// value cannot exceed 9:
+//   per window position, from the exact sums:  m = RN(RN32(S)*rw), q = RN(RN32(Sq)*rw), v = RN(q - m*m) (FMA)
+//   reference:  cv >= (vA + vB) - E,  E <= 7.1u(QA+QB)  (its float roundings of mean^2 and sumsq/w), our estimates
+//   add <= 10.3u(QA+QB) + u V;  |delta| <= |mB - mA| + 3.6u(|mA|+|mB|) likewise;  tstat <= |delta| sqrt(w/cv) (1+3u).
+//   With u = 2^-24 the slack terms below (2^-19 (qA+qB), 2^-20 (|mA|+|mB|), 2^-16 relative) cover all of it
+//   several times over; a NaN or a non-positive variance bound makes the test fail, i.e. the index counts as hot.
+struct SgkLSide {
+    float m, q, v;
+};
+template <int W>
+SGK_TM SgkLSide sgk_lside(double S, double Sq) {
+    constexpr float rw = 1.0f / (float)W;
+    SgkLSide s;
+    s.m = (float)S * rw;
+    s.q = (float)Sq * rw;
+    s.v = fmaf(-s.m, s.m, s.q);
+    return s;
+}
+SGK_TM bool sgk_lside_domain(const SgkLSide &s) {  // fallback kernel only: estimates free of subnormal effects
+    return sgk_band60(s.q) & sgk_band60(s.m);
+}
+template <int W>
+SGK_TM bool sgk_long_cold(const SgkLSide &a, const SgkLSide &b) {
+    const float V = a.v + b.v;
+    const float Qs = a.q + b.q;
+    const float rhs = fmaf(Qs, -81.0f * 1.9073486328125e-06f, 81.0f * V);  // 81 (V - 2^-19 (qA+qB))
+    const float D = b.m - a.m;
+    const float Ms = fabsf(a.m) + fabsf(b.m);
+    const float Dub = fmaf(Ms, 9.5367431640625e-07f, fabsf(D));             // |D| + 2^-20 (|mA|+|mB|)
+    const float lhs = (Dub * Dub) * ((float)W * (1.0f + 1.52587890625e-05f));
+    return lhs < rhs;
+}
+
 template <int W>
 SGK_TM float sgk_tstat_fast(double A, double A2, double B, double B2) {
     bool ok;
