@@ -7,6 +7,7 @@
 //   4. sgk_tstat_fast<W> == sgk_tstat_ref<W> on window sums of pA-like data
 //   5. sgk_tail_f32 (f32 error-free-transformation tail, v_rsq_f32 modelled with 2^-22 relative error): certified => equal
 //   6. sgk_tstat_try_ab<W> (A side ringed, B side fresh; what LazyPass evaluates): certified => equal to sgk_tstat_ref<W>
+//   8. sgk_div_with_rcp == IEEE f32 division by an event length (v_rcp_f32 modelled with +-1 ulp)
 //   7. sgk_long_cold<W> true => sgk_tstat_ref<W> <= 9.0 (the lazy long detector's bound), incl. values steered to ~9
 // Build/run:  g++ -O2 -mfma -ffp-contract=off -fopenmp -o /tmp/verify_math oracle/verify_math.cpp && /tmp/verify_math [quick]
 #include <cstdint>
@@ -37,6 +38,16 @@ static inline float perturbed_rsq32(float v) {
     return (float)((1.0 / sqrt((double)v)) * (1.0 + u * 2.384185791015625e-07));
 }
 #define SGK_RSQ32(v) perturbed_rsq32(v)
+// v_rcp_f32 model: the correctly rounded reciprocal moved by -1, 0 or +1 ulp
+static inline float perturbed_rcp32(float v) {
+    const uint64_t r = rng_next(g_pert_state);
+    float x = 1.0f / v;
+    uint32_t u; memcpy(&u, &x, 4);
+    u += (uint32_t)((int)(r % 3) - 1);
+    memcpy(&x, &u, 4);
+    return x;
+}
+#define SGK_RCP32(v) perturbed_rcp32(v)
 #include "../sigtk_amd/csrc/tstat_math.h"
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -266,6 +277,32 @@ static uint64_t check_long_cold(uint64_t count, double *false_hot) {
     return bad;
 }
 
+// 8. sgk_div_with_rcp(a, len, sgk_refined_rcp(len)) == a / len for integer len in [1, 2^24) and a = 0 or 2^-43 <= |a| <= 2^44
+static uint64_t check_div_len(uint64_t count) {
+    uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t t = 0; t < 64; ++t) {
+        uint64_t s = 0xD1F1ULL * (t + 11);
+        g_pert_state = 90210 + t;
+        for (uint64_t k = 0; k < count / 64; ++k) {
+            const uint64_t r = rng_next(s), r2 = rng_next(s);
+            float len;
+            switch (k & 3) {
+                case 0: len = (float)(1 + (r % 64)); break;            // typical event lengths
+                case 1: len = (float)(1 + (r % 4096)); break;
+                default: len = (float)(1 + (r % 16777215));
+            }
+            float a = u2f((uint32_t)((r2 & 0x807FFFFF) | ((uint32_t)(127 - 43 + (r2 >> 40) % 88) << 23)));
+            if ((k % 1001) == 0) a = 0.0f;
+            if ((k & 7) == 5) a = len * (float)(1 + (r2 % 100000)) * 0.171249f;  // sums of pA-like values
+            const float want = a / len;
+            const float got = sgk_div_with_rcp(a, len, sgk_refined_rcp(len));
+            if (f2u(want) != f2u(got)) bad++;
+        }
+    }
+    return bad;
+}
+
 int main(int argc, char **argv) {
     const bool quick = argc > 1 && strcmp(argv[1], "quick") == 0;
     const uint32_t step = quick ? 257 : 1;
@@ -292,6 +329,7 @@ int main(int argc, char **argv) {
     b = check_try_ab<7>(n64 / 4, &uf); printf("tstat_try_ab<7>  mismatches: %llu (uncertified %.3g)\n", (unsigned long long)b, uf); bad += b;
     b = check_long_cold<6>(n64 / 4, &uf);  printf("long_cold<6>  violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
     b = check_long_cold<14>(n64 / 4, &uf); printf("long_cold<14> violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
+    b = check_div_len(n64);            printf("div_with_rcp (event length) mismatches: %llu\n", (unsigned long long)b); bad += b;
     printf("%s\n", bad ? "FAILED" : "ALL EXACT");
     return bad ? 1 : 0;
 }

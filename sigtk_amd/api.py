@@ -15,6 +15,8 @@ import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libsigtk_gpu.so")
+# development only: A/B builds of the kernels (tools/build_variant.sh) are selected with SIGTK_AMD_LIB
+LIB_PATH = os.environ.get("SIGTK_AMD_LIB", LIB_PATH)
 
 SGK_OK = 0
 SGK_ERR_CAPACITY = -5

@@ -43,7 +43,10 @@ namespace sgk {
 #ifndef SGK_LEAD_RNA
 #define SGK_LEAD_RNA 256
 #endif
-constexpr int LEAD = 64;   // speculative warm-up (samples); multiple of 64
+constexpr int LEAD = 64;   // speculative warm-up (samples) of the generic pass; multiple of 64
+#ifndef SGK_LEAD_DNA
+#define SGK_LEAD_DNA 64
+#endif
 
 __device__ inline uint32_t chunk_len(int64_t n) {
     const int64_t k = (n + 4095) / 4096;
@@ -525,7 +528,8 @@ struct LazyPass {
     float sv;
     int sp;
     lmask_t inpk, val, strong;
-    lmask_t ph1, ph2, ph3;        // lanes whose peak_pos was set 1, 2, 3 indices ago
+    lmask_t hist[H1 + 1];           // hist[k]: lanes whose peak_pos was set k+1 indices ago
+    uint32_t bw;                  // bitmap word (32 positions) that holds position j - H1 - 1, the usual emitted peak
     // lazy long detector
     int lm, r0;                   // short peak position at the last reset (masked while i <= lm + W1); last reset
     lmask_t hot;
@@ -578,10 +582,15 @@ struct LazyPass {
         if constexpr (FLAGGED) ok = ok && sgk_try_domain<W1>(b1, b1q, ar[(U + NA - W1) % NA]);
         ar[U % NA] = sgk_arole<W1>(b1, b1q);
         // long window: bound only
+#ifdef SGK_EXP_NO_LONG
+        bool cold = true;
+        (void)b2; (void)b2q;
+#else
         const SgkLSide lb = sgk_lside<W2>(b2, b2q);
         bool cold = sgk_long_cold<W2>(ls[(U + NL - W2) % NL], lb);
         if constexpr (FLAGGED) cold = cold && sgk_lside_domain(ls[(U + NL - W2) % NL]) && sgk_lside_domain(lb);
         ls[U % NL] = lb;
+#endif
         t1[U & 3] = v;
         nk[U & 3] = ~__ballot(ok);
         hc[U & 3] = ~__ballot(cold);
@@ -608,16 +617,37 @@ struct LazyPass {
         if constexpr (SLOW) dom &= live;
         val = inpk & (val | (Q & strong));
         // (i - peak_pos) > w/2  <=>  peak_pos was not set during the last w/2 indices (nor at this one: ~P)
-        lmask_t recent = ph1;
-        if constexpr (H1 >= 2) recent |= ph2;
-        if constexpr (H1 >= 3) recent |= ph3;
+        lmask_t recent = hist[0];
+#pragma unroll
+        for (int k = 1; k < H1; ++k) recent |= hist[k];
         lmask_t em = val & ~P & ~recent;
         if constexpr (SLOW) em &= live;
         const lmask_t upd = P | ent | em;
-        if (lane_of(em)) {
-            const int p = jb + sp;  // pass-relative position of the emitted peak (in the past)
-            if constexpr (SLOW) lz_emit_slow(ring, bm, flushed, i_begin, s, e, p);
-            else atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+        // Emission.  A strong peak stays strong and in a peak until it is emitted, so the emission step is the LAST
+        // step at which this peak resets the long detector: masked_to and the reset index are taken here.
+        if constexpr (SLOW) {
+            if (lane_of(em)) {
+                lz_emit_slow(ring, bm, flushed, i_begin, s, e, jb + sp);
+                lm = sp;
+                r0 = u;
+            }
+        } else {
+            // the usual emitted peak was set exactly H1+1 indices ago: its position is the same in every lane, and so
+            // is its bit in the lane's current bitmap word
+            const uint32_t bit = 1u << ((jb + u - H1 - 1) & 31);
+            if (lane_of(em)) {
+                bw |= bit;
+                lm = sp;
+                r0 = u;
+            }
+            const lmask_t erare = em & ~hist[H1];
+            if (erare != 0ull) {
+                if (lane_of(erare)) {  // an older peak: undo the bit, set the right one (its word is in the ring)
+                    bw &= ~bit;
+                    const int p = jb + sp;
+                    atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+                }
+            }
         }
         sv = lane_of(upd) ? v : sv;
         sp = lane_of(pos) ? u : sp;
@@ -625,27 +655,35 @@ struct LazyPass {
         val = val & ~em;
         if constexpr (SLOW) {
             // a frozen lane's history does not age
-            if constexpr (H1 >= 3) ph3 = (ph2 & live) | (ph3 & ~live);
-            if constexpr (H1 >= 2) ph2 = (ph1 & live) | (ph2 & ~live);
-            ph1 = pos | (ph1 & ~live);
+#pragma unroll
+            for (int k = H1; k >= 1; --k) hist[k] = (hist[k - 1] & live) | (hist[k] & ~live);
+            hist[0] = pos | (hist[0] & ~live);
         } else {
-            if constexpr (H1 >= 3) ph3 = ph2;
-            if constexpr (H1 >= 2) ph2 = ph1;
-            ph1 = pos;
+#pragma unroll
+            for (int k = H1; k >= 1; --k) hist[k] = hist[k - 1];
+            hist[0] = pos;
         }
-        // lazy long detector: a reset starts a new run; the run that ends here is recorded if it was hot
+        // lazy long detector: the run that ends at this reset is recorded if it was hot; a new run starts at the
+        // peak's last reset (its emission); resets in between leave nothing behind
         const lmask_t rec = dom & hot;
         if (rec != 0ull) {
             if (lane_of(rec)) nrec = lz_record(runs, nrec, ib + max(r0, lm + W1 + 1), ib + u, s, e, n);
         }
-        lm = lane_of(dom) ? sp : lm;
-        r0 = lane_of(dom) ? u : r0;
         lmask_t on = __ballot(lm < u - W1);
         if constexpr (SLOW) on &= live;
-        hot = (hot & ~dom) | (on & hck);
+        hot = (hot & ~dom) | (on & hck & (~dom | em));
+    }
+    // the bitmap word moves on when position j - H1 - 1 enters the next 32-position span
+    __device__ __forceinline__ void bw_advance() {
+        const int p = jb - 1;  // last position of the span that is complete (jb is a multiple of 32 here)
+        atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], bw);
+        bw = 0u;
     }
     template <int U>
     __device__ __forceinline__ void dstep() {
+        if constexpr (U == H1 + 1) {
+            if ((jb & 16) == 0) bw_advance();
+        }
         dstep_core<false>(U, t1[U & 3], hc[U & 3], ~0ull);
     }
     // the four steps of a quad in a block near the read's ends (or holding a very old peak): rolled, predicated
@@ -655,6 +693,7 @@ struct LazyPass {
             const lmask_t hck = k == 0 ? hc[0] : (k == 1 ? hc[1] : (k == 2 ? hc[2] : hc[3]));
             // lanes that are done and indices behind the read's end are frozen
             const lmask_t live = ~done & __ballot((unsigned)(ib + u0 + k) < (unsigned)n);
+            if (u0 + k == H1 + 1 && (jb & 16) == 0) bw_advance();
             dstep_core<true>(u0 + k, v, hck, live);
         }
     }
@@ -783,7 +822,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, int lead, bool a
     f.ring = L->ring[l];
     f.runs = L->runs[l];
     const int n = f.n;
-    const int i_begin = s - lead;  // multiple of 64
+    const int i_begin = s - lead;  // multiple of 32
     f.i_begin = i_begin;
 #pragma unroll
     for (int k = 0; k < LZ_RING_WORDS; ++k) f.ring[k] = 0u;
@@ -810,7 +849,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, int lead, bool a
     f.sv = FLT_MAX;
     f.sp = 0;
     f.inpk = 0ull; f.val = 0ull; f.strong = 0ull; f.hot = 0ull;
-    f.ph1 = 0ull; f.ph2 = 0ull; f.ph3 = 0ull;
+#pragma unroll
+    for (int k = 0; k <= LP::H1; ++k) f.hist[k] = 0ull;
+    f.bw = 0u;
     f.lm = LZ_NONE;
     f.r0 = i_begin < 0 ? -i_begin : 0;  // the (pseudo) reset a speculative pass starts from; index 0 for chunk 0
     if (lead == 0) {
@@ -822,9 +863,8 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, int lead, bool a
         f.hot = __ballot((st.bits & 8u) != 0u);
         f.sp = (st.bits & 1u) ? st.sp - i_begin : 0;
         f.lm = st.lm == LZ_NONE ? LZ_NONE : st.lm - W1 - i_begin;  // handed over as masked_to; kept as the peak position
-        f.ph1 = __ballot((st.bits & 1u) && st.sp == i_begin - 1);
-        f.ph2 = __ballot((st.bits & 1u) && st.sp == i_begin - 2);
-        f.ph3 = __ballot((st.bits & 1u) && st.sp == i_begin - 3);
+#pragma unroll
+        for (int k = 0; k <= LP::H1; ++k) f.hist[k] = __ballot((st.bits & 1u) && st.sp == i_begin - 1 - k);
         f.r0 = st.r0 - i_begin;
     }
     f.nrec = 0;
@@ -893,7 +933,11 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, int lead, bool a
     }
     // the run still open at the end of the read is replayed by the lane that holds the read's last index
     if (active && lane_of(f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, i_begin + jb + max(f.r0, f.lm + W1 + 1), n, s, e, n);
-    // remaining ring words
+    // remaining ring words (the current bitmap word first)
+    {
+        const int p = jb - LP::H1 - 2 < 0 ? 0 : jb - LP::H1 - 2;  // a position inside the word bw stands for
+        atomicOr(&f.ring[(p >> 5) & (LZ_RING_WORDS - 1)], f.bw);
+    }
     for (int p0 = f.flushed; p0 < jb; p0 += 256) lz_flush(f.ring, f.bm, i_begin, p0, own_lo, own_hi);
     if (active) L->nrec[l] = f.nrec;
 }
@@ -960,7 +1004,7 @@ __device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, c
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs `lead` readable samples
     // before the read (speculative warm-up of chunk 0) and 16 after it; other reads (e.g. a read at
     // the very start of a caller's buffer) take the exact fallback
-    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -((W1 == 7) ? SGK_LEAD_RNA : LEAD) || rc.hi < (int64_t)n + 16) return 1;
+    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.lo > -((W1 == 7) ? SGK_LEAD_RNA : SGK_LEAD_DNA) || rc.hi < (int64_t)n + 16) return 1;
     const int K = (int)chunk_len(n);
     const int c = lane_id();
     const int s = c * K;
@@ -977,7 +1021,9 @@ __device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, c
     // samples ~1.4 % of the chunk boundaries need a re-run, with 256 about 0.002 %.  A re-run costs the wave one
     // more pass over a chunk (K samples), the warm-up costs `lead` samples per lane: short reads (small K) are
     // better off with a short warm-up and the occasional re-run, long reads with a long one.
-    int lead = LEAD;
+    // (DNA: 32 samples of warm-up were tried: 6 re-runs per 640 000 chunk boundaries of the benchmark and no gain; 64 leaves
+    // the re-run count at 0)
+    int lead = SGK_LEAD_DNA;
     if (W1 == 7) lead = K <= 128 ? 64 : (K <= 512 ? 128 : SGK_LEAD_RNA);
     bool run = active;
     for (int iter = 0; iter < 66; ++iter) {
@@ -1065,28 +1111,98 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
     a.ev_stdv[slot0 + k] = sd;
 }
 
-#ifndef SGK_BT
-#define SGK_BT 32
-#endif
-constexpr int BT = SGK_BT;                       // samples per lane per builder tile (16 or 32)
+constexpr int BT = 32;      // samples per lane per builder tile: 64 bytes of int16, one 32-bit bitmap word
+// create_event (events.c:457-473) for the fast builder: the two divisions by the event length share one refined
+// reciprocal (tstat_math.h: bit-identical to `/` inside the range guard); SoA stores through per-read base pointers.
+struct EvOut {
+    uint32_t *start, *length;
+    float *mean, *stdv;
+    uint32_t cap;
+};
+__device__ __forceinline__ void store_event_fast(const EvOut &o, uint32_t k, uint32_t ps, uint32_t pe, double dsum,
+                                                 double dsumsq, bool &overflow) {
+    if (k >= o.cap) { overflow = true; return; }
+    const float len = (float)(pe - ps);
+    const float r1 = sgk_refined_rcp(len);
+    const float m = sgk_div_with_rcp((float)dsum, len, r1);
+    const float var = sgk_div_with_rcp((float)dsumsq, len, r1) - m * m;
+    const float sd = sqrtf(fmaxf(var, 0.0f));
+    o.start[k] = ps;
+    o.length[k] = pe - ps;
+    o.mean[k] = m;
+    o.stdv[k] = sd;
+}
+
 #ifndef SGK_BREC
-#define SGK_BREC 512
+#define SGK_BREC 576
 #endif
-// Boundary records per tile in LDS (18 bytes each; 10 KB per wave with the lane prefixes: 16 waves per CU).  The detector can emit a boundary every 3 samples (64 * 11 per
-// tile), but sizing LDS for that costs occupancy; a tile with more than BREC boundaries (events shorter than 4
-// samples on average over 2048 samples) sends its read to k_event_fallback instead, which has no such limit.
+// Boundary records per tile in LDS: {S, S2} as one 16-byte record + a 16-bit tile-relative position (10.6 KB per
+// wave with the lane prefixes).  The detector can emit a boundary every 3 samples (683 per tile), but sizing LDS for
+// that costs occupancy; a tile with more than BREC boundaries (events shorter than 3.6 samples on average over 2048
+// samples: never seen on nanopore data, sp1 peaks at 425) sends its read to k_event_fallback instead.
 constexpr int BREC = SGK_BREC;
+struct __attribute__((aligned(16))) BuildRec {
+    double S, S2;
+};
 struct BuildLds {
-    double S[BREC];
-    double S2[BREC];
+    BuildRec rec[BREC];
     double pt[64];
     double pt2[64];
     uint16_t p[BREC];  // tile-relative sample index of the boundary
 };
-static_assert(64 * BT <= 65536 && sizeof(BuildLds) <= 10240, "builder LDS budget: 16 waves per CU");
+static_assert(sizeof(BuildLds) <= 11776, "builder LDS budget: 13 waves per CU");
+
+// min non-zero |x| / max |x| of a read from the extremes of its raw samples (x = (raw + off) * unit is monotone in
+// raw); returns false when the read crosses or touches zero pA (the smallest non-zero magnitude is then not known
+// from the extremes; such reads fail the guard anyway: it tolerates a ratio of ~64 between the magnitudes)
+__device__ inline bool raw_extremes_to_pa(int rmin, int rmax, const Scale &sc, float &mn, float &mx) {
+    const float a = ((float)rmin + sc.offf), b = ((float)rmax + sc.offf);
+    const float xa = fabsf(a * sc.unit), xb = fabsf(b * sc.unit);
+    mn = fminf(xa, xb);
+    mx = fmaxf(xa, xb);
+    const bool same_sign = (a > 0.0f && b > 0.0f) || (a < 0.0f && b < 0.0f);
+    return same_sign && mn > 0.0f && mx < __builtin_inff();
+}
+
+typedef short sgk_s2 __attribute__((ext_vector_type(2)));
+
+// One lane's walk over its 32 samples of a tile: lane-relative double prefix sums, one record per boundary bit.
+// FULL: every sample of the tile is inside the read (no per-sample validity select).
+template <typename T, bool FULL>
+__device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, int nvalid, const Scale &sc, int l,
+                                           int excl, BuildLds *L, double &S, double &S2, uint32_t &mnb,
+                                           uint32_t &mxb) {
+    char *rr = reinterpret_cast<char *>(L->rec) + excl * 16;
+    char *rp = reinterpret_cast<char *>(L->p) + excl * 2;
+#pragma unroll
+    for (int k = 0; k < BT; ++k) {
+        float x = to_pa(buf[k], sc);
+        if (!FULL && k >= nvalid) x = 0.0f;
+        const float xq = x * x;
+        if constexpr (std::is_same<T, float>::value) {
+            // pA input: the guard's extremes are tracked on the bit patterns (non-negative floats order like
+            // unsigned integers; zero - 1 wraps to the top, so it never wins the minimum; inf / nan end up above
+            // every finite value and fail the guard)
+            const uint32_t ab = __float_as_uint(x) & 0x7fffffffu;
+            mxb = ab > mxb ? ab : mxb;
+            mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
+        }
+        if ((bits >> k) & 1u) {
+            BuildRec rc;
+            rc.S = S;
+            rc.S2 = S2;
+            *reinterpret_cast<BuildRec *>(rr) = rc;
+            *reinterpret_cast<uint16_t *>(rp) = (uint16_t)(l * BT + k);
+            rr += 16;
+            rp += 2;
+        }
+        S = S + (double)x;
+        S2 = S2 + (double)xq;
+    }
+}
 
 template <typename T>
-__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L) {
+__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined) {
     const int64_t n = rc.n;
     const int l = lane_id();
     const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
@@ -1095,20 +1211,25 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
+    EvOut eo;
+    eo.start = a.ev_start + slot0;
+    eo.length = a.ev_length + slot0;
+    eo.mean = a.ev_mean + slot0;
+    eo.stdv = a.ev_stdv + slot0;
+    eo.cap = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
     double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary, relative to the current tile start
-    // exactness guard: min non-zero |x| and max |x| over the read, tracked on the bit patterns (non-negative
-    // floats order like unsigned integers; zero - 1 wraps to the top, so it never wins the minimum; inf / nan
-    // end up above every finite value and fail the guard)
+    // exactness guard inputs: int16 reads track the extremes of the RAW samples (packed 16-bit min / max, two samples
+    // per instruction); pA reads the extremes of the float bit patterns
     uint32_t mnb = 0xffffffffu, mxb = 0u;
+    sgk_s2 rmin2 = {32767, 32767}, rmax2 = {-32768, -32768};
     constexpr int NV = BT * (int)sizeof(T) / 16;
     // tile loader: this lane's 32 samples and its 32 bitmap bits.  The next tile is fetched while the
     // current one is processed (register double buffer).
     auto load_tile = [&](int64_t tb, T (&buf)[BT], uint32_t &bits, int &nvalid) {
         const int64_t pos0 = tb + (int64_t)l * BT;
-        bits = (pos0 < n) ? (bm32[pos0 >> 5] >> (pos0 & 31)) : 0u;
-        if (BT < 32) bits &= (1u << (BT & 31)) - 1u;
+        bits = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
         const int64_t rem = n - pos0;
         nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
         if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
@@ -1128,7 +1249,6 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     int nnvalid;
     load_tile(0, nbuf, nbits, nnvalid);
     for (int64_t tb = 0; tb < n; tb += 64 * BT) {
-        const int64_t pos0 = tb + (int64_t)l * BT;
         T buf[BT];
 #pragma unroll
         for (int k = 0; k < BT; ++k) buf[k] = nbuf[k];
@@ -1139,44 +1259,37 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         const int incl = wave_incl_scan_i(cnt);
         const int excl = incl - cnt;
         const int total = wave_last_i(incl);
-        // walk: lane-relative prefix sums, boundary records.  Only the last tile of a read can hold lanes with
-        // fewer than BT samples: every other tile skips the per-sample validity select.
-        double S = 0.0, S2 = 0.0;
-        auto walk = [&](auto full_tag, auto checked_tag) {
-            constexpr bool FULL = decltype(full_tag)::value, CHECKED = decltype(checked_tag)::value;
-            int off = excl * 2;  // byte offset of the next record in p[]; four times that in S[] and S2[]
-            char *const rp = reinterpret_cast<char *>(L->p), *const rs = reinterpret_cast<char *>(L->S),
-                        *const rs2 = reinterpret_cast<char *>(L->S2);
+        const bool full = tb + 64 * BT <= n;
+        if constexpr (std::is_same<T, int16_t>::value) {
+            // raw extremes (samples behind the read's end repeat a valid one)
+            sgk_s2 w[BT / 2];
+            __builtin_memcpy(w, buf, sizeof(w));
+            if (!full) {
+                const sgk_s2 first = {(short)rc.base[0], (short)rc.base[0]};
 #pragma unroll
-            for (int k = 0; k < BT; ++k) {
-                float x = to_pa(buf[k], rc.sc);
-                if (!FULL && k >= nvalid) x = 0.0f;
-                const float xq = x * x;
-                const uint32_t ab = __float_as_uint(x) & 0x7fffffffu;
-                mxb = ab > mxb ? ab : mxb;
-                mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
-                if ((bits >> k) & 1u) {
-                    if (!CHECKED || off < BREC * 2) {
-                        *reinterpret_cast<uint16_t *>(rp + off) = (uint16_t)(l * BT + k);
-                        *reinterpret_cast<double *>(rs + 4 * off) = S;
-                        *reinterpret_cast<double *>(rs2 + 4 * off) = S2;
-                    }
-                    off += 2;
+                for (int k = 0; k < BT / 2; ++k) {
+                    if (2 * k + 1 >= nvalid) w[k] = (2 * k >= nvalid) ? first : sgk_s2{w[k].x, w[k].x};
                 }
-                S = S + (double)x;
-                S2 = S2 + (double)xq;
             }
-        };
-        // a tile with more than BREC boundaries takes the bounds-checked walk; its read is redone by the fallback
-        if (tb + 64 * BT <= n && total <= BREC) walk(std::true_type{}, std::false_type{});
-        else walk(std::false_type{}, std::true_type{});
+#pragma unroll
+            for (int k = 0; k < BT / 2; ++k) {
+                rmin2 = __builtin_elementwise_min(rmin2, w[k]);
+                rmax2 = __builtin_elementwise_max(rmax2, w[k]);
+            }
+        }
+        // walk: lane-relative prefix sums, boundary records.  A tile with more than BREC boundaries is not recorded:
+        // its read is redone by the fallback.
+        double S = 0.0, S2 = 0.0;
+        if (total > BREC) dense = true;
+        const uint32_t wbits = total > BREC ? 0u : bits;
+        if (full) build_walk<T, true>(buf, wbits, nvalid, rc.sc, l, excl, L, S, S2, mnb, mxb);
+        else build_walk<T, false>(buf, wbits, nvalid, rc.sc, l, excl, L, S, S2, mnb, mxb);
         const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
         L->pt[l] = inS - S;
         L->pt2[l] = inS2 - S2;
         const double tileS = wave_last_d(inS), tileS2 = wave_last_d(inS2);
         __syncthreads();
-        const int tot = total < BREC ? total : BREC;
-        if (total > BREC) dense = true;
+        const int tot = total > BREC ? 0 : total;
         // one event per lane per round.  Prefix sums are kept relative to the tile start (exact under the guard, so
         // no absolute base is needed); the previous boundary of lane l is lane l-1's record, lane 0 takes the
         // carry: the last record of the previous round / tile.
@@ -1186,11 +1299,12 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             const int kk = act ? k : tot - 1;
             const uint32_t pr = L->p[kk], p = (uint32_t)tb + pr;
             const int ln = (int)(pr / BT);
-            const double G = L->pt[ln] + L->S[kk];
-            const double G2 = L->pt2[ln] + L->S2[kk];
+            const BuildRec rcd = L->rec[kk];
+            const double G = L->pt[ln] + rcd.S;
+            const double G2 = L->pt2[ln] + rcd.S2;
             const uint32_t pp = (uint32_t)wave_shr1_i((int)p, (int)prevp);
             const double Gp = wave_shr1_d(G, Gprev), G2p = wave_shr1_d(G2, G2prev);
-            if (act) store_event(a, slot0, cap, (uint64_t)rank + (uint64_t)k, pp, p, G - Gp, G2 - G2p, overflow);
+            if (act) store_event_fast(eo, rank + (uint32_t)k, pp, p, G - Gp, G2 - G2p, overflow);
             const int last = (tot - k0) < 64 ? (tot - k0 - 1) : 63;  // wave-uniform
             prevp = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
             Gprev = readlane_d(G, last);
@@ -1203,21 +1317,36 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         __syncthreads();
     }
     // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
+    float mn, mx;
+    bool known = true;
+    if constexpr (std::is_same<T, int16_t>::value) {
+        int rmn = rmin2.x < rmin2.y ? rmin2.x : rmin2.y, rmxv = rmax2.x > rmax2.y ? rmax2.x : rmax2.y;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o1 = (uint32_t)__shfl_xor((int)mnb, d, 64), o2 = (uint32_t)__shfl_xor((int)mxb, d, 64);
-        mnb = o1 < mnb ? o1 : mnb;
-        mxb = o2 > mxb ? o2 : mxb;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o1 = __shfl_xor(rmn, d, 64), o2 = __shfl_xor(rmxv, d, 64);
+            rmn = o1 < rmn ? o1 : rmn;
+            rmxv = o2 > rmxv ? o2 : rmxv;
+        }
+        known = raw_extremes_to_pa(rmn, rmxv, rc.sc, mn, mx);
+    } else {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)mnb, d, 64), o2 = (uint32_t)__shfl_xor((int)mxb, d, 64);
+            mnb = o1 < mnb ? o1 : mnb;
+            mxb = o2 > mxb ? o2 : mxb;
+        }
+        mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
+        mx = __uint_as_float(mxb);
+        known = mxb < 0x7f800000u;
     }
-    const float mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u), mx = __uint_as_float(mxb);
-    const bool flagged = dense || mxb >= 0x7f800000u || !guard_ok(mn, mx, n) || a.flags[r] == 2;
+    const bool flagged = dense || !known || !guard_ok(mn, mx, n) || declined;
     if (l == 0) {
         a.flags[r] = flagged ? 1 : 0;
         if (flagged) {
             const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
             a.flag_list[k] = r;
         } else {
-            store_event(a, slot0, cap, (uint64_t)rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
+            store_event_fast(eo, rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
             a.n_events[r] = rank + 1;
             atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
         }
@@ -1359,10 +1488,15 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 // ---------------------------------------------------------------- kernels
 
-// DNA preset: 155 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): ~200 VGPRs -> 2 (two waves already saturate
-// the vector issue, tools/valu_rate.hip)
+// DNA preset: 168 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): 242 VGPRs -> 2
 template <int W1, typename T>
-__global__ __launch_bounds__(64, (W1 == 3 ? 3 : 2)) void k_event_detect(EvArgs a) {
+#ifndef SGK_DET_WAVES_DNA
+#define SGK_DET_WAVES_DNA 3
+#endif
+#ifndef SGK_DET_WAVES_RNA
+#define SGK_DET_WAVES_RNA 2
+#endif
+__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_detect(EvArgs a) {
     __shared__ LzLds L;
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
@@ -1371,11 +1505,31 @@ __global__ __launch_bounds__(64, (W1 == 3 ? 3 : 2)) void k_event_detect(EvArgs a
 }
 
 template <typename T>
-__global__ __launch_bounds__(64, 4) void k_event_build(EvArgs a) {
+__global__ __launch_bounds__(64, 3) void k_event_build(EvArgs a) {
     __shared__ BuildLds L;
     const uint32_t r = blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    build_read<T>(a, rc, r, &L);
+    build_read<T>(a, rc, r, &L, a.flags[r] == 2);
+}
+
+// Detector and builder of one read in one wave, back to back (SGK_EVENT_FUSED, the default): the builder's phases
+// that wait on memory (sample tiles, event stores) run under other waves' detector arithmetic instead of in a
+// kernel of their own.  The bitmap goes through memory (L2) between the two phases of the same wave.
+union EventLds {
+    LzLds lz;
+    BuildLds b;
+};
+template <int W1, typename T>
+__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
+    __shared__ EventLds L;
+    const uint32_t r = blockIdx.x;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
+    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L.lz, nullptr);
+    // the bitmap words of every lane (and the replay's atomics) are in L2 before any lane reads them back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    build_read<T>(a, rc, r, &L.b, rcode != 0);
 }
 
 template <int W1, typename T>
@@ -1415,6 +1569,9 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 
 // ---------------------------------------------------------------- launcher
 
+#ifndef SGK_EVENT_FUSED
+#define SGK_EVENT_FUSED 1
+#endif
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
     if (a.n_reads == 0) return SGK_OK;
@@ -1423,6 +1580,14 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     // >= 3072 reads in flight to fill its 12 waves/CU, so the overlapped step was 8.8 ms against 7.8 ms.)
     ProfScope whole("path:event", st);
     SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
+#if SGK_EVENT_FUSED
+    {
+        ProfScope ps("k_event", st);
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
+    }
+    SGK_HIP_TRY(hipGetLastError());
+#else
     {
         ProfScope ps("k_event_detect", st);
         if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
@@ -1434,6 +1599,7 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, a);
     }
     SGK_HIP_TRY(hipGetLastError());
+#endif
     {
         ProfScope ps("k_event_fallback", st);
         if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);

@@ -287,13 +287,39 @@ SGK_TM bool sgk_try_domain(double S, double Sq, const SgkARole &a) {
     return sgk_band60(sum2) & sgk_band60(sumsq2) & d_ok & (cv < 1152921504606846976.0f);  // cv < 2^60
 }
 
+// ---- create_event (events.c:457-473): two correctly rounded f32 divisions by the same event length ----
+// The core of the IEEE f32 division expansion (reciprocal refined once, quotient refined twice, all residuals by
+// FMA) without its scaling / fix-up wrapper: valid while nothing under- or overflows, which the range guard of the
+// fast path ensures (len is an integer in [1, 2^24); |a| is 0 or in [2^-43, 2^44]).  Verified against `/` by
+// oracle/verify_math.cpp with the hardware reciprocal modelled with 1 ulp of error.
+#ifndef SGK_RCP32
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGK_RCP32(v) __builtin_amdgcn_rcpf(v)
+#else
+#define SGK_RCP32(v) (1.0f / (v))
+#endif
+#endif
+SGK_TM float sgk_refined_rcp(float b) {
+    const float r0 = SGK_RCP32(b);
+    const float e = fmaf(-b, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+SGK_TM float sgk_div_with_rcp(float a, float b, float r1) {
+    const float q0 = a * r1;
+    const float rem0 = fmaf(-b, q0, a);
+    const float q1 = fmaf(rem0, r1, q0);
+    const float rem1 = fmaf(-b, q1, a);
+    return fmaf(rem1, r1, q1);
+}
+
 // ---- lazy long detector: a rigorous "cannot exceed thr2" test ----------------------------------------
 // The long detector (events.c:371-443 with the second window) can only emit a peak when some t-statistic it saw
 // since its last reset exceeded thr2 = 9.0 (valid_peak needs peak_value > threshold).  On nanopore data it is reset
 // by the short detector every few samples and that almost never happens (2e-4 of the indices), so the kernel
 // evaluates the long window exactly only inside such runs and otherwise proves, per index, that the reference's
 // value cannot exceed 9:
-//   per window position, from the exact sums:  m = RN(RN32(S)*rw), q = RN(RN32(Sq)*rw), v = RN(q - m*m) (FMA)
+//   per window position, from the exact sums:  m = RN32(S), q = RN(RN32(Sq)*w), v = RN(q - m*m) (FMA): w times the
+//   mean, w^2 times the mean square and the variance -- the test is homogeneous, so nothing is divided
 //   reference:  cv >= (vA + vB) - E,  E <= 7.1u(QA+QB)  (its float roundings of mean^2 and sumsq/w), our estimates
 //   add <= 10.3u(QA+QB) + u V;  |delta| <= |mB - mA| + 3.6u(|mA|+|mB|) likewise;  tstat <= |delta| sqrt(w/cv) (1+3u).
 //   With u = 2^-24 the slack terms below (2^-19 (qA+qB), 2^-20 (|mA|+|mB|), 2^-16 relative) cover all of it
@@ -303,10 +329,10 @@ struct SgkLSide {
 };
 template <int W>
 SGK_TM SgkLSide sgk_lside(double S, double Sq) {
-    constexpr float rw = 1.0f / (float)W;
+    // (everything scaled by W: the test below is homogeneous, so the sums are used as they are)
     SgkLSide s;
-    s.m = (float)S * rw;
-    s.q = (float)Sq * rw;
+    s.m = (float)S;
+    s.q = (float)Sq * (float)W;
     s.v = fmaf(-s.m, s.m, s.q);
     return s;
 }
