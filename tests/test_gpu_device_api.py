@@ -56,8 +56,9 @@ def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n:
 
 def test_unaligned_and_edge_reads_take_the_exact_fallback(gpu, oracle):
     reads, _, _, _ = gpu.synth_reads_host(5, [30000, 20001, 9999, 15000, 12000], seed=31, kind=0)
-    # read 0 at the very start of the buffer (no head room), read 1 on an odd sample, read 2 on a
-    # 2-byte-but-not-16-byte boundary, read 3 aligned with room, read 4 flush against the buffer end
+    # read 0 at the very start of the buffer (no head room: fine since round 2, no lane runs in front of a read),
+    # read 1 on an odd sample, read 2 on a 2-byte-but-not-16-byte boundary, read 3 aligned with room, read 4 flush
+    # against the buffer end
     offsets = [0, 30001, 50008, 60032, 0]
     offsets[4] = 75040
     n_samples = offsets[4] + len(reads[4])
@@ -65,7 +66,7 @@ def test_unaligned_and_edge_reads_take_the_exact_fallback(gpu, oracle):
     b, arena = _run_layout(gpu, oracle, reads, offsets, n_samples, 0)
     st = arena.status()
     assert st.n_capacity_overflow == 0
-    assert st.n_fallback_reads >= 3  # reads 0, 1 and 4 cannot use the fast path
+    assert st.n_fallback_reads >= 2  # reads 1 and 4 cannot use the fast path
     for r, raw in enumerate(reads):
         exp = oracle.event_raw(raw, 8192.0, 7.0, 1402.882324, 0)
         got = arena.read_events(r)
