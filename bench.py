@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: `sigtk event` throughput (raw samples/s, reads/s) on MI355X.
 
-Workload (BASELINE.json configs[1]): 10 000 synthetic DNA reads x 100 000 samples per GPU
-(S = 1e9 int16 samples, 2.0 GB), DNA detector parameters, seed 1; inputs and outputs are resident
-in HBM when the timed region starts.  One "step" = one pass of the event path (detect -> build
--> exact fallback) over the whole batch.  With --gpus N every rank processes its own batch of the
-same size (reads shard embarrassingly; no data-path collective) -> weak scaling.
+Default workload (BASELINE.json configs[1], `--config 2`): 10 000 synthetic DNA reads x 100 000 samples per GPU
+(S = 1e9 int16 samples, 2.0 GB), DNA detector parameters, seed 1; inputs and outputs are resident in HBM when the
+timed region starts.  One "step" = one pass of the path over the whole batch.  With --gpus N every rank processes
+its own batch of the same size (reads shard embarrassingly; no data-path collective) -> weak scaling.
+
+Other BASELINE configurations (secondary lines, same JSON contract):
+  --config 3   `event` with RNA parameters + `prefix` on 50 000 RNA-like reads x 100 000 samples
+  --config 4   fused `stat` + `pa` on 125 000 DNA reads x 100 000 samples per GPU (the per-GPU shard of 1 M reads)
+  --config 5   pa -> event -> stat over a resident pool of 125 000 DNA reads per GPU
+  --ragged S   (config 2) log-normal read lengths, sigma S, same mean: the mixed-length line
 
 The oracle is used only in the CPU-baseline leg (rank 0, N=1): as the checker of the benched output and as the
-timed baseline.  Prints ONE JSON line on rank 0 (see the driver contract): value = total samples/s over all
-ranks; `roofline` = algorithmic HBM bytes of one step (2*S + 16*E + 40*R) over the
-HIP-event-measured duration of the path's kernels; `cpu_baseline` = the real reference
-(oracle/_ref/libsigtk_ref.so, kind "reference") or the oracle restatement (kind "port") timed
-single-threaded on a bounded subsample of the same reads on this host.
+timed baseline.  Prints ONE JSON line on rank 0 (see the driver contract): value = total samples/s over all ranks;
+`roofline` = algorithmic HBM bytes of one step over the HIP-event-measured duration of the path's
+kernels; `cpu_baseline` = the real reference (oracle/_ref/libsigtk_ref.so, kind "reference") or the oracle
+restatement (kind "port") timed single-threaded on a bounded subsample of the same reads on this host.
 """
 import argparse
 import json
@@ -25,7 +29,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a copy kernel reaches (same guide)
+
+CONFIGS = {
+    2: dict(name="sigtk event (DNA params)", reads=10000, kind=0, rna=0, seed=1),
+    3: dict(name="sigtk event (RNA params) + prefix", reads=50000, kind=1, rna=1, seed=2),
+    4: dict(name="sigtk stat + pa (fused)", reads=125000, kind=0, rna=0, seed=3),
+    5: dict(name="sigtk pa -> event -> stat", reads=125000, kind=0, rna=0, seed=4),
+}
 
 
 def main():
@@ -33,13 +45,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0: the configuration's)")
     ap.add_argument("--read-len", type=int, default=100000)
-    ap.add_argument("--rna", type=int, default=0)
-    ap.add_argument("--cpu-reads", type=int, default=2000, help="reads in the CPU baseline subsample (0 = skip)")
+    ap.add_argument("--ragged", type=float, default=0.0, help="sigma of log-normal read lengths with mean --read-len")
+    ap.add_argument("--rna", type=int, default=-1, help="detector preset (default: the configuration's)")
+    ap.add_argument("--cpu-reads", type=int, default=-1, help="reads in the CPU baseline subsample (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / MAX-reduce "
                     "(nccl = RCCL; 'gloo' lets several ranks share one GPU for testing)")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.reads:
+        cfg["reads"] = args.reads
+    if args.rna >= 0:
+        cfg["rna"] = args.rna
+        cfg["kind"] = args.rna
+        if args.config == 2:
+            cfg["name"] = "sigtk event (%s params)" % ("RNA" if args.rna else "DNA")
+    rna = cfg["rna"]
 
     import torch
     import torch.distributed as dist
@@ -62,13 +85,32 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    api.load_library()  # raises if the HIP extension is missing: no fallback
-    kind = 1 if args.rna else 0
-    first_read = rank * args.reads  # every rank generates a different slice of the read population
-    batch = device.synth_reads(args.reads, args.read_len, seed=1, kind=kind, device=dev, first_read=first_read)
-    arena = device.EventArena(batch)
+    L = api.load_library()  # raises if the HIP extension is missing: no fallback
+    R = cfg["reads"]
+    first_read = rank * R  # every rank generates a different slice of the read population
+    lens = None
+    if args.ragged > 0:
+        rs = np.random.RandomState(5 + rank)
+        lens = args.read_len * np.exp(rs.normal(-0.5 * args.ragged ** 2, args.ragged, size=R))
+        lens = np.clip(lens, 200, 16 * args.read_len).astype(np.int64)
+    batch = device.synth_reads(R, args.read_len, seed=cfg["seed"], kind=cfg["kind"], device=dev,
+                               first_read=first_read, lengths=lens)
     S = batch.total_samples
-    R = batch.n_reads
+    arena = device.EventArena(batch) if args.config in (2, 3, 5) else None
+    pa_out = torch.empty(batch.n_samples, dtype=torch.float32, device=dev) if args.config in (4, 5) else None
+
+    def step():
+        if args.config == 2:
+            device.event(batch, arena, rna)
+        elif args.config == 3:
+            device.event(batch, arena, rna)
+            device.prefix(batch, rna, 0)
+        elif args.config == 4:
+            device.stat_pa(batch, pa_out)
+        else:
+            # pA is written once by the fused stat+pa pass; the event kernels scale on the fly
+            device.stat_pa(batch, pa_out)
+            device.event(batch, arena, rna)
 
     def barrier():
         torch.cuda.synchronize()
@@ -78,19 +120,18 @@ def main():
 
     # ---- warmup (untimed)
     for _ in range(max(args.warmup, 1)):
-        device.event(batch, arena, args.rna)
+        step()
     torch.cuda.synchronize()
-    st = arena.status()
-    E = int(st.n_events_total)
+    st = arena.status() if arena is not None else None
+    E = int(st.n_events_total) if st is not None else 0
     parity = None
     # ---- timed region: exactly K steps
-    L = api.load_library()
     L.sgk_profile_reset()
     L.sgk_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        device.event(batch, arena, args.rna)
+        step()
     barrier()
     t1 = time.perf_counter()
     L.sgk_profile_enable(0)
@@ -105,87 +146,50 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = S * world / (elapsed / args.steps)
-        # per-step device time of each kernel (HIP events on the stream it was launched on, summed over
-        # its launches in a step) and of the whole path ("path:event": first launch -> last kernel done;
-        # detector, builder and the rare fallback run back to back on one stream)
+        # per-step device time of each kernel (HIP events on the stream it was launched on, summed over its launches
+        # in a step); "path:*" entries bracket a whole subtool (first launch -> last kernel done)
         kern = {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("path:")}
-        path_ms = prof["path:event"][0] / args.steps if "path:event" in prof else sum(kern.values())
+        paths = {k: v[0] / args.steps for k, v in prof.items() if k.startswith("path:")}
+        path_ms = sum(paths.values()) if paths else sum(kern.values())
+        if args.config in (4, 5):
+            path_ms = sum(kern.values())  # stat/pa launch without a path bracket
         dominant = max(kern, key=kern.get) if kern else None
-        alg_bytes = 2 * S + 16 * E + 40 * R
-        achieved = alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
-        traffic = None
-        valu = None
+        alg = {2: 2 * S + 16 * E + 40 * R,
+               3: (2 * S + 16 * E + 40 * R) + (2 * S + 48 * R),
+               4: 6 * S + 32 * R,
+               5: 2 * S + 16 * E + 72 * R + 4 * S}[args.config]
+        achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
+        # HBM traffic and VALU counters cannot be collected inside this process (rocprofv3 --pmc passes of this same
+        # command, tools/refresh_profiles.sh): the live line carries `traffic: null`; what was recorded for the
+        # committed build is quoted under `recorded_pmc` with its source, for N = 1 and the default shape only
+        recorded = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and not args.rna and R == 10000 and args.read_len == 100000:
-            # PMC passes of this same command (separate rocprofv3 --pmc runs, see profiles/README.md): HBM bytes
-            # per step, and the VALU occupancy that actually bounds the dominant kernel (it is issue-bound: a
-            # wave64 vector instruction holds its SIMD for 4 cycles whatever its type)
+        if world == 1 and args.config == 2 and not rna and R == 10000 and args.read_len == 100000 and not args.ragged \
+                and os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
-                traffic = pmc.get("hbm_bytes_per_step")
-                sq = pmc.get("sq_counters_per_step", {}).get("k_event_detect")
-                if sq:
-                    busy_ms = sq["SQ_ACTIVE_INST_VALU_quadcycles"] * 4 / 1024 / 2.4e9 * 1e3
-                    valu = {"kernel": "k_event_detect", "wave_instructions": sq["SQ_INSTS_VALU"],
-                            "busy_ms_at_2.4GHz": round(busy_ms, 2), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc)"}
-            except Exception:
-                traffic = None
+                recorded = {"hbm_bytes_per_step": pmc.get("hbm_bytes_per_step"),
+                            "valu_wave_instructions_per_step": pmc.get("valu_wave_instructions_per_step"),
+                            "valu_busy_fraction": pmc.get("valu_busy_fraction"),
+                            "recorded_for": pmc.get("recorded_for"), "source": "profiles/pmc_traffic.json"}
+            except (OSError, ValueError):
+                recorded = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes": alg_bytes, "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
-                    "dominant_kernel": dominant, "path_ms": round(path_ms, 4), "valu": valu}
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+                    "traffic": None, "algorithmic_bytes": alg,
+                    "limiter": "vector instruction issue (bit-exact f64/f32 expression tree; see DESIGN.md 3.1), "
+                               "not HBM: `bound` names the roofline the contract prices against",
+                    "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
+                    "dominant_kernel": dominant, "path_ms": round(path_ms, 4), "recorded_pmc": recorded}
 
         cpu = None
-        if args.cpu_reads > 0 and world == 1:
-            nb = min(args.cpu_reads, R)
-            o_end = int(batch.offsets_host[nb - 1]) + int(batch.lengths_host[nb - 1])
-            samples = batch.samples[:o_end].cpu().numpy()
-            offs = np.concatenate([batch.offsets_host[:nb], [np.uint64(o_end)]]).astype(np.uint64)
-            # the oracle/reference helpers take CSR offsets: reads here are padded to 64 samples, so
-            # hand them per-read views through a compacted copy
-            lens = batch.lengths_host[:nb].astype(np.int64)
-            comp = np.concatenate([samples[int(batch.offsets_host[r]):int(batch.offsets_host[r]) + int(lens[r])]
-                                   for r in range(nb)])
-            coffs = np.zeros(nb + 1, dtype=np.uint64)
-            np.cumsum(lens, out=coffs[1:])
-            dig = batch.dig[:nb].cpu().numpy(); off = batch.off[:nb].cpu().numpy(); rng = batch.rng[:nb].cpu().numpy()
-            # the CPU leg is the only place the oracle is touched: first as the checker of the benched output
-            # (three reads, bit for bit), then as the timed single-thread baseline
-            from oracle.oracle import Oracle, RefLib
-            orc = Oracle()
-            ok = True
-            for r in (0, nb // 2, nb - 1):
-                o = int(batch.offsets_host[r]); n = int(batch.lengths_host[r])
-                raw = batch.samples[o:o + n].cpu().numpy()
-                exp = orc.event_raw(raw, float(batch.dig[r]), float(batch.off[r]), float(batch.rng[r]), args.rna)
-                got = arena.read_events(r)
-                ok &= (got.start.size == exp.start.size and np.array_equal(got.start.astype(np.uint64), exp.start)
-                       and np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
-                       and np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32)))
-            parity = bool(ok)
-            if not ok:
-                raise SystemExit("bench: GPU event output differs from the oracle -- the timing above is void")
-            try:
-                os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
-            except Exception:
-                pass
-            if RefLib.available():
-                ref = RefLib()
-                tc0 = time.perf_counter()
-                ne = ref.event_batch_count(comp, coffs, dig, off, rng, args.rna)
-                tc = time.perf_counter() - tc0
-                kind_s = "reference"
-            else:
-                tc0 = time.perf_counter()
-                ne = Oracle().event_batch_count(comp, coffs, dig, off, rng, args.rna, faithful=1)
-                tc = time.perf_counter() - tc0
-                kind_s = "port"
-            cpu = {"value": round(int(lens.sum()) / tc, 1), "unit": "samples/s", "cores": 1, "kind": kind_s,
-                   "sample": "first %d reads of the benched batch (%d samples, %d events), %.1f s, 1 thread of %d host cpus"
-                             % (nb, int(lens.sum()), ne, tc, os.cpu_count())}
+        cpu_reads = args.cpu_reads if args.cpu_reads >= 0 else (2000 if args.config in (2, 3) else 300)
+        if cpu_reads > 0 and world == 1:
+            cpu, parity = cpu_leg(args, cfg, batch, arena, cpu_reads, rna)
 
         out = {
-            "metric": "event_raw_samples_per_sec",
+            "metric": "event_raw_samples_per_sec" if args.config in (2, 3) else "raw_samples_per_sec",
             "value": round(value, 1),
             "unit": "samples/s",
             "reads_per_sec": round(R * world / (elapsed / args.steps), 1),
@@ -198,11 +202,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32+f64",
             "data": "synthetic",
-            "config": {"workload": "sigtk event (%s params) on %d synthetic reads x %d samples per GPU "
-                                   "(BASELINE configs[1]), device-resident" % ("RNA" if args.rna else "DNA", R,
-                                                                               args.read_len),
-                       "reads_per_gpu": R, "samples_per_read": args.read_len, "events_per_step_rank0": E,
-                       "fallback_reads": int(st.n_fallback_reads), "rerun_chunks": int(st.n_rerun_passes),
+            "config": {"workload": "%s on %d synthetic reads x %s samples per GPU (BASELINE configs[%d]), "
+                                   "device-resident" % (cfg["name"], R,
+                                                        ("log-normal(sigma %.2f, mean %d)" % (args.ragged, args.read_len))
+                                                        if args.ragged else str(args.read_len), args.config - 1),
+                       "reads_per_gpu": R, "samples_per_read": args.read_len, "samples_per_gpu": int(S),
+                       "events_per_step_rank0": E,
+                       "fallback_reads": int(st.n_fallback_reads) if st is not None else None,
+                       "rerun_chunks": int(st.n_rerun_passes) if st is not None else None,
+                       "long_detector_replays": int(st.n_long_replays) if st is not None else None,
                        "parallelism": "reads sharded across ranks, no collective"},
             "parity_spot_check": parity,
             "roofline": roofline,
@@ -212,6 +220,63 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_leg(args, cfg, batch, arena, nb, rna):
+    """The only place the oracle is touched: first as the checker of the benched output (three reads, bit for bit),
+    then as the timed single-thread baseline on the first `nb` reads of the benched batch."""
+    from oracle.oracle import Oracle, RefLib
+    nb = min(nb, batch.n_reads)
+    lens = batch.lengths_host[:nb].astype(np.int64)
+    o_end = int(batch.offsets_host[nb - 1]) + int(lens[nb - 1])
+    samples = batch.samples[:o_end].cpu().numpy()
+    # the oracle/reference helpers take CSR offsets: reads here are padded, so hand them a compacted copy
+    comp = np.concatenate([samples[int(batch.offsets_host[r]):int(batch.offsets_host[r]) + int(lens[r])]
+                           for r in range(nb)])
+    coffs = np.zeros(nb + 1, dtype=np.uint64)
+    np.cumsum(lens, out=coffs[1:])
+    dig = batch.dig[:nb].cpu().numpy(); off = batch.off[:nb].cpu().numpy(); rng = batch.rng[:nb].cpu().numpy()
+    orc = Oracle()
+    parity = None
+    if arena is not None:
+        ok = True
+        for r in (0, nb // 2, nb - 1):
+            o = int(batch.offsets_host[r]); n = int(batch.lengths_host[r])
+            raw = batch.samples[o:o + n].cpu().numpy()
+            exp = orc.event_raw(raw, float(batch.dig[r]), float(batch.off[r]), float(batch.rng[r]), rna)
+            got = arena.read_events(r)
+            ok &= (got.start.size == exp.start.size and np.array_equal(got.start.astype(np.uint64), exp.start)
+                   and np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+                   and np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32)))
+        parity = bool(ok)
+        if not ok:
+            raise SystemExit("bench: GPU event output differs from the oracle -- the timing above is void")
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except OSError:
+        pass
+    use_ref = RefLib.available()
+    lib = RefLib() if use_ref else orc
+    kind_s = "reference" if use_ref else "port"
+    tc0 = time.perf_counter()
+    note = ""
+    if args.config in (2, 3, 5):
+        ne = lib.event_batch_count(comp, coffs, dig, off, rng, rna) if use_ref else \
+            lib.event_batch_count(comp, coffs, dig, off, rng, rna, faithful=1)
+        note = "%d events" % ne
+    if args.config in (3, 4, 5):
+        for r in range(nb):
+            raw = comp[int(coffs[r]):int(coffs[r + 1])]
+            if args.config == 3:
+                lib.find_adaptor(raw, 0)
+            else:
+                lib.stat(raw, dig[r], off[r], rng[r])
+                lib.pa(raw, dig[r], off[r], rng[r])
+    tc = time.perf_counter() - tc0
+    cpu = {"value": round(int(lens.sum()) / tc, 1), "unit": "samples/s", "cores": 1, "kind": kind_s,
+           "sample": "first %d reads of the benched batch (%d samples%s), %.1f s, 1 thread of %d host cpus"
+                     % (nb, int(lens.sum()), (", " + note) if note else "", tc, os.cpu_count())}
+    return cpu, parity
 
 
 if __name__ == "__main__":
