@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--ragged", type=float, default=0.0, help="sigma of log-normal read lengths with mean --read-len")
     ap.add_argument("--rna", type=int, default=-1, help="detector preset (default: the configuration's)")
     ap.add_argument("--cpu-reads", type=int, default=-1, help="reads in the CPU baseline subsample (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the configuration's reads (default); strong: ONE population of that "
+                         "size is split over the ranks in contiguous ranges balanced by cumulative samples")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / MAX-reduce "
                     "(nccl = RCCL; 'gloo' lets several ranks share one GPU for testing)")
     args = ap.parse_args()
@@ -87,12 +90,19 @@ def main():
 
     L = api.load_library()  # raises if the HIP extension is missing: no fallback
     R = cfg["reads"]
-    first_read = rank * R  # every rank generates a different slice of the read population
+    first_read = rank * R  # weak scaling: every rank generates a different slice of the read population
     lens = None
     if args.ragged > 0:
-        rs = np.random.RandomState(5 + rank)
+        rs = np.random.RandomState(5 + (rank if args.scaling == "weak" else 0))
         lens = args.read_len * np.exp(rs.normal(-0.5 * args.ragged ** 2, args.ragged, size=R))
         lens = np.clip(lens, 200, 16 * args.read_len).astype(np.int64)
+    if args.scaling == "strong" and world > 1:
+        # one population of R reads: rank g takes the g-th contiguous range of near-equal cumulative samples
+        from sigtk_amd import shard
+        all_lens = lens if lens is not None else np.full(R, args.read_len, dtype=np.int64)
+        lo, hi = shard.partition_by_samples(all_lens, world)[rank]
+        first_read, R = lo, hi - lo
+        lens = all_lens[lo:hi] if lens is not None else None
     batch = device.synth_reads(R, args.read_len, seed=cfg["seed"], kind=cfg["kind"], device=dev,
                                first_read=first_read, lengths=lens)
     S = batch.total_samples
@@ -140,12 +150,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # units all ranks processed in one step (weak: S per rank; strong: the ranks' shares of one population)
+    S_all, R_all = float(S), float(R)
+    if world > 1:
+        t = torch.tensor([S_all, R_all], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        S_all, R_all = float(t[0].item()), float(t[1].item())
     prof = api.profile_read()
     L.sgk_profile_reset()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = S * world / (elapsed / args.steps)
+        value = S_all / (elapsed / args.steps)
         # per-step device time of each kernel (HIP events on the stream it was launched on, summed over its launches
         # in a step); "path:*" entries bracket a whole subtool (first launch -> last kernel done)
         kern = {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("path:")}
@@ -192,13 +208,13 @@ def main():
             "metric": "event_raw_samples_per_sec" if args.config in (2, 3) else "raw_samples_per_sec",
             "value": round(value, 1),
             "unit": "samples/s",
-            "reads_per_sec": round(R * world / (elapsed / args.steps), 1),
+            "reads_per_sec": round(R_all / (elapsed / args.steps), 1),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32+f64",
             "data": "synthetic",

@@ -25,6 +25,7 @@ void set_hip_error(hipError_t e, const char *what, const char *file, int line) {
 struct ProfRec {
     const char *name;
     hipEvent_t t0, t1;
+    int device;  // the events belong to this device: it is made current again to read / destroy them
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -35,6 +36,8 @@ ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), slot(-1
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.name = n;
+    r.device = 0;
+    (void)hipGetDevice(&r.device);
     if (hipEventCreate(&r.t0) != hipSuccess) return;
     if (hipEventCreate(&r.t1) != hipSuccess) {
         (void)hipEventDestroy(r.t0);
@@ -176,18 +179,25 @@ void sgk_profile_enable(int on) {
 
 void sgk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     for (auto &r : g_prof) {
+        (void)hipSetDevice(r.device);
         (void)hipEventSynchronize(r.t1);
         (void)hipEventDestroy(r.t0);
         (void)hipEventDestroy(r.t1);
     }
+    (void)hipSetDevice(cur);
     g_prof.clear();
 }
 
 int sgk_profile_read(const char **names, double *ms, uint32_t *calls, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int k = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     for (auto &r : g_prof) {
+        (void)hipSetDevice(r.device);  // records of several devices (sigtk-amd --gpus N) share the list
         if (hipEventSynchronize(r.t1) != hipSuccess) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.t0, r.t1) != hipSuccess) continue;
@@ -204,6 +214,7 @@ int sgk_profile_read(const char **names, double *ms, uint32_t *calls, int cap) {
         ms[j] += (double)t;
         calls[j] += 1;
     }
+    (void)hipSetDevice(cur);
     return k;
 }
 

@@ -7,6 +7,9 @@
 #include <sys/stat.h>
 #include <zlib.h>
 
+/* an inflated record larger than this is refused (a 2^31-sample record is 4 GiB of signal) */
+#define B5_MAX_INFLATED (1ull << 33)
+
 static const uint8_t B5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', 1};
 static const char B5_EOF_MARK[5] = {'5', 'W', 'O', 'L', 'B'};
 
@@ -94,7 +97,8 @@ static int svb_zd_decode(const uint8_t *blob, uint64_t nbytes, b5_rec_t *rec) {
     uint32_t count;
     memcpy(&count, blob, 4);
     const uint64_t nkeys = ((uint64_t)count + 3) / 4;
-    if (4 + nkeys > nbytes) return B5_ERR_PRESS;
+    /* every value takes a key and at least one data byte: a short blob cannot claim a huge count */
+    if (count > 0x7fffffffu || 4 + nkeys + (uint64_t)count > nbytes) return B5_ERR_PRESS;
     if (rec->cap_signal < count) {
         int16_t *q = (int16_t *)realloc(rec->raw_signal, sizeof(int16_t) * ((uint64_t)count + 1));
         if (!q) return B5_ERR_MEM;
@@ -143,7 +147,7 @@ static int parse_record(const b5_file_t *f, const uint8_t *p, uint64_t n, b5_rec
         if (ln > left) return B5_ERR_FORMAT;
         return svb_zd_decode(q, ln, rec);
     }
-    if (ln * 2 > left) return B5_ERR_FORMAT;
+    if (ln > 0x7fffffffull || ln * 2 > left) return B5_ERR_FORMAT; /* ln is untrusted: no wrap in ln * 2 */
     if (rec->cap_signal < ln) {
         int16_t *s = (int16_t *)realloc(rec->raw_signal, sizeof(int16_t) * (ln + 1));
         if (!s) return B5_ERR_MEM;
@@ -182,6 +186,7 @@ static int read_record(b5_file_t *f, b5_rec_t *rec, int id_only) {
             const int z = uncompress(rec->zbuf, &out, rec->buf, size);
             if (z == Z_OK) { n = out; break; }
             if (z != Z_BUF_ERROR) return B5_ERR_PRESS;
+            if (rec->cap_zbuf >= B5_MAX_INFLATED) return B5_ERR_PRESS; /* zip bomb / truncated stream */
             cap = rec->cap_zbuf * 2;
         }
         p = rec->zbuf;
@@ -304,6 +309,7 @@ int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t 
             const int z = uncompress(*scratch, &outlen, raw, size);
             if (z == Z_OK) { n = outlen; break; }
             if (z != Z_BUF_ERROR) return B5_ERR_PRESS;
+            if (*scratch_cap >= B5_MAX_INFLATED) return B5_ERR_PRESS; /* zip bomb / truncated stream */
             want = *scratch_cap * 2;
         }
         p = *scratch;
@@ -331,7 +337,7 @@ int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t 
         if (ln > left || ln < 4 || ln > 0xffffffffull) return B5_ERR_FORMAT;
         uint32_t count;
         memcpy(&count, q, 4);
-        if (count > 0x7fffffffu) return B5_ERR_FORMAT;
+        if (count > 0x7fffffffu || 4 + ((uint64_t)count + 3) / 4 + (uint64_t)count > ln) return B5_ERR_FORMAT;
         out->signal_bytes = ln;
         out->n_samples = count;
     } else {

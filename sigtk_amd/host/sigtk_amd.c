@@ -127,9 +127,16 @@ static int8_t pore_detect(const b5_file_t *f) {
 
 /* ------------------------------------------------------------------ small utilities */
 
+/* Fatal errors can be raised on the reader, loader and writer threads while other threads still have HIP work in
+ * flight: leave without running exit handlers (exit() would run the HIP runtime's concurrently with live streams). */
+static void die_now(void) {
+    fflush(stderr);
+    _exit(EXIT_FAILURE);
+}
+
 static void die_mem(void) {
     ERROR("main", "%s", "out of memory");
-    exit(EXIT_FAILURE);
+    die_now();
 }
 
 /* growable output buffer */
@@ -214,7 +221,7 @@ static pool_t *pool_create(int nthreads) {
         w->tid = t + 1;
         if (pthread_create(&p->th[t], NULL, pool_worker, w) != 0) {
             ERROR("pool", "%s", "cannot create thread");
-            exit(EXIT_FAILURE);
+            die_now();
         }
     }
     return p;
@@ -342,7 +349,7 @@ typedef struct {
 
 static void gpu_fail(const char *what, int rc) {
     ERROR(what, "%s %s", sgk_strerror(rc), sgk_last_hip_error());
-    exit(EXIT_FAILURE);
+    die_now();
 }
 
 static void batch_add_record(batch_t *b, uint64_t size, const uint8_t *ref) {
@@ -400,7 +407,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
     for (uint32_t i = 0; i < b->n; i++) {
         if (b->recs[i].err) {
             fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
-            exit(EXIT_FAILURE);
+            die_now();
         }
         b->lengths[i] = b->recs[i].v.n_samples;
         b->blob_bytes[i] = (uint32_t)b->recs[i].v.signal_bytes;
@@ -417,7 +424,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
     for (uint32_t i = 0; i < b->n; i++) {
         if (b->recs[i].err) {
             fprintf(stderr, "Error in slow5_get_next. Error code %d\n", b->recs[i].err);
-            exit(EXIT_FAILURE);
+            die_now();
         }
     }
     int tool = SGK_TOOL_PA, flags = 0;
@@ -639,7 +646,7 @@ static void row_qts(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, ui
         char *p = sbuf_room(o, 8 + (size_t)zlen);
         if (compress2((Bytef *)p + 8, &zlen, t, (uLong)n, Z_DEFAULT_COMPRESSION) != Z_OK) {
             ERROR("qts", "%s", "zlib compression failed");
-            exit(EXIT_FAILURE);
+            die_now();
         }
         const uint64_t z64 = zlen;
         memcpy(p, &z64, 8);
@@ -733,7 +740,7 @@ static void *writer_main(void *arg) {
         for (uint32_t i = 0; i < nchunks; i++)
             if (chunk[i].n && fwrite(chunk[i].p, 1, chunk[i].n, P->out_fp) != chunk[i].n) {
                 ERROR("writer", "%s", "write to the output failed");
-                exit(EXIT_FAILURE);
+                die_now();
             }
         P->t_write += realtime() - t2;
         b->n = 0;
@@ -787,19 +794,19 @@ static void *reader_main(void *arg) {
         }
         if (ret != B5_EOF) {
             fprintf(stderr, "Error in slow5_get_next. Error code %d\n", ret);
-            exit(EXIT_FAILURE);
+            die_now();
         }
     } else {
         if (b5_index(f) < 0) {
             ERROR("cmain", "Error loading index file for %s", f->path);
-            exit(EXIT_FAILURE);
+            die_now();
         }
         for (int i = 0; i < P->n_ids; i++) {
             fprintf(stderr, "Read ID %s\n", P->ids[i]);
             uint64_t size = 0;
             if (b5_get_raw(f, P->ids[i], &b->raw, &b->raw_len, &b->raw_cap, &size) < 0) {
                 ERROR("cmain", "%s", "Error when fetching the read");
-                exit(EXIT_FAILURE);
+                die_now();
             }
             batch_add_record(b, size, NULL);
             if (b->bytes >= P->limit_bytes) {
@@ -840,7 +847,7 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
     pthread_t wth, rth;
     if (pthread_create(&wth, NULL, writer_main, P) != 0 || pthread_create(&rth, NULL, reader_main, P) != 0) {
         ERROR("cmain", "%s", "cannot create the pipeline threads");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     /* loader: inflate/parse, stage and submit every filled batch */
     for (;;) {
@@ -942,7 +949,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     if (!f) {
         if (is_ent) fprintf(stderr, "Error in opening file\n"); /* ent.c:97-100 */
         else ERROR("cmain", "cannot open %s. ", argv[optind]);
-        exit(EXIT_FAILURE);
+        die_now();
     }
     if (!is_ent) {
         opt.rna = drna_detect(f);
@@ -982,7 +989,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     const double t_init = realtime() - t_init0;
     if (ndev <= 0) {
         ERROR("cmain", "%s", "no usable GPU: sigtk-amd has no CPU compute path");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > ndev) {
@@ -1043,7 +1050,7 @@ static int qtsmain(int argc, char *argv[]) {
             b = atoi(optarg);
             if (b < 1 || b > 8) {
                 fprintf(stderr, "Error: number of bits to truncate must be between 1 and 8\n");
-                exit(EXIT_FAILURE);
+                die_now();
             }
         } else if (c == 'm') {
             method = optarg;
@@ -1067,7 +1074,7 @@ static int qtsmain(int argc, char *argv[]) {
     }
     if (out_fn == NULL) {
         fprintf(stderr, "Error: output file not specified\n");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     int q_method;
     if (strcmp(method, "floor") == 0) q_method = SGK_QTS_FLOOR;
@@ -1075,17 +1082,17 @@ static int qtsmain(int argc, char *argv[]) {
     else if (strcmp(method, "fill-ones") == 0) q_method = SGK_QTS_FILL_ONES;
     else {
         fprintf(stderr, "Unknown method for -m. Available options are floor,round,fill-ones.\n");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     b5_file_t *f = b5_open(argv[optind]);
     if (!f) {
         fprintf(stderr, "Error in opening file\n");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     FILE *out = fopen(out_fn, "wb");
     if (!out) {
         fprintf(stderr, "Error opening file!\n");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     /* header block: the fixed 68 bytes and the header text, as they are */
     {
@@ -1095,7 +1102,7 @@ static int qtsmain(int argc, char *argv[]) {
         if (fseek(f->fp, 0, SEEK_SET) != 0 || fread(h, 1, hb, f->fp) != hb || fwrite(h, 1, hb, out) != hb ||
             fseek(f->fp, (long)f->first_rec, SEEK_SET) != 0) {
             fprintf(stderr, "Error writing header!\n");
-            exit(EXIT_FAILURE);
+            die_now();
         }
         free(h);
     }
@@ -1104,7 +1111,7 @@ static int qtsmain(int argc, char *argv[]) {
     const double t_init = realtime() - t_init0;
     if (ndev <= 0) {
         ERROR("qtsmain", "%s", "no usable GPU: sigtk-amd has no CPU compute path");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > ndev) n_gpus = ndev;
@@ -1125,7 +1132,7 @@ static int qtsmain(int argc, char *argv[]) {
     run_pipeline(&P, n_gpus, t_init);
     if (fwrite("5WOLB", 1, 5, out) != 5 || fclose(out) != 0) {
         fprintf(stderr, "Error writing record!\n");
-        exit(EXIT_FAILURE);
+        die_now();
     }
     b5_close(f);
     return 0;
@@ -1284,7 +1291,11 @@ int main(int argc, char *argv[]) {
             realtime() - realtime0, cputime(), peakrss() / 1024.0 / 1024.0 / 1024.0);
     /* everything is written; leave without running the HIP runtime's exit handlers (they take longer than a
      * small input does) */
-    fflush(stdout);
+    if (fflush(stdout) != 0 || ferror(stdout)) {
+        /* a short final write (ENOSPC, EPIPE) must not leave a truncated TSV behind exit code 0 */
+        fprintf(stderr, "[%s::ERROR] writing to stdout failed\n", __func__);
+        ret = EXIT_FAILURE;
+    }
     fflush(stderr);
     _exit(ret);
 }

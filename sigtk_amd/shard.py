@@ -14,8 +14,10 @@ import numpy as np
 
 
 def partition_by_samples(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
-    """Contiguous read ranges [lo, hi) per rank with near-equal cumulative samples.
-    Same rule as process_batch() in sigtk_amd/host/sigtk_amd.c."""
+    """Contiguous read ranges [lo, hi) per rank with near-equal cumulative samples (SURVEY.md 8e).
+    Used by `bench.py --scaling strong` (one fixed read population split over the ranks); the C CLI hands whole
+    batches to its GPUs round-robin instead (host/sigtk_amd.c: job index % n_gpus), which balances by samples too
+    because batches are cut by sample count."""
     lengths = np.asarray(lengths, dtype=np.int64)
     n = lengths.size
     csum = np.concatenate(([0], np.cumsum(lengths)))

@@ -83,13 +83,6 @@ def test_c_reader_compression_variants(cli, tmp_path, rp, sp):
     _check_dump(cli, path, recs)
 
 
-def test_truncated_file_is_an_error(cli, tmp_path):
-    data = open(os.path.join(GOLDEN, "sp1_dna.blow5"), "rb").read()
-    path = str(tmp_path / "trunc.blow5")
-    open(path, "wb").write(data[:len(data) // 2])
-    assert run(cli, "_dump", path).returncode == 1
-
-
 def test_no_gpu_is_a_loud_error(cli):
     if api.device_count() > 0:
         pytest.skip("a GPU is present")
@@ -112,6 +105,43 @@ def test_truncated_file_is_an_error(cli, tmp_path):
     for extra in ([], ["--split"], ["--map"]):
         p = run(cli, "_dump", *extra, path)
         assert p.returncode == 1
+
+
+def _crafted(tmp_path, name, len_field, signal_bytes, signal_press):
+    """an uncompressed-record BLOW5 with one record whose len_raw_signal field is `len_field`"""
+    import struct
+    path = str(tmp_path / name)
+    blow5.write_blow5(path, [blow5.Read("r0", 0, 8192.0, 3.0, 1402.882324, 4000.0,
+                                        np.arange(16, dtype=np.int16))], {}, 0, signal_press)
+    data = bytearray(open(path, "rb").read())
+    hdr_len = struct.unpack_from("<I", data, 64)[0]
+    rec0 = 68 + hdr_len
+    rid = b"r0"
+    body = struct.pack("<H", len(rid)) + rid + struct.pack("<Iddddq", 0, 8192.0, 3.0, 1402.882324, 4000.0, 0)
+    body = body[:-8] + struct.pack("<Q", len_field) + signal_bytes
+    out = bytes(data[:rec0]) + struct.pack("<Q", len(body)) + body + b"5WOLB"
+    open(path, "wb").write(out)
+    return path
+
+
+@pytest.mark.parametrize("len_field", [1 << 63, 1 << 32, (1 << 63) + 8, 0x7fffffff])
+def test_crafted_sample_count_is_rejected(cli, tmp_path, len_field):
+    """len_raw_signal is untrusted -- 2^63 made `ln * 2` wrap and the reader walk off its buffer"""
+    path = _crafted(tmp_path, "evil.blow5", len_field, b"\x01\x00" * 8, 0)
+    for extra in ([], ["--split"], ["--map"]):
+        p = subprocess.run([cli, "_dump", *extra, path], capture_output=True, timeout=60)
+        assert p.returncode == 1, (extra, p.returncode, p.stderr[-200:])
+
+
+def test_crafted_svb_count_is_rejected(cli, tmp_path):
+    """a 5-byte svb-zd blob that claims 2^31 - 1 samples must be refused at parse time, not after the buffers
+    for it were sized"""
+    import struct
+    blob = struct.pack("<I", 0x7fffffff) + b"\x00"
+    path = _crafted(tmp_path, "evil_svb.blow5", len(blob), blob, 1)
+    for extra in ([], ["--split"], ["--map"]):
+        p = subprocess.run([cli, "_dump", *extra, path], capture_output=True, timeout=60)
+        assert p.returncode == 1, (extra, p.returncode, p.stderr[-200:])
 
 
 def test_reader_survives_corrupt_input(cli, tmp_path):

@@ -107,3 +107,15 @@ def test_event_guard_failing_reads_repair_path(gpu, oracle, rna):
     got, status = gpu.event(reads, dig, off, rng, rna)
     _check_events(oracle, reads, dig, off, rng, rna, got)
     assert status.n_fallback_reads >= 7
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_event_ragged_lognormal(gpu, oracle, rna):
+    """mixed read lengths (log-normal, sigma 0.8, as bench.py --ragged 0.8): short reads run on 16-sample chunk
+    granularity with a short warm-up, long ones on the full-length layout, in one batch"""
+    rs = np.random.RandomState(11)
+    lens = (6000 * np.exp(rs.normal(-0.32, 0.8, size=48))).astype(np.int64).clip(1, 90000)
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens.tolist(), seed=9, kind=rna)
+    got, status = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+    assert status.n_capacity_overflow == 0
