@@ -73,6 +73,8 @@ def main():
         save("sp1_dna.ent.tsv", ref(tmp, "ent", sp1))
         # long-form event output of the whole file is ~6.5 MB: keep its hash only
         manifest["sp1_dna.event.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", sp1)).hexdigest()
+        # BASELINE config 1: `pa` over the whole fixture (4.4 MB of text): hash only
+        manifest["sp1_dna.pa.tsv.sha256"] = hashlib.sha256(ref(tmp, "pa", sp1)).hexdigest()
         # qts writes a BLOW5: keep a digest of what a reader sees in the reference's output (ids, scaling, signal)
         for bits, method in ((1, "round"), (3, "round"), (2, "floor"), (4, "fill-ones")):
             outp = os.path.join(tmp, "q.blow5")

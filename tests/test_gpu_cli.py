@@ -66,6 +66,8 @@ def test_sp1_outputs(cli, fname, args):
 
 def test_sp1_event_long_form_hash(cli):
     assert hashlib.sha256(out(cli, "event", SP1)).hexdigest() == MANIFEST["sp1_dna.event.tsv.sha256"]
+    # BASELINE config 1: `sigtk pa` on the whole bundled file, byte for byte what the reference prints
+    assert hashlib.sha256(out(cli, "pa", SP1)).hexdigest() == MANIFEST["sp1_dna.pa.tsv.sha256"]
 
 
 def test_reference_golden_event_dna_exp(cli):
