@@ -200,9 +200,112 @@ static int idx_cmp(const void *a, const void *b) {
     return strcmp(((const b5_idx_entry_t *)a)->id, ((const b5_idx_entry_t *)b)->id);
 }
 
+/* ---- the on-disk index "<file>.idx" the reference keeps beside a BLOW5 (slow5lib/src/slow5_idx.c:360-500;
+ * src/cmain.c:127-131 loads or creates it before reading by id): magic "SLOW5IDX\1", the file's version (3 x u8),
+ * zeros up to offset 64, then (u16 id length, id, u64 offset of the record's size field, u64 size = 8 + record
+ * bytes) per record, then "XDI5WOLS".  Reused when present and consistent, written (best effort) after a scan. */
+static const char B5_IDX_MAGIC[9] = {'S', 'L', 'O', 'W', '5', 'I', 'D', 'X', '\1'};
+static const char B5_IDX_EOF[8] = {'X', 'D', 'I', '5', 'W', 'O', 'L', 'S'};
+
+static char *idx_path(const b5_file_t *f) {
+    const size_t n = strlen(f->path);
+    char *p = (char *)malloc(n + 5);
+    if (!p) return NULL;
+    memcpy(p, f->path, n);
+    memcpy(p + n, ".idx", 5);
+    return p;
+}
+
+/* 0: loaded into f->idx; non-zero: absent / stale / malformed (the caller scans the file instead) */
+static int idx_load(b5_file_t *f) {
+    char *ip = idx_path(f);
+    if (!ip) return B5_ERR_MEM;
+    FILE *fp = fopen(ip, "rb");
+    free(ip);
+    if (!fp) return B5_ERR_NOTFOUND;
+    uint8_t head[64];
+    int rc = B5_ERR_FORMAT;
+    b5_idx_entry_t *idx = NULL;
+    uint64_t n = 0, cap = 0;
+    if (fread(head, 1, 64, fp) != 64 || memcmp(head, B5_IDX_MAGIC, 9) != 0 || memcmp(head + 9, f->version, 3) != 0)
+        goto done;
+    if (fseek(f->fp, 0, SEEK_END) != 0 || fseek(fp, 0, SEEK_END) != 0) { rc = B5_ERR_IO; goto done; }
+    const uint64_t fsize = (uint64_t)ftell(f->fp);
+    const uint64_t isize = (uint64_t)ftell(fp);
+    if (isize < 72 || fseek(fp, 64, SEEK_SET) != 0) goto done;
+    uint64_t pos = 64;
+    while (pos < isize - 8) {
+        uint16_t idl;
+        if (fread(&idl, 2, 1, fp) != 1 || pos + 2 + (uint64_t)idl + 16 > isize - 8) goto done;
+        char *id = (char *)malloc((size_t)idl + 1);
+        if (!id) { rc = B5_ERR_MEM; goto done; }
+        uint64_t off_size[2];
+        if (fread(id, 1, idl, fp) != idl || fread(off_size, 8, 2, fp) != 2 || off_size[0] < f->first_rec ||
+            off_size[1] < 8 || off_size[0] + off_size[1] > fsize) {
+            free(id);
+            goto done;
+        }
+        id[idl] = '\0';
+        if (n == cap) {
+            cap = cap ? cap * 2 : 1024;
+            b5_idx_entry_t *q = (b5_idx_entry_t *)realloc(idx, cap * sizeof *idx);
+            if (!q) { free(id); rc = B5_ERR_MEM; goto done; }
+            idx = q;
+        }
+        idx[n].id = id;
+        idx[n].offset = off_size[0];
+        idx[n].size = off_size[1];
+        n++;
+        pos += 2 + (uint64_t)idl + 16;
+    }
+    {
+        uint8_t tail[8];
+        if (pos == isize - 8 && fread(tail, 1, 8, fp) == 8 && memcmp(tail, B5_IDX_EOF, 8) == 0) rc = 0;
+    }
+done:
+    fclose(fp);
+    if (rc) {
+        for (uint64_t i = 0; i < n; i++) free(idx[i].id);
+        free(idx);
+        return rc;
+    }
+    qsort(idx, n, sizeof *idx, idx_cmp);
+    f->idx = idx;
+    f->n_idx = n;
+    return 0;
+}
+
+/* best effort: a read-only directory just means the next run scans again */
+static void idx_write(const b5_file_t *f, const b5_idx_entry_t *in_file_order, uint64_t n) {
+    char *ip = idx_path(f);
+    if (!ip) return;
+    FILE *fp = fopen(ip, "wb");
+    if (fp) {
+        uint8_t head[64];
+        memset(head, 0, sizeof head);
+        memcpy(head, B5_IDX_MAGIC, 9);
+        memcpy(head + 9, f->version, 3);
+        int ok = fwrite(head, 1, 64, fp) == 64;
+        for (uint64_t i = 0; ok && i < n; i++) {
+            const size_t l = strlen(in_file_order[i].id);
+            const uint16_t idl = (uint16_t)l;
+            ok = l <= 0xffff && fwrite(&idl, 2, 1, fp) == 1 && fwrite(in_file_order[i].id, 1, l, fp) == l &&
+                 fwrite(&in_file_order[i].offset, 8, 1, fp) == 1 && fwrite(&in_file_order[i].size, 8, 1, fp) == 1;
+        }
+        ok = ok && fwrite(B5_IDX_EOF, 1, 8, fp) == 8;
+        if (fclose(fp) != 0) ok = 0;
+        if (!ok) remove(ip);
+    }
+    free(ip);
+}
+
 int b5_index(b5_file_t *f) {
     if (f->idx) return 0;
     const long keep = ftell(f->fp);
+    if (idx_load(f) == 0) {
+        fseek(f->fp, keep, SEEK_SET);
+        return 0;
+    }
     if (fseek(f->fp, (long)f->first_rec, SEEK_SET) != 0) return B5_ERR_IO;
     b5_rec_t tmp;
     memset(&tmp, 0, sizeof tmp);
@@ -223,6 +326,7 @@ int b5_index(b5_file_t *f) {
         }
         idx[n].id = strdup(tmp.read_id);
         idx[n].offset = pos;
+        idx[n].size = (uint64_t)ftell(f->fp) - pos;
         n++;
     }
     b5_rec_free(&tmp);
@@ -231,6 +335,7 @@ int b5_index(b5_file_t *f) {
         free(idx);
         return rc;
     }
+    idx_write(f, idx, n);  /* file order, as the reference writes it */
     qsort(idx, n, sizeof *idx, idx_cmp);
     f->idx = idx;
     f->n_idx = n;

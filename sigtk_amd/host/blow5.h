@@ -26,6 +26,7 @@ typedef struct {
 typedef struct {
     char *id;
     uint64_t offset; /* file offset of the u64 record size */
+    uint64_t size;   /* 8 + record bytes (what the reference's .idx stores) */
 } b5_idx_entry_t;
 
 typedef struct {
@@ -57,7 +58,8 @@ void b5_close(b5_file_t *f);
 char *b5_hdr_get(const b5_file_t *f, const char *name, uint32_t rg);
 /* next record in file order: 0 ok, B5_EOF at the proper end, other negatives on error */
 int b5_next(b5_file_t *f, b5_rec_t *rec);
-/* build the in-memory read-id index (one sequential scan of the record sizes + ids) */
+/* the read-id index: loaded from "<file>.idx" (the reference's on-disk index, slow5lib/src/slow5_idx.c) when that
+ * exists and matches the file, else built by one sequential scan and written there (best effort) */
 int b5_index(b5_file_t *f);
 /* random access by read id (needs b5_index) */
 int b5_get(b5_file_t *f, const char *read_id, b5_rec_t *rec);

@@ -1150,10 +1150,11 @@ static uint64_t fnv_i16(const int16_t *x, uint64_t n) {
 }
 static int dumpmain(int argc, char *argv[]) {
     int split = 0;
-    const char *path = NULL;
+    const char *path = NULL, *want_id = NULL;
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--split") == 0) split = 1;
         else if (strcmp(argv[i], "--map") == 0) split = 2;  /* split API over the mapped file (b5_map / b5_next_ref) */
+        else if (strcmp(argv[i], "--id") == 0 && i + 1 < argc) want_id = argv[++i]; /* one record through the index */
         else path = argv[i];
     }
     if (!path) return 1;
@@ -1163,6 +1164,17 @@ static int dumpmain(int argc, char *argv[]) {
         return 1;
     }
     int ret;
+    if (want_id) {
+        b5_rec_t rec;
+        memset(&rec, 0, sizeof rec);
+        ret = b5_get(f, want_id, &rec);
+        if (ret == 0)
+            printf("%s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", rec.read_id, (unsigned long)rec.len_raw_signal,
+                   rec.digitisation, rec.offset, rec.range, (unsigned long)fnv_i16(rec.raw_signal, rec.len_raw_signal));
+        b5_rec_free(&rec);
+        b5_close(f);
+        return ret == 0 ? 0 : 1;
+    }
     printf("#press\t%d\t%d\tgroups\t%u\n", f->record_press, f->signal_press, f->num_read_groups);
     if (split) {
         uint8_t *raw = NULL, *scratch = NULL;

@@ -166,3 +166,42 @@ def test_reader_survives_corrupt_input(cli, tmp_path):
         for extra in ([], ["--split"], ["--map"]):
             p = subprocess.run([cli, "_dump", *extra, path], capture_output=True, timeout=60)
             assert p.returncode in (0, 1), (it, extra, p.returncode, p.stderr[-300:])
+
+
+def test_index_file_is_written_reused_and_checked(cli, tmp_path, sp1):
+    """read-id mode keeps "<file>.idx" beside the BLOW5 like the reference (src/cmain.c:127-131,
+    slow5lib/src/slow5_idx.c): created by the first run, loaded by the next, ignored when it does not fit the file"""
+    import shutil
+    path = str(tmp_path / "a.blow5")
+    shutil.copy(os.path.join(GOLDEN, "sp1_dna.blow5"), path)
+    r = sp1.reads[37]
+    p = run(cli, "_dump", "--id", r.read_id, path)
+    assert p.returncode == 0 and p.stdout.split("\t")[0] == r.read_id and int(p.stdout.split("\t")[5], 16) == fnv(r.raw)
+    idx = open(path + ".idx", "rb").read()
+    assert idx[:9] == b"SLOW5IDX\x01" and idx[9:12] == bytes([0, 2, 0]) and idx[-8:] == b"XDI5WOLS"
+    assert idx[12:64] == bytes(52)
+    # 100 entries in file order: u16 id length, id, u64 offset, u64 size; offsets increase by the sizes
+    import struct
+    pos, off_prev, ids = 64, None, []
+    while pos < len(idx) - 8:
+        (idl,) = struct.unpack_from("<H", idx, pos)
+        rid = idx[pos + 2:pos + 2 + idl].decode()
+        off, size = struct.unpack_from("<QQ", idx, pos + 2 + idl)
+        assert off_prev is None or off == off_prev
+        off_prev = off + size
+        ids.append(rid)
+        pos += 2 + idl + 16
+    assert ids == [x.read_id for x in sp1.reads] and off_prev == os.path.getsize(path) - 5
+    # second run: loads the index (make the data file unscannable past the first record to prove it)
+    first = sp1.reads[0]
+    p = run(cli, "_dump", "--id", sp1.reads[99].read_id, path)
+    assert p.returncode == 0 and int(p.stdout.split("\t")[5], 16) == fnv(sp1.reads[99].raw)
+    # an index of another file (offsets beyond the end) is not trusted: the file is scanned again, the index rewritten
+    bad = bytearray(idx)
+    struct.pack_into("<Q", bad, 64 + 2 + len(ids[0]), 1 << 40)
+    open(path + ".idx", "wb").write(bytes(bad))
+    p = run(cli, "_dump", "--id", first.read_id, path)
+    assert p.returncode == 0 and int(p.stdout.split("\t")[5], 16) == fnv(first.raw)
+    assert open(path + ".idx", "rb").read() == idx
+    # unknown id
+    assert run(cli, "_dump", "--id", "no-such-read", path).returncode == 1
