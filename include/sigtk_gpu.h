@@ -381,6 +381,50 @@ float *sgk_signal_in_picoamps(const int16_t *raw, uint64_t len_raw_signal, doubl
 /* event_table getevents(size_t nsample, float *rawptr, int8_t rna) (src/events.c:553) */
 sgk_event_table sgk_getevents(size_t nsample, float *rawptr, int8_t rna);
 
+/* jnn_pair_t, jnn_param_t, jnnv2_param_t exactly as src/jnn.h:13-16, 18-27, 74-81 */
+typedef struct {
+    int64_t x;
+    int64_t y;
+} sgk_jnn_pair_t;
+typedef struct {
+    float std_scale;
+    int corrector;
+    int seg_dist;
+    int window;
+    float stall_len;
+    int error;
+    float top;
+    float bot;
+} sgk_jnn_param_t;
+typedef struct {
+    float std_scale;
+    int seg_dist;
+    int window; /* must be 2000 (both presets of the reference): the rolling mean divides by it exactly */
+    float stall_len;
+    int hi_thresh;
+    int lo_thresh;
+} sgk_jnnv2_param_t;
+/* jnn_pair_t *jnn_raw(const int16_t*, int64_t, jnn_param_t, int *n) (src/jnn.c:282): malloc'd, caller frees; NULL with
+ * *n = 0 for an empty read, as the reference */
+sgk_jnn_pair_t *sgk_jnn_raw(const int16_t *raw, int64_t nsample, sgk_jnn_param_t param, int *n);
+/* jnn_pair_t *jnn_pa(const float*, int64_t, jnn_param_t, int *n) (src/jnn.c:295) */
+sgk_jnn_pair_t *sgk_jnn_pa(const float *raw, int64_t nsample, sgk_jnn_param_t param, int *n);
+/* jnn_pair_t jnnv2(const int16_t*, int64_t, jnnv2_param_t) (src/jnn.c:99): {-1,-1} when nsample <= window */
+sgk_jnn_pair_t sgk_jnnv2(const int16_t *sig, int64_t nsample, sgk_jnnv2_param_t param);
+/* jnn_pair_t find_adaptor(slow5_rec_t*, int8_t pore) (src/jnn.c:181): the record's raw signal and its length */
+sgk_jnn_pair_t sgk_find_adaptor(const int16_t *raw, int64_t nsample, int8_t pore);
+/* jnn_pair_t find_polya(const float*, int64_t, float top, float bot, int8_t pore) (src/jnn.c:352) */
+sgk_jnn_pair_t sgk_find_polya(const float *raw, int64_t nsample, float top, float bot, int8_t pore);
+/* the six inlines of src/stat.h:17-73 (sequential float sums in sample order; medians = rank n/2) */
+float sgk_meanf(const float *x, int n);
+float sgk_meani16(const int16_t *x, int n);
+float sgk_stdvf(const float *x, int n);
+float sgk_stdvi16(const int16_t *x, int n);
+float sgk_medianf(const float *x, int n);
+int16_t sgk_mediani16(const int16_t *x, int n);
+/* SGK_OK, or why the last shim call of this thread returned NULL / {-1,-1} / NaN */
+int sgk_shim_status(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,32 @@ class Oracle:
                                  _p(y, C.c_int64), C.c_int64(cap))
         return x[:k].copy(), y[:k].copy()
 
+    def jnn_param(self, **kw) -> "_JnnParam":
+        """jnn_param_t (src/jnn.h:18-27) from keywords"""
+        return _JnnParam(kw.get("std_scale", 0.75), kw.get("corrector", 50), kw.get("seg_dist", 50),
+                         kw.get("window", 150), kw.get("stall_len", 0.25), kw.get("error", 5),
+                         kw.get("top", 0.0), kw.get("bot", 0.0))
+
+    def jnn_core(self, sig, p: "_JnnParam"):
+        """jnn_core (src/jnn.c:190-278) on an already-clamped float signal, any jnn_param_t"""
+        sig = np.ascontiguousarray(sig, dtype=np.float32)
+        cap = sig.size // 2 + 16
+        x = np.empty(cap, dtype=np.int64)
+        y = np.empty(cap, dtype=np.int64)
+        k = self.lib.orc_jnn_core(_p(sig, C.c_float), C.c_int64(sig.size), p, _p(x, C.c_int64), _p(y, C.c_int64),
+                                  C.c_int64(cap))
+        return x[:k].copy(), y[:k].copy()
+
+    def jnn_pa(self, pa, p: "_JnnParam"):
+        """jnn_pa (src/jnn.c:295-306): rm_outlierf then jnn_core"""
+        pa = np.ascontiguousarray(pa, dtype=np.float32)
+        cap = pa.size // 2 + 16
+        x = np.empty(cap, dtype=np.int64)
+        y = np.empty(cap, dtype=np.int64)
+        k = self.lib.orc_jnn_pa(_p(pa, C.c_float), C.c_int64(pa.size), p, _p(x, C.c_int64), _p(y, C.c_int64),
+                                C.c_int64(cap))
+        return x[:k].copy(), y[:k].copy()
+
     def find_adaptor(self, raw, pore):
         raw = np.ascontiguousarray(raw, dtype=np.int16)
         xy = np.zeros(2, dtype=np.int64)

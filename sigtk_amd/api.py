@@ -102,6 +102,9 @@ ABI_SYMBOLS = [
     "sgk_job_create", "sgk_job_destroy", "sgk_job_device", "sgk_job_begin", "sgk_job_submit", "sgk_job_submit_qts",
     "sgk_job_wait",
     "sgk_job_output",
+    # per-read shims with the reference's signatures (csrc/shims.hip)
+    "sgk_jnn_raw", "sgk_jnn_pa", "sgk_jnnv2", "sgk_find_adaptor", "sgk_find_polya",
+    "sgk_meanf", "sgk_meani16", "sgk_stdvf", "sgk_stdvi16", "sgk_medianf", "sgk_mediani16", "sgk_shim_status",
 ]
 
 
@@ -300,6 +303,112 @@ def synth_reads_host(n_reads: int, read_len, seed: int, kind: int, first_read: i
                            off.ctypes.data, rng.ctypes.data, n_reads, first_read, seed, kind)
     reads = [samples[int(offs[r]):int(offs[r]) + int(lens[r])].copy() for r in range(n_reads)]
     return reads, dig[:n_reads], off[:n_reads], rng[:n_reads]
+
+
+# ---- per-read shims with the reference's own signatures (include/sigtk_gpu.h, csrc/shims.hip) -----------------
+class JnnPair(C.Structure):
+    _fields_ = [("x", C.c_int64), ("y", C.c_int64)]
+
+
+class JnnParam(C.Structure):   # jnn_param_t, src/jnn.h:18-27
+    _fields_ = [("std_scale", C.c_float), ("corrector", C.c_int), ("seg_dist", C.c_int), ("window", C.c_int),
+                ("stall_len", C.c_float), ("error", C.c_int), ("top", C.c_float), ("bot", C.c_float)]
+
+
+class Jnnv2Param(C.Structure):  # jnnv2_param_t, src/jnn.h:74-81
+    _fields_ = [("std_scale", C.c_float), ("seg_dist", C.c_int), ("window", C.c_int), ("stall_len", C.c_float),
+                ("hi_thresh", C.c_int), ("lo_thresh", C.c_int)]
+
+
+def _shim_lib():
+    L = load_library()
+    if not getattr(L, "_shims_bound", False):
+        L.sgk_jnn_raw.restype = C.POINTER(JnnPair)
+        L.sgk_jnn_raw.argtypes = [C.c_void_p, C.c_int64, JnnParam, C.POINTER(C.c_int)]
+        L.sgk_jnn_pa.restype = C.POINTER(JnnPair)
+        L.sgk_jnn_pa.argtypes = [C.c_void_p, C.c_int64, JnnParam, C.POINTER(C.c_int)]
+        L.sgk_jnnv2.restype = JnnPair
+        L.sgk_jnnv2.argtypes = [C.c_void_p, C.c_int64, Jnnv2Param]
+        L.sgk_find_adaptor.restype = JnnPair
+        L.sgk_find_adaptor.argtypes = [C.c_void_p, C.c_int64, C.c_int8]
+        L.sgk_find_polya.restype = JnnPair
+        L.sgk_find_polya.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int8]
+        for f in ("sgk_meanf", "sgk_stdvf", "sgk_medianf", "sgk_meani16", "sgk_stdvi16"):
+            getattr(L, f).restype = C.c_float
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+        L.sgk_mediani16.restype = C.c_int16
+        L.sgk_mediani16.argtypes = [C.c_void_p, C.c_int]
+        L._libc_free = C.CDLL(None).free
+        L._libc_free.argtypes = [C.c_void_p]
+        L._shims_bound = True
+    return L
+
+
+def _segs(L, ptr, n):
+    out = [(int(ptr[k].x), int(ptr[k].y)) for k in range(n)] if ptr else []
+    if ptr:
+        L._libc_free(ptr)
+    return out
+
+
+def shim_jnn_raw(raw, param: JnnParam):
+    """jnn_raw(raw, n, param, &n) -> list of (x, y); raises on a shim error"""
+    L = _shim_lib()
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    n = C.c_int(0)
+    ptr = L.sgk_jnn_raw(raw.ctypes.data, raw.size, param, C.byref(n))
+    check(L.sgk_shim_status(), "sgk_jnn_raw")
+    return _segs(L, ptr, n.value)
+
+
+def shim_jnn_pa(pa, param: JnnParam):
+    L = _shim_lib()
+    pa = np.ascontiguousarray(pa, dtype=np.float32)
+    n = C.c_int(0)
+    ptr = L.sgk_jnn_pa(pa.ctypes.data, pa.size, param, C.byref(n))
+    check(L.sgk_shim_status(), "sgk_jnn_pa")
+    return _segs(L, ptr, n.value)
+
+
+def shim_jnnv2(raw, param: Jnnv2Param):
+    L = _shim_lib()
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    p = L.sgk_jnnv2(raw.ctypes.data, raw.size, param)
+    return (int(p.x), int(p.y)), L.sgk_shim_status()
+
+
+def shim_find_adaptor(raw, pore: int):
+    L = _shim_lib()
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    p = L.sgk_find_adaptor(raw.ctypes.data, raw.size, pore)
+    check(L.sgk_shim_status(), "sgk_find_adaptor")
+    return int(p.x), int(p.y)
+
+
+def shim_find_polya(pa, top: float, bot: float, pore: int):
+    L = _shim_lib()
+    pa = np.ascontiguousarray(pa, dtype=np.float32)
+    p = L.sgk_find_polya(pa.ctypes.data, pa.size, top, bot, pore)
+    check(L.sgk_shim_status(), "sgk_find_polya")
+    return int(p.x), int(p.y)
+
+
+def shim_stat_f32(x):
+    """(meanf, stdvf, medianf) of a float array through the three shims"""
+    L = _shim_lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = tuple(np.float32(getattr(L, f)(x.ctypes.data, x.size)) for f in ("sgk_meanf", "sgk_stdvf", "sgk_medianf"))
+    check(L.sgk_shim_status(), "sgk_*f")
+    return out
+
+
+def shim_stat_i16(x):
+    L = _shim_lib()
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    out = (np.float32(L.sgk_meani16(x.ctypes.data, x.size)), np.float32(L.sgk_stdvi16(x.ctypes.data, x.size)),
+           int(L.sgk_mediani16(x.ctypes.data, x.size)))
+    check(L.sgk_shim_status(), "sgk_*i16")
+    return out
 
 
 def profile_read():

@@ -60,7 +60,7 @@ int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *s
     a.seg_y = seg_y;
     a.n_segs = n_segs;
     a.err_count = static_cast<uint32_t *>(ws);
-    return launch_jnn(a, rna, static_cast<hipStream_t>(stream));
+    return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
 int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,

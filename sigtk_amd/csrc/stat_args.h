@@ -17,10 +17,33 @@ struct StatArgs {
     float *pa_out;               // stat+pa fused: pA of every sample, written by the median pass (or null)
 };
 
+// jnn_param_t (src/jnn.h:18-27) and the run-finder part of jnnv2_param_t (src/jnn.h:74-81; its window is fixed at
+// 2000, the value of both presets: the rolling mean divides by it with the exact constant division)
+struct JnnP {
+    float std_scale;
+    int corrector, seg_dist, window;
+    float stall_len;
+    int error;
+    float top, bot;
+};
+struct AdaptP {
+    float std_scale;
+    int seg_dist, lo_thresh, hi_thresh;
+};
+JnnP jnn_preset(int rna);          // jnn_print's presets (src/jnn.c:313-319)
+JnnP jnn_polya_preset();           // JNNV1_R9_POLYA == JNNV1_RNA004_POLYA (src/jnn.h:52-72)
+AdaptP adaptor_preset(int pore);   // find_adaptor's presets (src/jnn.c:181-188)
+
 int check_batch(const sgk_batch_t *b);
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
 int launch_stat(const StatArgs &a, hipStream_t st);  // a.pa_out != null: fused stat + pa
-int launch_jnn(const StatArgs &a, int rna, hipStream_t st);
+int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st);
 int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st);
+int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st);  // jnnv2 only: prefix[r].adapt_x / adapt_y
+// reference-signature shims on float input (one array per call): sequential float moments + order statistic, and
+// jnn_core over rm_outlierf(x); device pointers
+int launch_stat_f32(const float *x, int n, float *out3, hipStream_t st);
+int launch_jnn_f32(const float *x, int64_t n, const JnnP &p, int32_t *seg_x, int32_t *seg_y, uint32_t cap,
+                   uint32_t *n_segs, hipStream_t st);
 
 }  // namespace sgk

@@ -474,8 +474,30 @@ struct JnnAuto {
     }
 };
 
-// jnn_raw with jnn_print's presets (src/jnn.c:282-293, :313-319; presets src/jnn.h:29-49)
-__global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
+JnnP jnn_preset(int rna) {  // JNNV1_DRNA_R9_PARAM / JNNV1_CDNA_R9_PARAM, src/jnn.h:29-49
+    JnnP p;
+    p.std_scale = 0.75f; p.corrector = 50; p.seg_dist = 50; p.error = 5; p.top = 0.0f; p.bot = 0.0f;
+    if (rna) { p.window = 1000; p.stall_len = 1.0f; }
+    else { p.window = 150; p.stall_len = 0.25f; }
+    return p;
+}
+JnnP jnn_polya_preset() {  // src/jnn.h:52-72
+    JnnP p;
+    p.std_scale = -1.0f; p.corrector = 50; p.seg_dist = 200; p.window = 250; p.stall_len = 1.0f; p.error = 30;
+    p.top = 0.0f; p.bot = 0.0f;
+    return p;
+}
+AdaptP adaptor_preset(int pore) {  // JNNV2_RNA_R9_ADAPTOR / JNNV2_RNA_RNA004_ADAPTOR, src/jnn.h:84-98
+    AdaptP p;
+    p.std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
+    p.seg_dist = 1500;
+    p.lo_thresh = (pore == SGK_PORE_RNA004) ? 500 : 2000;
+    p.hi_thresh = 200000;
+    return p;
+}
+
+// jnn_raw (src/jnn.c:282-293): jnn_core over rm_outlier(raw) with any jnn_param_t
+__global__ __launch_bounds__(64) void k_jnn(StatArgs a, JnnP p) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
     const bool valid = r < a.b.n_reads;
@@ -483,20 +505,24 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
     if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
     int skip;
     Stream1 rs = make_stream(lds, a.b, g.start, valid && g.len > 0, skip);
-    const float nf = (float)(int)g.len;
-    float s = 0.0f;
-    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) { s = s + clampf_raw(v); });
-    const float mn = s / nf;
-    float q = 0.0f;
-    sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
-        const float d = clampf_raw(v) - mn;
-        q = q + d * d;
-    });
-    const float sd = sqrtf(q / nf);
-    const float band = sd * 0.75f;
+    float top = p.top, bot = p.bot;
+    if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
+        const float nf = (float)(int)g.len;
+        float s = 0.0f;
+        sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) { s = s + clampf_raw(v); });
+        const float mn = s / nf;
+        float q = 0.0f;
+        sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
+            const float d = clampf_raw(v) - mn;
+            q = q + d * d;
+        });
+        const float sd = sqrtf(q / nf);
+        const float band = sd * p.std_scale;
+        top = mn + band;
+        bot = mn - band;
+    }
     JnnAuto A;
-    if (rna) A.init(mn + band, mn - band, 50, 50, 1000, 1.0f, 5);
-    else A.init(mn + band, mn - band, 50, 50, 150, 0.25f, 5);
+    A.init(top, bot, p.corrector, p.seg_dist, p.window, p.stall_len, p.error);
     const uint64_t slot0 = valid ? a.seg_slots[r] : 0, cap = valid ? a.seg_slots[r + 1] - slot0 : 0;
     bool overflow = false;
     auto emit = [&](int k, int x, int y) {
@@ -507,6 +533,92 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, int rna) {
     A.finish(emit);
     if (valid) a.n_segs[r] = (uint32_t)A.nseg;
     if (overflow) atomicAdd(a.err_count, 1u);
+}
+
+// jnn_pa (src/jnn.c:295-306) on ONE float array: jnn_core over rm_outlierf(x).  A compatibility entry (the batched
+// path never holds pA in memory); every lane of the single wave walks the array, lane 0 stores.
+__global__ __launch_bounds__(64) void k_jnn_f32(const float *x, int64_t n, JnnP p, int32_t *seg_x, int32_t *seg_y,
+                                                uint32_t cap, uint32_t *n_segs) {
+    float top = p.top, bot = p.bot;
+    if (p.std_scale > 0.0f) {
+        float s = 0.0f;
+        for (int64_t j = 0; j < n; ++j) s = s + clampf_pa(x[j]);
+        const float mn = s / (float)(int)n;
+        float q = 0.0f;
+        for (int64_t j = 0; j < n; ++j) {
+            const float d = clampf_pa(x[j]) - mn;
+            q = q + d * d;
+        }
+        const float sd = sqrtf(q / (float)(int)n);
+        top = mn + sd * p.std_scale;
+        bot = mn - sd * p.std_scale;
+    }
+    JnnAuto A;
+    A.init(top, bot, p.corrector, p.seg_dist, p.window, p.stall_len, p.error);
+    bool overflow = false;
+    const bool writer = lane_id() == 0;
+    auto emit = [&](int k, int sx, int sy) {
+        if ((uint32_t)k < cap) { if (writer) { seg_x[k] = sx; seg_y[k] = sy; } }
+        else overflow = true;
+    };
+    for (int64_t j = 0; j < n; ++j) A.step((int)j, A.in_mask_f(clampf_pa(x[j])), emit);
+    A.finish(emit);
+    if (writer) {
+        n_segs[0] = (uint32_t)A.nseg;
+        n_segs[1] = overflow ? 1u : 0u;
+    }
+}
+
+// meanf / stdvf / medianf (src/stat.h:17-27, 36-44, 56-63) of ONE float array, for the reference-signature shims:
+// the sequential float sums on every lane of the wave (lane 0 stores), the order statistic of rank n/2 by a
+// three-level (11 + 11 + 10 bit) radix select on the order-preserving integer image of the floats.
+__global__ __launch_bounds__(256) void k_stat_f32(const float *x, int n, float *out3) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t sel_prefix, sel_rank;
+    if (threadIdx.x < 64) {
+        float s = 0.0f;
+        for (int j = 0; j < n; ++j) s = s + x[j];
+        const float mn = s / n;
+        float q = 0.0f;
+        for (int j = 0; j < n; ++j) q = q + (x[j] - mn) * (x[j] - mn);
+        if (threadIdx.x == 0) { out3[0] = mn; out3[1] = sqrtf(q / n); }
+    }
+    auto key = [](float f) -> uint32_t {
+        const uint32_t u = __float_as_uint(f);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    };
+    uint32_t prefix = 0u, rank = (uint32_t)(n / 2);
+    const int shifts[3] = {21, 10, 0};
+    const int bitsn[3] = {11, 11, 10};
+    uint32_t known = 0u;  // mask of the key bits fixed so far
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        for (int k = threadIdx.x; k < 2048; k += 256) hist[k] = 0u;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const uint32_t kk = key(x[j]);
+            if ((kk & known) == prefix) atomicAdd(&hist[(kk >> shifts[lvl]) & ((1u << bitsn[lvl]) - 1u)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0u, b = 0u;
+            const uint32_t nb = 1u << bitsn[lvl];
+            for (; b < nb; ++b) {
+                if (acc + hist[b] > rank) break;
+                acc += hist[b];
+            }
+            sel_prefix = prefix | (b << shifts[lvl]);
+            sel_rank = rank - acc;
+        }
+        __syncthreads();
+        prefix = sel_prefix;
+        rank = sel_rank;
+        known |= ((1u << bitsn[lvl]) - 1u) << shifts[lvl];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+        out3[2] = __uint_as_float(u);
+    }
 }
 
 // find_polya (src/jnn.c:352-374): first segment of jnn_pa on pA[adapt_y..n) with fixed thresholds
@@ -527,7 +639,8 @@ __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
     Stream1 rs = make_stream(lds, a.b, g.start, valid && g.len > 0, skip);
     const float mid = m_a + 30.0f;
     JnnAuto A;
-    A.init(mid + 20.0f, mid - 20.0f, 50, 200, 250, 1.0f, 30);
+    const JnnP pp = {-1.0f, 50, 200, 250, 1.0f, 30, 0.0f, 0.0f};  // JNNV1_R9_POLYA, src/jnn.h:52-61
+    A.init(mid + 20.0f, mid - 20.0f, pp.corrector, pp.seg_dist, pp.window, pp.stall_len, pp.error);
     int px = -1, py = -1;
     auto emit = [&](int k, int x, int y) {
         if (k == 0) { px = x; py = y; }
@@ -688,7 +801,7 @@ __device__ inline int roll_threshold(float x, bool strict) {
     return lo;
 }
 
-__global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
+__global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, AdaptP ap) {
     __shared__ __attribute__((aligned(16))) char lds[2 * Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
     const bool valid = r < a.b.n_reads;
@@ -714,10 +827,9 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, int pore) {
         q = q + d * d;
     });
     const float sd = sqrtf(q / mf);
-    const float std_scale = (pore == SGK_PORE_RNA004) ? 0.7f : 0.5f;
     RunFinder F;
-    const float bot = mn - sd * std_scale;
-    F.init(roll_threshold(bot, false), roll_threshold(bot, true), 1500, (pore == SGK_PORE_RNA004) ? 500 : 2000, 200000);
+    const float bot = mn - sd * ap.std_scale;
+    F.init(roll_threshold(bot, false), roll_threshold(bot, true), ap.seg_dist, ap.lo_thresh, ap.hi_thresh);
     // the answer is the first qualifying segment (the reference breaks out of its segment list, src/jnn.c:154-167),
     // and a segment is final once a later one has started without merging into it: nothing after that changes it
     sweep_rolling(lead, trail, skip, n, [&](int i, int tot) { F.step(i, tot); }, [&]() { return !run || F.found != 0; });
@@ -752,11 +864,32 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
     return SGK_OK;
 }
 
-int launch_jnn(const StatArgs &a, int rna, hipStream_t st) {
+int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
-    SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, rna);
+    SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
+    const uint32_t nr = a.b.n_reads;
+    if (nr == 0) return SGK_OK;
+    SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_stat_f32(const float *x, int n, float *out3, hipStream_t st) {
+    SGK_LAUNCH("k_stat_f32", k_stat_f32, 1, 256, x, n, out3);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
+int launch_jnn_f32(const float *x, int64_t n, const JnnP &p, int32_t *seg_x, int32_t *seg_y, uint32_t cap,
+                   uint32_t *n_segs, hipStream_t st) {
+    SGK_LAUNCH("k_jnn_f32", k_jnn_f32, 1, 64, x, n, p, seg_x, seg_y, cap, n_segs);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -765,7 +898,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, pore);
+    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     SGK_HIP_TRY(hipGetLastError());
     SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
     SGK_HIP_TRY(hipGetLastError());
