@@ -2,14 +2,17 @@
 """Summarise the rocprofv3 --pmc passes of tools/refresh_profiles.sh into profiles/pmc_traffic.json.
 
 usage: python tools/pmc_summary.py gpurun_out/<tag> [out.json]
-Reads <tag>/pmc_fetch, pmc_write, pmc_sq (counter_collection.csv of the newest run in each), averages every
-counter over the dispatches of k_event_detect / k_event_build, and applies the corrections documented in the
-"_comment" field (units: FETCH_SIZE / WRITE_SIZE are KiB)."""
+Reads <tag>/pmc_fetch, pmc_write, pmc_sq (counter_collection.csv of the newest run in each), averages every counter
+over the dispatches of each event kernel, and prices the HBM traffic as MI355X_MICROARCH.md (HBM) prescribes (units:
+FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes)."""
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
+
+KERNELS = ("k_event_detect", "k_event_build", "k_event_fallback", "k_event")
 
 
 def newest(d):
@@ -19,14 +22,21 @@ def newest(d):
     return fs[-1]
 
 
+def kname(name):
+    # longest match first: "k_event<" is the fused kernel, "k_event_detect<" etc. the separate ones
+    for k in ("k_event_detect", "k_event_build", "k_event_fallback"):
+        if k in name:
+            return k
+    return "k_event" if "k_event" in name else None
+
+
 def per_kernel(path):
     acc = {}
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"]
-        for k in ("k_event_detect", "k_event_build"):
-            if k in name:
-                acc.setdefault(k, {}).setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-                acc[k][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        k = kname(row["Kernel_Name"])
+        if k:
+            acc.setdefault(k, {}).setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[k][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -36,47 +46,46 @@ def main():
     fetch = per_kernel(newest(os.path.join(tag, "pmc_fetch")))
     write = per_kernel(newest(os.path.join(tag, "pmc_write")))
     sq = per_kernel(newest(os.path.join(tag, "pmc_sq")))
-    raw = {k: {"FETCH_SIZE": round(fetch[k]["FETCH_SIZE"]), "WRITE_SIZE": round(write[k]["WRITE_SIZE"])}
-           for k in ("k_event_detect", "k_event_build")}
-    # corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-byte requests at 64 bytes, so it
-    # under-counts by up to 2x depending on the request mix, and patterns other than the plain 16 B/lane stream are
-    # to be calibrated on a known byte count.  The builder reads every sample and every bitmap word exactly once
-    # (S*2 + S/8 bytes, S = 1e9 samples in bench config 2): that known count is its calibrated read volume (it lies
-    # between the raw count and twice the raw count, both kept in "raw_kib").  The detector's lane-strided 32-byte
-    # pieces are taken at face value (true value between 1x and 2x of the raw count).
-    S = 10000 * 100000
-    known_build_read = 2 * S + S // 8
-    rb = raw["k_event_build"]["FETCH_SIZE"] * 1024
-    build_read = min(max(rb, known_build_read), 2 * rb)
-    b = {"k_event_detect": {"read": raw["k_event_detect"]["FETCH_SIZE"] * 1024,
-                            "write": raw["k_event_detect"]["WRITE_SIZE"] * 1024},
-         "k_event_build": {"read": build_read, "write": raw["k_event_build"]["WRITE_SIZE"] * 1024}}
-    total = sum(v["read"] + v["write"] for v in b.values())
-    sqo = {}
-    for k, cs in sq.items():
-        sqo[k] = {("SQ_ACTIVE_INST_VALU_quadcycles" if c == "SQ_ACTIVE_INST_VALU" else c): round(v) for c, v in cs.items()}
+    bench = json.loads(open(os.path.join(tag, "bench.json")).read().strip().splitlines()[-1])
+    S = bench["config"]["samples_per_gpu"]
+    E = bench["config"]["events_per_step_rank0"]
+    alg = bench["roofline"]["algorithmic_bytes"]
+    main_k = "k_event" if "k_event" in fetch else "k_event_detect"
+    raw = {k: {"FETCH_SIZE_KiB": round(fetch[k]["FETCH_SIZE"]), "WRITE_SIZE_KiB": round(write[k]["WRITE_SIZE"])}
+           for k in fetch if k != "k_event_fallback"}
+    rd_raw = sum(v["FETCH_SIZE_KiB"] for v in raw.values()) * 1024
+    wr = sum(v["WRITE_SIZE_KiB"] for v in raw.values()) * 1024
+    # what the path must move at least, given its structure: samples read by the detector and again by the builder,
+    # the bitmap written and read back, the events written
+    known_rd = 2 * (2 * S) + S // 8
+    known_wr = 16 * E + S // 8
+    rd = min(max(rd_raw, known_rd), 2 * rd_raw)
+    busy = {k: v["SQ_ACTIVE_INST_VALU"] * 4 / v["SQ_BUSY_CYCLES"] * 32 / 1024 for k, v in sq.items() if "SQ_BUSY_CYCLES" in v}
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(__file__)).decode().strip()
+    except Exception:
+        commit = None
     doc = {
-        "_comment": "HBM bytes per bench step (config 2: 1e9 samples, 1.94e8 events) from rocprofv3 --pmc FETCH_SIZE / "
-                    "--pmc WRITE_SIZE, collected in separate passes (tools/refresh_profiles.sh + tools/pmc_summary.py; "
-                    "mean over the dispatches of the run). Counter unit is KiB. Corrections per MI355X_MICROARCH.md (HBM): "
-                    "FETCH_SIZE counts 128-byte requests as 64 bytes, so a read stream is under-counted by up to 2x "
-                    "depending on its request mix. k_event_build (64 contiguous bytes per lane, four 16-byte loads) reads "
-                    "every sample and bitmap word exactly once: its read volume is calibrated on that known byte count "
-                    "(2.125e9; raw count x1.36, inside the [1x, 2x] bracket). k_event_detect (lane-strided 32-byte pieces) "
-                    "is taken at face value; its true value lies between 1x and 2x of the raw count. WRITE_SIZE is exact "
-                    "for wide stores.",
-        "source": tag,
-        "raw_kib": raw,
-        "bytes": b,
-        "hbm_bytes_per_step": total,
-        "sq_counters_per_step": sqo,
-        "notes": "detect re-reads the samples (2.0 GB algorithmic + 4 %% speculative warm-up; the rest is L2 capacity "
-                 "misses on lines consumed over four blocks) and writes the peak bitmap with 8-byte lane-private stores "
-                 "(0.125 GB algorithmic, 0.58 GB measured: partial-line writes). build reads samples + bitmap once and "
-                 "writes the events once. VALU occupancy = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz: "
-                 "%.2f ms for k_event_detect, %.2f ms for k_event_build."
-                 % tuple(sqo[k]["SQ_ACTIVE_INST_VALU_quadcycles"] * 4 / 1024 / 2.4e9 * 1e3
-                         for k in ("k_event_detect", "k_event_build")),
+        "_comment": "HBM bytes per bench step (config 2: 1e9 samples) from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+                    "collected in separate passes (tools/refresh_profiles.sh + tools/pmc_summary.py; mean over the "
+                    "dispatches of the run).  Counter unit is KiB.  Per MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies "
+                    "128-byte requests at 64 bytes, so a wide coalesced read stream is reported at exactly half and other "
+                    "access widths are uncalibrated: the read volume is therefore bracketed by [raw, 2 x raw] and priced at "
+                    "the known minimum of the path's structure when that lies inside the bracket (samples read by the "
+                    "detector and again by the builder, bitmap read back).  WRITE_SIZE is exact for wide stores.",
+        "recorded_for": {"commit": commit, "source": tag, "kernel": main_k},
+        "raw": raw,
+        "read_bytes": {"raw": rd_raw, "bracket_high": 2 * rd_raw, "structural_minimum": known_rd, "priced": rd},
+        "write_bytes": {"counted": wr, "structural_minimum": known_wr},
+        "hbm_bytes_per_step": rd + wr,
+        "algorithmic_bytes_per_step": alg,
+        "traffic_over_algorithmic": round((rd + wr) / alg, 3),
+        "valu_wave_instructions_per_step": round(sum(v.get("SQ_INSTS_VALU", 0) for k, v in sq.items() if k != "k_event_fallback")),
+        "valu_lane_instructions_per_sample": round(sum(v.get("SQ_INSTS_VALU", 0) for k, v in sq.items()
+                                                       if k != "k_event_fallback") * 64 / S, 1),
+        "salu_wave_instructions_per_step": round(sum(v.get("SQ_INSTS_SALU", 0) for k, v in sq.items() if k != "k_event_fallback")),
+        "valu_busy_fraction": {k: round(v, 3) for k, v in busy.items()},
+        "sq_counters_per_step": {k: {c: round(v) for c, v in cs.items()} for k, cs in sq.items()},
     }
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))

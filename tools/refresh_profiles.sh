@@ -1,18 +1,29 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- tools/refresh_profiles.sh <tag>): bench lines, rocprofv3 kernel stats and the PMC
+# passes the numbers in DESIGN.md / profiles/ come from.  Everything lands in gpurun_out/<tag>/; copy what is to be
+# kept into profiles/ (tools/pmc_summary.py writes profiles/pmc_traffic.json).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/${1:-r01c}
+O=gpurun_out/${1:-r02}
 mkdir -p $O
-timeout -s KILL 600 python bench.py > $O/bench.json 2> $O/bench.err
-timeout -s KILL 300 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>> $O/bench.err
+timeout -s KILL 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -s KILL 600 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --ragged 0.8 --cpu-reads 0 > $O/bench_ragged.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_5k.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_5k_rna.json 2>> $O/bench.err
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 > $O/prof.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_sq.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_sq.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_rna -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --rna 1 > $O/pmc_sq_rna.log 2>&1
 if [ "$2" != "nosub" ]; then
+timeout -s KILL 900 python bench.py --config 3 > $O/bench_c3.json 2>> $O/bench.err
+timeout -s KILL 900 python bench.py --config 4 --steps 5 > $O/bench_c4.json 2>> $O/bench.err
+timeout -s KILL 900 python bench.py --config 5 --steps 3 > $O/bench_c5.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 125000 --rna 0 > $O/subtools_c4.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 50000 --rna 1 > $O/subtools_c3.json 2>> $O/bench.err
 fi
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
-tail -1 $O/bench.json
+tail -1 $O/bench.json | cut -c1-400
