@@ -72,6 +72,22 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     return CLI
 
 
+def build_tools(force: bool = False, verbose: bool = False) -> None:
+    """the stand-alone HIP programs of tools/ (issue-rate microbenchmark, hardware accuracy check of v_rsq_f32)"""
+    tdir = os.path.join(ROOT, "tools")
+    for name in ("rsq_check", "valu_rate"):
+        src = os.path.join(tdir, name + ".hip")
+        exe = os.path.join(tdir, name)
+        deps = [src] + ([os.path.join(tdir, "valu_rate_tests.inc")] if name == "valu_rate" else [])
+        if not os.path.exists(src) or (not force and _newer(exe, deps)):
+            continue
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-o", exe, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+
 if __name__ == "__main__":
+    build_tools(force="--force" in sys.argv, verbose=True)
     build_lib(force="--force" in sys.argv, verbose=True)
     build_cli(force="--force" in sys.argv, verbose=True)
