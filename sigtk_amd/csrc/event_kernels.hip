@@ -1088,7 +1088,9 @@ __device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, c
         if (c == 0) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
         __threadfence_block();
         __syncthreads();  // every lane's bitmap words are in memory before the replay ORs into them
+#ifndef SGK_EXP_NO_REPLAY
         replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active);
+#endif
     }
     return 0;
 }
