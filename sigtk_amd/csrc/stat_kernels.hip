@@ -17,7 +17,10 @@
 //     thresholds derived from those sequential float moments: one read per lane as well.  Their
 //     per-sample work is integer: mask algebra for jnn_core, integer rolling totals with the exact
 //     constant division (tstat_math.h) and integer thresholds for jnnv2's run finder.
+#include <stdlib.h>
+
 #include "row_stream.h"
+#include "seqsum.h"
 #include "sgk_common.h"
 #include "stat_args.h"
 #include "tstat_math.h"
@@ -359,11 +362,16 @@ __device__ bool block_select_range(const int16_t *x, int64_t n, int64_t k1, int6
     return b1 > 0 && b1 < nb - 1 && b2 > 0 && b2 < nb - 1;
 }
 
-template <int MODE, bool PA = false>
+// FLAGGED: only the reads k_stat_wave could not settle (order statistic outside its window)
+template <int MODE, bool PA = false, bool FLAGGED = false>
 __global__ __launch_bounds__(256) void k_median(StatArgs a) {
     __shared__ uint32_t hist[MODE == REG_WHOLE ? RANGE_BINS : 4096];
     __shared__ uint32_t part[260];
     const uint32_t r = blockIdx.x;
+    if (FLAGGED) {
+        const uint32_t fl = MODE == REG_WHOLE ? a.stat[r].reserved : a.prefix[r].reserved;
+        if (!(fl & (MODE == REG_POLYA ? 2u : 1u))) return;
+    }
     const Region g = get_region(MODE, a.b, a.prefix, r);
     if (g.len <= 0) {
         if (threadIdx.x == 0 && MODE == REG_WHOLE) { a.stat[r].raw_median = 0; a.stat[r].pa_median = 0.0f; a.stat[r].reserved = 0; }
@@ -395,6 +403,316 @@ __global__ __launch_bounds__(256) void k_median(StatArgs a) {
         if (MODE == REG_WHOLE) { a.stat[r].raw_median = med; a.stat[r].pa_median = pm; a.stat[r].reserved = 0; }
         else if (MODE == REG_ADAPT) a.prefix[r].adapt_median = pm;
         else a.prefix[r].polya_median = pm;
+        if (FLAGGED && MODE != REG_WHOLE) a.prefix[r].reserved &= ~(MODE == REG_POLYA ? 2u : 1u);
+    }
+}
+
+// ---------------------------------------------------------------- one WAVE per read (seqsum.h)
+// The sequential float sums of a read (or of a region of it) by one wavefront: tiles of 64 x SS_SPL samples, every
+// lane loads its 32 contiguous bytes with two 16-byte loads (tile t + 1 is in flight while tile t is consumed), the
+// sums advance through the tile as seqsum.h describes.  Two passes over the samples:
+//   1. sum of raw and of pA                                   -> the two means (src/stat.h:17-33)
+//   2. sums of the squared deviations (src/stat.h:36-54), the histogram of the raw values over a window of WH_BINS codes
+//      centred on the raw mean (median = order statistic of rank n/2, src/stat.h:56-73), and -- fused stat + pa,
+//      BASELINE config 4 -- the pA value of every sample
+// The second pass of a read follows its first on the same wave; reads whose order statistic falls outside the window
+// are flagged (`reserved`) and taken by k_median.  Ragged batches cost what their samples cost: a wave is busy for the
+// length of ITS read, not for the longest read among 64 neighbours as in the lane-per-read kernels above.
+constexpr int WH_BINS = 2048;
+constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_POLYA = 2u;
+
+struct WaveTile {
+    uint32_t w[SS_SPL / 2];
+    template <int E>
+    __device__ __forceinline__ int16_t sample() const {
+        return (E & 1) ? (int16_t)(w[E / 2] >> 16) : (int16_t)(w[E / 2] & 0xffffu);
+    }
+};
+// this lane's 16 samples at base-relative index p (a multiple of 8, as is n_total >= 8).  Both 16-byte loads are
+// unconditional -- a half that lies beyond the buffer reads the buffer's last 16 bytes instead; such samples are outside
+// the region and masked by the term functors -- so that the load of tile t + 1 stays in flight under tile t.
+__device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int64_t n_total, int64_t p) {
+    const int64_t last = n_total - 8;
+    const int64_t p0 = p < last ? p : last, p1 = p + 8 < last ? p + 8 : last;
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(samples + p0), q1 = *reinterpret_cast<const uint4 *>(samples + p1);
+    t.w[0] = q0.x; t.w[1] = q0.y; t.w[2] = q0.z; t.w[3] = q0.w;
+    t.w[4] = q1.x; t.w[5] = q1.y; t.w[6] = q1.z; t.w[7] = q1.w;
+}
+
+// calls f.template operator()<E>(raw, valid) for this lane's 16 samples (tile-local indices q0 .. q0 + 15)
+template <int E, bool INTERIOR, typename F>
+__device__ __forceinline__ void wt_each_(const WaveTile &t, int q0, int q_lo, int q_hi, F &f) {
+    if constexpr (E < SS_SPL) {
+        f.template operator()<E>(t.sample<E>(), INTERIOR || (q0 + E >= q_lo && q0 + E < q_hi));
+        wt_each_<E + 1, INTERIOR>(t, q0, q_lo, q_hi, f);
+    }
+}
+
+struct WaveRead {  // wave-uniform description of the region a wave works on
+    const int16_t *samples;
+    int64_t n_total, rb, len;
+    int skip, ntiles;
+    __device__ void init(const sgk_batch_t &b, const Region &g) {
+        samples = b.samples;
+        n_total = (int64_t)b.n_samples;
+        rb = g.start & ~(int64_t)7;
+        skip = (int)(g.start - rb);
+        len = g.len;
+        ntiles = (int)((skip + len + SS_TILE - 1) / SS_TILE);
+    }
+    __device__ __forceinline__ void load(WaveTile &t, int tile) const {
+        const int64_t q = (int64_t)tile * SS_TILE + lane_id() * SS_SPL;  // first sample of this lane, region-relative + skip
+        wt_load(t, samples, n_total, rb + q);
+    }
+    // a tile strictly inside the region (and not the first one, whose head is added natively): no predicates
+    __device__ __forceinline__ bool interior(int tile) const {
+        return tile > 0 && (int64_t)(tile + 1) * SS_TILE - skip <= len;
+    }
+    __device__ __forceinline__ int head() const { return (int)(len < SS_HEAD ? len : SS_HEAD); }
+    // tile-local index range [q_lo, q_hi) of the region's samples in `tile`, without its first `drop` samples
+    __device__ __forceinline__ void range(int tile, int drop, int &q_lo, int &q_hi) const {
+        const int64_t lo = (int64_t)skip + drop - (int64_t)tile * SS_TILE, hi = (int64_t)skip + len - (int64_t)tile * SS_TILE;
+        q_lo = lo < 0 ? 0 : (lo > SS_TILE ? SS_TILE : (int)lo);
+        q_hi = hi < 0 ? 0 : (hi > SS_TILE ? SS_TILE : (int)hi);
+    }
+};
+
+// term functors of the four sums (seqsum.h): INTERIOR tiles need no validity test.  `z` is 0; the rare paths of
+// ss_finish pass an OPAQUE zero (SsOpaque) so that their term arithmetic stays inside those paths -- the compiler
+// otherwise hoists all of it in front of the fast path and keeps 32 terms alive across it.
+template <bool INTERIOR>
+struct TermBase {
+    static constexpr bool interior = INTERIOR;
+    const WaveTile &t;
+    int q0, q_lo, q_hi;  // q0: tile-local index of this lane's first sample
+    uint32_t z;
+    template <int E>
+    __device__ __forceinline__ bool valid() const { return INTERIOR || (q0 + E >= q_lo && q0 + E < q_hi); }
+    template <int E>
+    __device__ __forceinline__ int16_t sample() const {
+        const uint32_t w = t.w[E / 2] ^ z;
+        return (E & 1) ? (int16_t)(w >> 16) : (int16_t)(w & 0xffffu);
+    }
+};
+template <bool INTERIOR>
+struct TermRaw {  // (float)raw, src/stat.h:29-33
+    TermBase<INTERIOR> b;
+    __device__ __forceinline__ TermRaw with(uint32_t z) const { TermRaw r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        return b.template valid<E>() ? (float)b.template sample<E>() : 0.0f;
+    }
+};
+template <bool INTERIOR>
+struct TermPa {   // pA, src/stat.h:17-27 on signal_in_picoamps' output
+    TermBase<INTERIOR> b;
+    Scale so;     // unit carries the orientation of the accumulator
+    __device__ __forceinline__ TermPa with(uint32_t z) const { TermPa r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        return b.template valid<E>() ? to_pa(b.template sample<E>(), so) : 0.0f;
+    }
+};
+template <bool INTERIOR>
+struct TermDevRaw {  // (raw - mean)^2, src/stat.h:46-54
+    TermBase<INTERIOR> b;
+    float mean;
+    __device__ __forceinline__ TermDevRaw with(uint32_t z) const { TermDevRaw r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        const float d = (float)b.template sample<E>() - mean;
+        return b.template valid<E>() ? d * d : 0.0f;
+    }
+};
+template <bool INTERIOR>
+struct TermDevPa {   // (pA - mean)^2, src/stat.h:36-44
+    TermBase<INTERIOR> b;
+    Scale sc;
+    float mean;
+    __device__ __forceinline__ TermDevPa with(uint32_t z) const { TermDevPa r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        const float d = to_pa(b.template sample<E>(), sc) - mean;
+        return b.template valid<E>() ? d * d : 0.0f;
+    }
+};
+
+// one tile of two chains: both walks are issued before either chain's (branching) bookkeeping.  mka / mkb build the
+// chains' term functors from a TermBase<INTERIOR>.
+template <bool NEG, typename MA, typename MB>
+__device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &wr, const WaveTile &cur, int t, MA mka, MB mkb,
+                                         SsCount *ca = nullptr, SsCount *cb = nullptr) {
+    const int q0 = lane_id() * SS_SPL;
+    int q_lo, q_hi;
+    if (t == 0) {  // the head of the read, natively (the functors mask what lies behind it)
+        wr.range(0, 0, q_lo, q_hi);
+        const int qh = q_lo + wr.head();
+        if (qh > q_lo)
+            ss_serial2(ma, mb, mka(TermBase<false>{cur, q0, q_lo, qh, 0u}), mkb(TermBase<false>{cur, q0, q_lo, qh, 0u}),
+                       q_lo / SS_SPL, (qh - 1) / SS_SPL);
+    }
+    wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
+    SsWalk wa, wb;
+    if (wr.interior(t)) {
+        wa = ss_walk<NEG>(ma, mka(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
+        wb = ss_walk<NEG>(mb, mkb(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
+    } else {
+        wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+        wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+    }
+    if (ca) { ++ca->tiles; ++cb->tiles; }
+    if (!ss_fast<NEG>(ma, wa)) ma = ss_finish<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wa, ca);
+    if (!ss_fast<NEG>(mb, wb)) mb = ss_finish<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wb, cb);
+}
+
+template <int MODE, bool PA>
+__global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
+    __shared__ uint32_t hist_all[4][WH_BINS];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t r = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
+    if (r >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
+    uint32_t *hist = hist_all[wv];
+    const Region g = get_region(MODE, a.b, a.prefix, r);
+    const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+    WaveRead wr;
+    wr.init(a.b, g);
+    const float nf = (float)(int)g.len;
+#ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
+    SsCount counts[4] = {};
+#define SS_CNT(i) (&counts[i])
+#else
+#define SS_CNT(i) nullptr
+#endif
+
+    // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative)
+    float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
+    {
+        WaveTile cur, nxt;
+        if (wr.ntiles > 0) wr.load(cur, 0);
+        for (int t = 0; t < wr.ntiles; ++t) {
+            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+            const Scale so = {sc.offf, sc.unit * sg};
+            ss_tile2<true>(
+                m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b}; },
+                [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
+            if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
+            cur = nxt;
+        }
+    }
+    const float mraw = m_raw / nf, mpa = (m_pa * sg) / nf;
+
+    // ---- pass 2: squared deviations, window histogram, pA
+    const int64_t k = g.len / 2;
+    const bool mirrored = sc.unit < 0.0f && g.len - 1 - k != k;  // pA order is the reverse of the raw order
+    int c = (mraw == mraw) ? (int)fminf(fmaxf(mraw, -32768.0f), 32767.0f) : 0;
+    int lo = c - WH_BINS / 2;
+    lo = lo < -32768 ? -32768 : (lo > 32768 - WH_BINS ? 32768 - WH_BINS : lo);
+#pragma unroll
+    for (int i = 0; i < WH_BINS / 64; ++i) hist[i * 64 + lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float q_raw = 0.0f, q_pa = 0.0f;
+#ifndef SGK_EXP_PASS1
+    {
+        WaveTile cur, nxt;
+        if (wr.ntiles > 0) wr.load(cur, 0);
+        float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
+        for (int t = 0; t < wr.ntiles; ++t) {
+            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+            int q_lo, q_hi;
+            wr.range(t, 0, q_lo, q_hi);
+            const bool interior = wr.interior(t);
+            const int q0 = lane * SS_SPL;
+            // histogram of the raw values; pA of every sample
+            auto each = [&]<int E>(int16_t v, bool valid) {
+#ifndef SGK_EXP_NOHIST
+                if (valid) {
+                    int b = (int)v - lo;
+                    b = b < 0 ? 0 : (b > WH_BINS - 1 ? WH_BINS - 1 : b);
+                    atomicAdd(&hist[b], 1u);
+                }
+#endif
+            };
+            if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
+            else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
+            if (PA) {
+                float *dst = pa_dst + (int64_t)t * SS_TILE + q0;
+                float pav[SS_SPL];
+                auto pa_of = [&]<int E>(int16_t v, bool) { pav[E] = to_pa(v, sc); };
+                wt_each_<0, true>(cur, q0, q_lo, q_hi, pa_of);
+                if (interior) {
+#pragma unroll
+                    for (int v4 = 0; v4 < SS_SPL / 4; ++v4)
+                        reinterpret_cast<float4 *>(dst)[v4] =
+                            make_float4(pav[4 * v4], pav[4 * v4 + 1], pav[4 * v4 + 2], pav[4 * v4 + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < SS_SPL; ++e)
+                        if (q0 + e >= q_lo && q0 + e < q_hi) dst[e] = pav[e];
+                }
+            }
+            ss_tile2<false>(
+                q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
+                [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));
+            cur = nxt;
+        }
+    }
+#endif
+    const float sdraw = sqrtf(q_raw / nf), sdpa = sqrtf(q_pa / nf);
+
+    // ---- the order statistics of ranks k (raw median) and, for a negative unit, n-1-k (the pA median's raw value)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PER = WH_BINS / 64;
+    uint32_t cnt[PER], lsum = 0u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { cnt[i] = hist[lane * PER + i]; lsum += cnt[i]; }
+    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)lsum), excl = incl - lsum;
+    int found[2] = {0, 0};
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const uint32_t rank = (uint32_t)(w ? (mirrored ? g.len - 1 - k : k) : k);
+        int bin = 0;
+        if (rank >= excl && rank < incl) {
+            uint32_t acc = excl;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                if (rank >= acc && rank < acc + cnt[i]) bin = lane * PER + i;
+                acc += cnt[i];
+            }
+        }
+        const unsigned long long own = __ballot(rank >= excl && rank < incl);
+        found[w] = own ? __builtin_amdgcn_readlane(bin, __builtin_amdgcn_readfirstlane(__ffsll((long long)own) - 1)) : 0;
+    }
+#ifdef SGK_SS_COUNT
+    if (lane == 0 && r == 0)
+        for (int i = 0; i < 4; ++i)
+            printf("chain %d: tiles %u generic %u walks %u crossings %u composes %u serial %u\n", i, counts[i].tiles,
+                   counts[i].generic, counts[i].walks, counts[i].crossings, counts[i].composes, counts[i].serial);
+#endif
+    const bool trusted = g.len > 0 && found[0] > 0 && found[0] < WH_BINS - 1 && found[1] > 0 && found[1] < WH_BINS - 1;
+    if (lane == 0) {
+        const int med = lo + found[0];
+        const float pm = to_pa((int16_t)(lo + found[1]), sc);
+        const bool pending = g.len > 0 && !trusted;
+        if (MODE == REG_WHOLE) {
+            sgk_stat_rec_t *o = a.stat + r;
+            o->raw_mean = mraw; o->pa_mean = mpa; o->raw_std = sdraw; o->pa_std = sdpa;
+            o->raw_median = g.len > 0 ? med : 0;
+            o->pa_median = g.len > 0 ? pm : 0.0f;
+            o->n = (uint32_t)g.len;
+            o->reserved = pending ? FLAG_MEDIAN_WHOLE : 0u;
+        } else if (MODE == REG_ADAPT) {
+            a.prefix[r].adapt_mean = mpa;
+            a.prefix[r].adapt_std = sdpa;
+            if (g.len > 0) a.prefix[r].adapt_median = pm;
+            if (pending) a.prefix[r].reserved |= FLAG_MEDIAN_ADAPT;
+        } else {
+            a.prefix[r].polya_mean = mpa;
+            a.prefix[r].polya_std = sdpa;
+            if (g.len > 0) a.prefix[r].polya_median = pm;
+            if (pending) a.prefix[r].reserved |= FLAG_MEDIAN_POLYA;
+        }
     }
 }
 
@@ -853,13 +1171,28 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, AdaptP ap) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__);     \
     } while (0)
 
+// SGK_LANE_PER_READ=1 selects the lane-per-read kernels of round 1 (kept as an independent second implementation:
+// tests compare the two; tools/bench_subtools.py times both)
+static bool lane_per_read() {
+    const char *e = getenv("SGK_LANE_PER_READ");
+    return e && e[0] == '1';
+}
+
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
+    if (lane_per_read()) {
+        SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
+        SGK_HIP_TRY(hipGetLastError());
+        if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
+        else SGK_LAUNCH("k_median", (k_median<REG_WHOLE, false>), nr, 256, a);
+        SGK_HIP_TRY(hipGetLastError());
+        return SGK_OK;
+    }
+    if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
+    else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
     SGK_HIP_TRY(hipGetLastError());
-    if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
-    else SGK_LAUNCH("k_median", (k_median<REG_WHOLE, false>), nr, 256, a);
+    SGK_LAUNCH("k_median_flagged", (k_median<REG_WHOLE, false, true>), nr, 256, a);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -900,16 +1233,29 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t gw = (nr + 63) / 64;
     SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     SGK_HIP_TRY(hipGetLastError());
-    SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
-    SGK_HIP_TRY(hipGetLastError());
-    SGK_LAUNCH("k_median_adapt", (k_median<REG_ADAPT>), nr, 256, a);
+    const bool lanes = lane_per_read();
+    if (lanes) {
+        SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
+        SGK_HIP_TRY(hipGetLastError());
+        SGK_LAUNCH("k_median_adapt", (k_median<REG_ADAPT>), nr, 256, a);
+    } else {
+        SGK_LAUNCH("k_stat_wave_adapt", (k_stat_wave<REG_ADAPT, false>), (nr + 3) / 4, 256, a);
+        SGK_HIP_TRY(hipGetLastError());
+        SGK_LAUNCH("k_median_adapt_flagged", (k_median<REG_ADAPT, false, true>), nr, 256, a);
+    }
     SGK_HIP_TRY(hipGetLastError());
     if (rna) {
         SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         SGK_HIP_TRY(hipGetLastError());
-        SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
-        SGK_HIP_TRY(hipGetLastError());
-        SGK_LAUNCH("k_median_polya", (k_median<REG_POLYA>), nr, 256, a);
+        if (lanes) {
+            SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median_polya", (k_median<REG_POLYA>), nr, 256, a);
+        } else {
+            SGK_LAUNCH("k_stat_wave_polya", (k_stat_wave<REG_POLYA, false>), (nr + 3) / 4, 256, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median_polya_flagged", (k_median<REG_POLYA, false, true>), nr, 256, a);
+        }
         SGK_HIP_TRY(hipGetLastError());
     }
     return SGK_OK;

@@ -14,7 +14,7 @@ def _scal(recs):
 
 def _close(a, b, what):
     a = np.float32(a); b = np.float32(b)
-    if np.isnan(a) and np.isnan(b):
+    if (np.isnan(a) and np.isnan(b)) or (np.isinf(a) and a == b):
         return
     assert abs(float(a) - float(b)) <= REL * max(abs(float(b)), 1e-30), "%s: gpu %r oracle %r" % (what, a, b)
 
@@ -143,3 +143,62 @@ def test_fused_stat_pa_matches_stat_and_pa(gpu, oracle):
         o = int(b.offsets_host[r])
         exp = oracle.pa(raw, dig[r], off[r], rng[r])
         assert np.array_equal(pa_h[o:o + raw.size].view(np.uint32), exp.view(np.uint32)), "read %d pA" % r
+
+
+def _adversarial_reads(gpu, seed):
+    """ragged + hostile reads for the wave-per-read sums (seqsum.h): every slow path of the chain is visited"""
+    rs = np.random.RandomState(seed)
+    lens = [0, 1, 2, 15, 16, 17, 63, 64, 65, 66, 127, 128, 129, 1000, 1023, 1024, 1025, 1040, 2047, 2048, 2049,
+            5000, 5000, 5000, 5000, 5000, 5000, 20000, 33000, 100000, 100000, 250000, 40000, 40000, 40000, 3000,
+            3000, 3000, 3000, 3000, 3000, 3000]
+    lens += [int(v) for v in np.clip(np.exp(rs.normal(8.5, 1.2, size=60)), 1, 150000)]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=seed, kind=0)
+    reads = [r.copy() for r in reads]
+    dig = dig.copy(); off = off.copy(); rng = rng.copy()
+    reads[22] = np.zeros(5000, dtype=np.int16)                              # all-zero raw
+    reads[23] = np.full(5000, 333, dtype=np.int16)                          # constant (deviations are 0 or tiny)
+    reads[24] = rs.randint(-32768, 32767, size=5000).astype(np.int16)       # full range, both signs
+    reads[25] = rs.randint(-2000, 2000, size=5000).astype(np.int16)
+    z = np.zeros(5000, dtype=np.int16); z[3000] = 7; z[4000:] = 1
+    reads[26] = z
+    reads[32] = np.full(40000, 32767, dtype=np.int16)                       # sums far beyond 2^24: ties every step
+    reads[33] = np.full(40000, 4095, dtype=np.int16)
+    o = rs.normal(500, 60, size=40000); o[20000] = 32000; o[30000] = -32000
+    reads[34] = np.clip(np.rint(o), -32768, 32767).astype(np.int16)         # outliers comparable to the sum
+    rng[35] = -rng[35]                                                       # negative unit: pA sum runs negative
+    off[36] = -600.0                                                         # pA changes sign inside the read
+    off[37] = -float(np.median(reads[37]))                                   # pA hovers around zero
+    dig[38] = 0.0                                                            # unit = inf
+    rng[39] = 0.0                                                            # unit = 0: every pA is 0
+    rng[40] = 1e-30                                                          # tiny pA
+    rng[41] = 1e38                                                           # huge pA: the sum overflows to inf
+    return reads, dig, off, rng
+
+
+def test_stat_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
+    """the wave-per-read kernels (default) and the lane-per-read kernels of round 1 (SGK_LANE_PER_READ=1) are two
+    independent implementations of the same sequential float sums: identical records, and identical to the oracle"""
+    reads, dig, off, rng = _adversarial_reads(gpu, 17)
+    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    wave = gpu.stat(reads, dig, off, rng)
+    monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+    lane = gpu.stat(reads, dig, off, rng)
+    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    for r in range(len(reads)):
+        assert wave[r].tobytes() == lane[r].tobytes(), "read %d (n=%d): wave %r lane %r" % (r, reads[r].size, wave[r], lane[r])
+    idx = [i for i in range(len(reads)) if reads[i].size > 0]
+    with np.errstate(all="ignore"):
+        _check_stat(oracle, [reads[i] for i in idx], dig[idx], off[idx], rng[idx], [wave[i] for i in idx])
+
+
+def test_prefix_wave_matches_lane_per_read(gpu, monkeypatch):
+    lens = [100, 2000, 2001, 2500, 20000, 50000, 100000, 100000, 100000, 100000, 30000, 70000]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=23, kind=1)
+    for pore in (0, 2):
+        monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        wave = gpu.prefix(reads, dig, off, rng, 1, pore)
+        monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+        lane = gpu.prefix(reads, dig, off, rng, 1, pore)
+        monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        for r in range(len(reads)):
+            assert wave[r].tobytes() == lane[r].tobytes(), "read %d: wave %r lane %r" % (r, wave[r], lane[r])
