@@ -1164,19 +1164,229 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, AdaptP ap) {
     else { o->adapt_x = 0; o->adapt_y = 0; }
 }
 
-// ---------------------------------------------------------------- launchers
-#define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
-    do {                                                                           \
-        ProfScope ps_(name, st);                                                   \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__);     \
-    } while (0)
+// ---------------------------------------------------------------- find_adaptor / jnnv2, one WAVE per read
+// Same arithmetic as k_adaptor, laid out as k_stat_wave: tiles of 64 x SS_SPL window indices; a lane holds the trailing
+// samples x[i..i+16) and the leading samples x[i+2000..i+2016) of its 16 indices, forms the 16 differences of the
+// clamped values (packed 16-bit), a DPP scan of the lanes' difference sums gives every lane its first rolling total
+// (integers: exact in any order), and the sequential float sums of the rolling means (src/jnn.c:106-107) advance through
+// seqsum.h.  Three passes: sum of the means; sum of their squared deviations; the run finder (src/jnn.c:126-158), whose
+// state only changes where the below / above-threshold flags flip: the wave jumps from flip to flip over 16-bit lane
+// masks and stops at the first qualifying segment that can no longer change.
+struct TermArr {  // terms kept in registers
+    const float (&x)[SS_SPL];
+    __device__ __forceinline__ TermArr with(uint32_t) const { return *this; }
+    template <int E>
+    __device__ __forceinline__ float get() const { return x[E]; }
+};
 
+// rolling totals of this lane's 16 window indices.  T0: total of the tile's first index (wave-uniform), advanced to
+// the next tile's.  d_lo: tile-local indices below it have no difference (they lie in front of the read).
+template <bool MASKED>
+__device__ __forceinline__ void roll_tile(const WaveTile &trail, const WaveTile &lead, int d_lo, int &T0, int (&tot)[SS_SPL]) {
+    const int q0 = lane_id() * SS_SPL;
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < SS_SPL / 2; ++k) {
+        const s16x2 d = clamp_raw2(lead.w[k]) - clamp_raw2(trail.w[k]);
+        int d0 = (int)d.x, d1 = (int)d.y;
+        if (MASKED) {
+            d0 = (q0 + 2 * k >= d_lo) ? d0 : 0;
+            d1 = (q0 + 2 * k + 1 >= d_lo) ? d1 : 0;
+        }
+        tot[2 * k] = run;
+        run += d0;
+        tot[2 * k + 1] = run;
+        run += d1;
+    }
+    const int incl = wave_incl_scan_i(run);
+    const int base = T0 + incl - run;
+#pragma unroll
+    for (int e = 0; e < SS_SPL; ++e) tot[e] += base;
+    T0 += wave_last_i(incl);
+}
+
+// first set bit at tile-local position >= cur of the 1024-bit mask held as 16 bits per lane (-1: none)
+__device__ __forceinline__ int mask_next(uint32_t m16, int cur) {
+    const int lo = cur - lane_id() * SS_SPL;
+    const uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
+    const unsigned long long has = __ballot(m != 0u);
+    if (!has) return -1;
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)has) - 1);
+    return l * SS_SPL + __builtin_amdgcn_readlane(__ffs((int)m) - 1, l);
+}
+// last set bit at a tile-local position in [cur, hi) (-1: none)
+__device__ __forceinline__ int mask_last(uint32_t m16, int cur, int hi) {
+    const int lo = cur - lane_id() * SS_SPL, up = hi - lane_id() * SS_SPL;
+    uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
+    m = up >= SS_SPL ? m : (up <= 0 ? 0u : m & ((1u << up) - 1u));
+    const unsigned long long has = __ballot(m != 0u);
+    if (!has) return -1;
+    const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)has));
+    return l * SS_SPL + __builtin_amdgcn_readlane(31 - __clz((int)m), l);
+}
+
+__global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t r = blockIdx.x * 4 + wv;
+    if (r >= a.b.n_reads) return;
+    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+    const int64_t n = g.len;
+    sgk_prefix_rec_t *o = a.prefix + r;
+    if (lane == 0) {
+        o->n = (uint32_t)n;
+        o->reserved = 0;
+        o->polya_x = -1; o->polya_y = -1;
+        o->adapt_mean = 0.0f; o->adapt_std = 0.0f; o->adapt_median = 0.0f;
+        o->polya_mean = 0.0f; o->polya_std = 0.0f; o->polya_median = 0.0f;
+    }
+    if (n <= ADW) {  // "Not enough data to trim", src/jnn.c:173-177
+        if (lane == 0) { o->adapt_x = -1; o->adapt_y = -1; }
+        return;
+    }
+    const int64_t m = n - ADW;  // number of rolling means
+    WaveRead wr;
+    wr.init(a.b, Region{g.start, m});
+    const int q0 = lane * SS_SPL;
+
+    // total of the first window: clamped samples 0 .. 1999 (tile-local positions skip .. skip + 1999 of tiles 0 and 1)
+    int first_total = 0;
+    {
+        int part = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            WaveTile w;
+            wr.load(w, t);
+            const int lo = wr.skip - t * SS_TILE, hi = wr.skip + ADW - t * SS_TILE;
+#pragma unroll
+            for (int k = 0; k < SS_SPL / 2; ++k) {
+                const s16x2 c = clamp_raw2(w.w[k]);
+                part += (q0 + 2 * k >= lo && q0 + 2 * k < hi) ? (int)c.x : 0;
+                part += (q0 + 2 * k + 1 >= lo && q0 + 2 * k + 1 < hi) ? (int)c.y : 0;
+            }
+        }
+        first_total = wave_last_i(wave_incl_scan_i(part));
+    }
+
+    // one sweep over the rolling totals: f(t, tot, q_lo, q_hi) per tile; returns early when f says so
+    auto sweep = [&](auto f) {
+        int T0 = first_total;
+        WaveTile tr, ld, trn, ldn;
+        auto load2 = [&](WaveTile &x, WaveTile &y, int t) {
+            const int64_t q = (int64_t)t * SS_TILE + q0;
+            wt_load(x, wr.samples, wr.n_total, wr.rb + q);
+            wt_load(y, wr.samples, wr.n_total, wr.rb + q + ADW);
+        };
+        load2(tr, ld, 0);
+        for (int t = 0; t < wr.ntiles; ++t) {
+            if (t + 1 < wr.ntiles) load2(trn, ldn, t + 1);
+            int tot[SS_SPL];
+            if (t == 0 && wr.skip > 0) roll_tile<true>(tr, ld, wr.skip, T0, tot);
+            else roll_tile<false>(tr, ld, 0, T0, tot);
+            if (f(t, tot)) break;
+            tr = trn; ld = ldn;
+        }
+    };
+    // one tile of a chain over terms term(tot)
+    auto chain_tile = [&](float &acc, int t, const int (&tot)[SS_SPL], auto term) {
+        int q_lo, q_hi;
+        float x[SS_SPL];
+        if (t == 0) {  // head, natively
+            wr.range(0, 0, q_lo, q_hi);
+            const int qh = q_lo + wr.head();
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < qh) ? term(tot[e]) : 0.0f;
+            if (qh > q_lo) acc = ss_serial(acc, TermArr{x}, q_lo / SS_SPL, (qh - 1) / SS_SPL);
+        }
+        wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
+        if (wr.interior(t)) {
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) x[e] = term(tot[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
+        }
+        const SsWalk w = ss_walk<false>(acc, TermArr{x});
+        if (!ss_fast<false>(acc, w)) acc = ss_finish<false>(acc, TermArr{x}, w);
+    };
+
+    const float mf = (float)(int)m;
+    float s = 0.0f;
+    sweep([&](int t, const int (&tot)[SS_SPL]) {
+        chain_tile(s, t, tot, [](int v) { return roll_mean(v); });
+        return false;
+    });
+    const float mn = s / mf;
+    float q = 0.0f;
+    sweep([&](int t, const int (&tot)[SS_SPL]) {
+        chain_tile(q, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
+        return false;
+    });
+    const float sd = sqrtf(q / mf);
+    const float bot = mn - sd * ap.std_scale;
+    const int t_lt = roll_threshold(bot, false), t_gt = roll_threshold(bot, true);
+
+    // the run finder (RunFinder above, src/jnn.c:126-167) from flip to flip
+    int in_run = 0, start = 0, end = 0, nseg = 0, last_x = 0, last_y = 0, ans_x = 0, ans_y = 0, found = 0;
+    auto settle = [&]() {
+        const int len = last_y - last_x;
+        if (!found && !(len > ap.hi_thresh) && !(len < ap.lo_thresh)) { found = 1; ans_x = last_x; ans_y = last_y; }
+    };
+    sweep([&](int t, const int (&tot)[SS_SPL]) {
+        int q_lo, q_hi;
+        wr.range(t, 0, q_lo, q_hi);
+        uint32_t bm = 0u, am = 0u;
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) {
+            bm |= (uint32_t)((tot[e] - t_lt) >> 31) & (1u << e);       // tot < t_lt
+            am |= ~(uint32_t)((tot[e] - t_gt) >> 31) & (1u << e);      // tot >= t_gt
+        }
+        const int lo = q_lo - q0, hi = q_hi - q0;
+        uint32_t vm = lo <= 0 ? 0xffffu : (lo >= SS_SPL ? 0u : (0xffffu >> lo) << lo);
+        vm = hi >= SS_SPL ? vm : (hi <= 0 ? 0u : vm & ((1u << hi) - 1u));
+        bm &= vm; am &= vm;
+        const int jbase = t * SS_TILE - wr.skip;  // window index of tile-local position 0
+        int cur = 0;
+        for (;;) {
+            if (!in_run) {
+                const int p = mask_next(bm, cur);
+                if (p < 0) break;
+                start = jbase + p; in_run = 1; cur = p + 1;
+            } else {
+                const int pa = mask_next(am, cur);
+                const int pb = mask_last(bm, cur, pa < 0 ? SS_TILE : pa);
+                if (pb >= 0) end = jbase + pb;
+                if (pa < 0) break;
+                if (nseg > 0 && start - last_y < ap.seg_dist) last_y = end;
+                else {
+                    if (nseg > 0) settle();
+                    last_x = start; last_y = end; ++nseg;
+                }
+                start = 0; end = 0; in_run = 0; cur = pa + 1;
+                if (found) break;
+            }
+        }
+        return found != 0;
+    });
+    if (nseg > 0) settle();
+    if (lane == 0) {
+        if (found) { o->adapt_x = ans_x + ADW / 2 - 1; o->adapt_y = ans_y + ADW / 2 - 1; }
+        else { o->adapt_x = 0; o->adapt_y = 0; }
+    }
+}
+
+// ---------------------------------------------------------------- launchers
 // SGK_LANE_PER_READ=1 selects the lane-per-read kernels of round 1 (kept as an independent second implementation:
 // tests compare the two; tools/bench_subtools.py times both)
 static bool lane_per_read() {
     const char *e = getenv("SGK_LANE_PER_READ");
     return e && e[0] == '1';
 }
+
+#define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
+    do {                                                                           \
+        ProfScope ps_(name, st);                                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__);     \
+    } while (0)
 
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
@@ -1209,7 +1419,8 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
 int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read()) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -1231,9 +1442,10 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
-    SGK_HIP_TRY(hipGetLastError());
     const bool lanes = lane_per_read();
+    if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
+    else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
+    SGK_HIP_TRY(hipGetLastError());
     if (lanes) {
         SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
         SGK_HIP_TRY(hipGetLastError());
