@@ -853,6 +853,272 @@ __global__ __launch_bounds__(64) void k_jnn(StatArgs a, JnnP p) {
     if (overflow) atomicAdd(a.err_count, 1u);
 }
 
+// ---------------------------------------------------------------- jnn_raw, one WAVE per read
+// jnn_core's state (open / err / prev_err / c) is reset whenever a segment ends, and every open segment ends inside a
+// streak of more than `error` consecutive out-of-range samples: behind such a streak the automaton is closed, whatever
+// happened before it -- SYNC POINTS that depend on the data alone.  The read is cut into 64 chunks; lane c scans from
+// the nominal start of chunk c to the first sync point at or behind it, runs the automaton from there (closed) to the
+// first sync point at or behind the nominal start of chunk c + 1, where lane c + 1 has started: exact, no speculation,
+// nothing to verify; reads without such streaks degenerate to fewer, longer lane runs.  (Valid while the `err--`
+// correction of jnn.c:228,238 cannot fire, i.e. error < corrector as in every preset; other parameters use k_jnn.)
+// Thresholds: the sequential float moments of the clamped signal through seqsum.h (two coalesced passes).  A lane
+// stages its kept segments in its own part of the upper half of the read's slots; the merge (src/jnn.c:246-258) is a
+// flag scan: a kept segment opens a new merged segment iff its start is seg_dist or more behind the previous end.
+template <bool INTERIOR>
+struct TermClamp {  // rm_outlier(raw), src/jnn.c:61-77
+    TermBase<INTERIOR> b;
+    __device__ __forceinline__ TermClamp with(uint32_t z) const { TermClamp r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        return b.template valid<E>() ? clampf_raw(b.template sample<E>()) : 0.0f;
+    }
+};
+template <bool INTERIOR>
+struct TermDevClamp {  // (rm_outlier(raw) - mean)^2
+    TermBase<INTERIOR> b;
+    float mean;
+    __device__ __forceinline__ TermDevClamp with(uint32_t z) const { TermDevClamp r = *this; r.b.z = z; return r; }
+    template <int E>
+    __device__ __forceinline__ float get() const {
+        const float d = clampf_raw(b.template sample<E>()) - mean;
+        return b.template valid<E>() ? d * d : 0.0f;
+    }
+};
+// one tile of one chain (see ss_tile2)
+template <bool NEG, typename MK>
+__device__ __forceinline__ void ss_tile1(float &m, const WaveRead &wr, const WaveTile &cur, int t, MK mk) {
+    const int q0 = lane_id() * SS_SPL;
+    int q_lo, q_hi;
+    if (t == 0) {
+        wr.range(0, 0, q_lo, q_hi);
+        const int qh = q_lo + wr.head();
+        if (qh > q_lo) m = ss_serial(m, mk(TermBase<false>{cur, q0, q_lo, qh, 0u}), q_lo / SS_SPL, (qh - 1) / SS_SPL);
+    }
+    wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
+    SsWalk w;
+    if (wr.interior(t)) w = ss_walk<NEG>(m, mk(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
+    else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+    if (!ss_fast<NEG>(m, w)) m = ss_finish<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), w);
+}
+
+constexpr int JW_BLOCK = 32;  // samples a lane takes per step of the chunked pass
+
+__global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t r = blockIdx.x * 4 + wv;
+    if (r >= a.b.n_reads) return;
+    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+    const int64_t n = g.len;
+    if (n <= 0) {
+        if (lane == 0) a.n_segs[r] = 0u;
+        return;
+    }
+    WaveRead wr;
+    wr.init(a.b, g);
+    float top = p.top, bot = p.bot;
+    if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
+        const float nf = (float)(int)n;
+        float s = 0.0f, q = 0.0f;
+        {
+            WaveTile cur, nxt;
+            wr.load(cur, 0);
+            for (int t = 0; t < wr.ntiles; ++t) {
+                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+                ss_tile1<false>(s, wr, cur, t, [&](auto b) { return TermClamp<decltype(b)::interior>{b}; });
+                cur = nxt;
+            }
+        }
+        const float mn = s / nf;
+        {
+            WaveTile cur, nxt;
+            wr.load(cur, 0);
+            for (int t = 0; t < wr.ntiles; ++t) {
+                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+                ss_tile1<false>(q, wr, cur, t, [&](auto b) { return TermDevClamp<decltype(b)::interior>{b, mn}; });
+                cur = nxt;
+            }
+        }
+        const float band = sqrtf(q / nf) * p.std_scale;
+        top = mn + band;
+        bot = mn - band;
+    }
+    // integer form of the tests (JnnAuto::init above): in <=> lo_i < iv < hi_i for the clamped integer sample iv
+    const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
+    const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
+    const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
+    const int keep_min = first_min_i < p.window ? first_min_i : p.window;
+    const int E1 = p.error + 1;
+
+    // ---- chunks in q space (q = sample index + wr.skip; chunk bounds are multiples of 8 -> 16-byte aligned loads)
+    const int64_t nq = wr.skip + n;
+    const int C = nq >= 2048 ? (nq / 1024 >= 64 ? 64 : (int)(nq / 1024)) : 1;
+    const int64_t K = ((nq + C - 1) / C + 7) & ~(int64_t)7;
+    const int LEAD = (E1 + 7) & ~7;
+    const bool active = lane < C;
+    const int64_t cs = (int64_t)lane * K, ce = cs + K;            // nominal chunk of this lane
+    int64_t qb = lane == 0 ? 0 : cs - LEAD;                      // where this lane starts reading
+    // slots: kept segments are staged in the upper half, the merged segments go to the lower half
+    const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
+    const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
+    int32_t *stage_x = a.seg_x + slot0 + half + (uint64_t)lane * capL, *stage_y = a.seg_y + slot0 + half + (uint64_t)lane * capL;
+
+    int runm = (lane == 0) ? -1 : 0, srchm = (active && lane != 0) ? -1 : 0;  // -1 / 0 lane masks
+    int opn = 0, err = 0, run = 0, start = 0, oc = 0;
+    int fx = 0, fy = 0, fstrong = 0, has_first = 0;
+    uint32_t cnt = 0u;
+    bool overflow = false;
+
+    auto load_block = [&](uint32_t (&w)[JW_BLOCK / 2], int64_t q) {
+        const int64_t last = wr.n_total - 8;
+#pragma unroll
+        for (int v = 0; v < JW_BLOCK / 8; ++v) {
+            int64_t pp = wr.rb + q + 8 * v;
+            pp = pp < last ? pp : last;
+            pp = pp < 0 ? 0 : pp;
+            const uint4 x = *reinterpret_cast<const uint4 *>(wr.samples + pp);
+            w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+        }
+    };
+    // one sample: q its position, v the raw value, vm the validity mask (-1: the sample belongs to the read)
+    int pastm = 0;  // -1 in the blocks that reach the end of this lane's nominal chunk
+    auto step = [&](int64_t q64, int i, int16_t v, int vm) {
+        const int iv = clampi_raw(v);
+        const int in = (((iv - hi_i) & (lo_i - iv)) >> 31) & vm;
+        const int out = ~in & vm;
+        oc = (oc - out) & ~in;                       // consecutive out-of-range samples
+        const int syncm = (E1 - 1 - oc) >> 31;       // more than `error` of them: the automaton is closed behind this sample
+        const int inr = in & runm, outr = out & runm;
+        const int errlt = (err - p.error) >> 31;
+        const int tol = outr & opn & errlt;
+        const int endm = outr & opn & ~errlt;
+        const int opening = inr & ~opn;
+        start = (opening & i) | (~opening & start);
+        err -= tol;
+        run = (run - tol) & ~inr;
+        const int kept = endm & ((keep_min - 1 - (i - start)) >> 31);
+        const int armed = syncm & (srchm | (runm & pastm));
+        if (__any((kept | armed) != 0)) {
+            if (kept) {
+                const int c = i - start, end = i - run;
+                const int strong = c >= p.window ? 1 : 0;
+                if (!has_first) { has_first = 1; fx = start; fy = end; fstrong = strong; }
+                else if (strong) {
+                    if (cnt < capL) { stage_x[cnt] = start; stage_y[cnt] = end; }
+                    else overflow = true;
+                    ++cnt;
+                }
+            }
+            if (armed) {
+                const int64_t pnext = q64 + 1;
+                if (srchm) {
+                    if (pnext >= cs) { srchm = 0; runm = pnext >= ce ? 0 : -1; }
+                } else if (pnext >= ce) runm = 0;
+            }
+        }
+        opn = (opn | inr) & ~endm;
+        err &= ~endm;
+        run &= ~endm;
+    };
+
+    uint32_t w[JW_BLOCK / 2], wn[JW_BLOCK / 2];
+    load_block(w, qb);
+    for (;;) {
+        const bool busy = active && (srchm | runm) && qb < nq;
+        if (!__any(busy)) break;
+        load_block(wn, qb + JW_BLOCK);
+        const bool full = qb >= wr.skip && qb + JW_BLOCK <= nq;
+        pastm = qb + JW_BLOCK > ce ? -1 : 0;
+        const int i0 = (int)(qb - wr.skip);
+        if (__all(full || !busy)) {
+            if (busy) {
+#pragma unroll
+                for (int e = 0; e < JW_BLOCK; ++e)
+                    step(qb + e, i0 + e, (e & 1) ? (int16_t)(w[e / 2] >> 16) : (int16_t)(w[e / 2] & 0xffffu), -1);
+            }
+        } else if (busy) {
+#pragma unroll
+            for (int e = 0; e < JW_BLOCK; ++e) {
+                const int64_t q = qb + e;
+                step(q, i0 + e, (e & 1) ? (int16_t)(w[e / 2] >> 16) : (int16_t)(w[e / 2] & 0xffffu),
+                     (q >= wr.skip && q < nq) ? -1 : 0);
+            }
+        }
+        qb += JW_BLOCK;
+#pragma unroll
+        for (int k = 0; k < JW_BLOCK / 2; ++k) w[k] = wn[k];
+    }
+
+    // ---- the kept segments in order: [a lane's first candidate, if it is strong or the first of the read] + its staged ones
+    const unsigned long long hasf = __ballot(has_first != 0);
+    const int firstlane = hasf ? __ffsll((long long)hasf) - 1 : -1;
+    const bool keep_first = has_first && (fstrong || lane == firstlane);
+    if (cnt > capL) cnt = capL;
+    const uint32_t kcnt = cnt + (keep_first ? 1u : 0u);
+    // y of the last kept segment of the nearest lane in front that has one
+    int last_y_own = 0;
+    if (kcnt) last_y_own = cnt ? stage_y[cnt - 1] : fy;
+    const unsigned long long nonempty = __ballot(kcnt != 0u);
+    const unsigned long long before = nonempty & ((1ull << lane) - 1ull);
+    const int src_prev = before ? 63 - __clzll((long long)before) : 0;
+    const int prev_y_in = __shfl(last_y_own, src_prev, 64);
+    const bool has_prev = before != 0ull;
+    auto entry = [&](uint32_t k, int &x, int &y) {
+        if (keep_first) {
+            if (k == 0) { x = fx; y = fy; return; }
+            --k;
+        }
+        x = stage_x[k]; y = stage_y[k];
+    };
+    // pass 1: how many merged segments start in this lane; is this lane's first kept segment one of them?
+    uint32_t nnew = 0u;
+    bool first_is_new = false;
+    {
+        int py = prev_y_in;
+        bool hp = has_prev;
+        for (uint32_t k = 0; k < kcnt; ++k) {
+            int x, y;
+            entry(k, x, y);
+            const bool nw = !hp || !(x - py < p.seg_dist);
+            if (k == 0) first_is_new = nw;
+            nnew += nw ? 1u : 0u;
+            py = y; hp = true;
+        }
+    }
+    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)nnew), base = incl - nnew;
+    const uint32_t total = (uint32_t)wave_last_i((int)incl);
+    // is the kept segment behind this lane's last one the start of a new merged segment (or absent)?
+    const unsigned long long after = lane == 63 ? 0ull : (nonempty & ~((2ull << lane) - 1ull));
+    const int src_next = after ? __ffsll((long long)after) - 1 : 0;
+    const bool next_new = __shfl(first_is_new ? 1 : 0, src_next, 64) != 0 || after == 0ull;
+    // pass 2: x of every segment that starts a merged one, y of every segment that ends one
+    {
+        int32_t *out_x = a.seg_x + slot0, *out_y = a.seg_y + slot0;
+        int py = prev_y_in;
+        bool hp = has_prev;
+        uint32_t idx = base;  // merged segments started so far (in front of and inside this lane)
+        int x = 0, y = 0;
+        if (kcnt) entry(0, x, y);
+        for (uint32_t k = 0; k < kcnt; ++k) {
+            const bool nw = !hp || !(x - py < p.seg_dist);
+            if (nw) {
+                if (idx < half) out_x[idx] = x; else overflow = true;
+                ++idx;
+            }
+            int xn = 0, yn = 0;
+            bool ends;
+            if (k + 1 < kcnt) {
+                entry(k + 1, xn, yn);
+                ends = !(xn - y < p.seg_dist);
+            } else ends = next_new;
+            if (ends && idx - 1 < half) out_y[idx - 1] = y;
+            py = y; hp = true;
+            x = xn; y = yn;
+        }
+    }
+    if (lane == 0) a.n_segs[r] = total < half ? total : half;
+    if (__any(overflow) && lane == 0) atomicAdd(a.err_count, 1u);
+}
+
 // jnn_pa (src/jnn.c:295-306) on ONE float array: jnn_core over rm_outlierf(x).  A compatibility entry (the batched
 // path never holds pA in memory); every lane of the single wave walks the array, lane 0 stores.
 __global__ __launch_bounds__(64) void k_jnn_f32(const float *x, int64_t n, JnnP p, int32_t *seg_x, int32_t *seg_y,
@@ -1411,7 +1677,9 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
-    SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 62 && p.window >= 128;
+    if (lane_per_read() || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    else SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }

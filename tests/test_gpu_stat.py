@@ -202,3 +202,33 @@ def test_prefix_wave_matches_lane_per_read(gpu, monkeypatch):
         monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
         for r in range(len(reads)):
             assert wave[r].tobytes() == lane[r].tobytes(), "read %d: wave %r lane %r" % (r, wave[r], lane[r])
+
+
+def test_jnn_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
+    """k_jnn_wave (chunks between data-determined sync points) against k_jnn and the oracle: ragged lengths, reads
+    with no sync point at all (one lane ends up running everything), reads that are all in or all out of range"""
+    rs = np.random.RandomState(4)
+    lens = [1, 2, 100, 127, 128, 129, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000, 5000, 5000, 5000, 5000,
+            20000, 65536, 65537, 100000, 100000, 100000, 100000, 250000]
+    lens += [int(v) for v in np.clip(np.exp(rs.normal(9.0, 1.0, size=40)), 1, 200000)]
+    for kind in (0, 1):
+        reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=31 + kind, kind=kind)
+        reads = [r.copy() for r in reads]
+        reads[14] = np.full(5000, 500, dtype=np.int16)                            # constant: never out of range... or always
+        reads[15] = np.where(np.arange(5000) % 2 == 0, 400, 900).astype(np.int16)  # alternating far-apart levels
+        reads[16] = (500 + 3 * ((np.arange(5000) // 4) % 2)).astype(np.int16)       # short streaks only: no sync point
+        sq = np.where((np.arange(100000) // 700) % 2 == 0, 480, 620) + rs.randint(-3, 4, size=100000)
+        reads[23] = sq.astype(np.int16)                                           # long in-range stretches, clean edges
+        nz = rs.normal(520, 40, size=100000); nz[::7] += 400                      # every 7th sample an outlier
+        reads[24] = np.clip(np.rint(nz), 0, 4000).astype(np.int16)
+        for rna in (0, 1):
+            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+            wave = gpu.jnn(reads, dig, off, rng, rna)
+            monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+            lane = gpu.jnn(reads, dig, off, rng, rna)
+            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+            for r in range(len(reads)):
+                np.testing.assert_array_equal(wave[r][0], lane[r][0], err_msg="kind %d rna %d read %d (n=%d) x" % (kind, rna, r, reads[r].size))
+                np.testing.assert_array_equal(wave[r][1], lane[r][1], err_msg="kind %d rna %d read %d (n=%d) y" % (kind, rna, r, reads[r].size))
+            sub = list(range(0, 27))
+            _check_jnn(oracle, [reads[i] for i in sub], rna, [wave[i] for i in sub])
