@@ -636,19 +636,26 @@ __global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
             if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
             else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
             if (PA) {
-                float *dst = pa_dst + (int64_t)t * SS_TILE + q0;
-                float pav[SS_SPL];
-                auto pa_of = [&]<int E>(int16_t v, bool) { pav[E] = to_pa(v, sc); };
-                wt_each_<0, true>(cur, q0, q_lo, q_hi, pa_of);
-                if (interior) {
+                // pA of every sample, written as whole cache lines: the tile is read once more as 4 x 256 samples with
+                // 8 bytes per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the chains' layout,
+                // 64 bytes per lane, would make every store instruction touch 32 lines partially)
 #pragma unroll
-                    for (int v4 = 0; v4 < SS_SPL / 4; ++v4)
-                        reinterpret_cast<float4 *>(dst)[v4] =
-                            make_float4(pav[4 * v4], pav[4 * v4 + 1], pav[4 * v4 + 2], pav[4 * v4 + 3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < SS_SPL; ++e)
-                        if (q0 + e >= q_lo && q0 + e < q_hi) dst[e] = pav[e];
+                for (int sub = 0; sub < SS_TILE / 256; ++sub) {
+                    const int qs = sub * 256 + lane * 4;
+                    int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
+                    const int64_t last = wr.n_total - 4;
+                    pp = pp < last ? pp : last;
+                    const uint2 rw = *reinterpret_cast<const uint2 *>(wr.samples + pp);
+                    const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
+                                                 to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
+                    float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
+                    if (interior) *reinterpret_cast<float4 *>(dst) = o;
+                    else {
+                        if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
+                        if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
+                        if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
+                        if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
+                    }
                 }
             }
             ss_tile2<false>(
@@ -945,6 +952,9 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     // integer form of the tests (JnnAuto::init above): in <=> lo_i < iv < hi_i for the clamped integer sample iv
     const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
     const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
+    // the same test on the UNCLAMPED sample: lo_i < clamp(v) < hi_i  <=>  lo_r < v < hi_r
+    const int hi_r = hi_i <= 0 ? -40000 : (hi_i > 1200 ? 40000 : hi_i);
+    const int lo_r = lo_i >= 1200 ? 40000 : (lo_i < 0 ? -40000 : lo_i);
     const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
     const int keep_min = first_min_i < p.window ? first_min_i : p.window;
     const int E1 = p.error + 1;
@@ -968,80 +978,124 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     uint32_t cnt = 0u;
     bool overflow = false;
 
-    auto load_block = [&](uint32_t (&w)[JW_BLOCK / 2], int64_t q) {
+    // a segment that ended with c >= keep_min samples: the lane's first one is kept in registers (whether it is kept
+    // depends on the lanes in front), later ones only matter if c >= window
+    auto candidate = [&](int sx, int sy, int c) {
+        const int strong = c >= p.window ? 1 : 0;
+        if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
+        else if (strong) {
+            if (cnt < capL) { stage_x[cnt] = sx; stage_y[cnt] = sy; }
+            else overflow = true;
+            ++cnt;
+        }
+    };
+    // A block of 32 samples as bit masks (bit e: sample e is in / out of range; samples outside the read are neither).
+    // The automaton goes from EVENT to event -- a segment opens at the next set bit of `inm`; it ends at the
+    // (error + 1 - err)-th set bit of `outm` behind that -- instead of sample by sample: a segment lives for ~13 samples
+    // on nanopore data, so a block holds a handful of events.  Positions [lo, hi) of the block belong to this lane's run.
+    auto run_block = [&](uint32_t inm, uint32_t outm, int i0, int lo, int hi) {
+        const uint32_t range = (lo >= 32 ? 0u : (0xffffffffu >> lo) << lo) & (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u));
+        inm &= range;
+        outm &= range;
+        int pos = lo;
+        for (;;) {
+            const uint32_t keep = pos >= 32 ? 0u : (0xffffffffu >> pos) << pos;  // bits at positions >= pos
+            if (!opn) {
+                const uint32_t m = inm & keep;
+                if (!m) break;
+                const int e = __ffs((int)m) - 1;
+                start = i0 + e; opn = -1; err = 0; run = 0; pos = e + 1;
+            } else {
+                uint32_t mo = outm & keep;
+                const int need = p.error - err + 1;
+                const int pc = __popc(mo);
+                if (pc < need) {
+                    err += pc;
+                    const uint32_t mi = inm & keep;
+                    run = mi ? __clz((int)mi) - (32 - hi) : run + (hi - pos);
+                    break;
+                }
+                for (int k = 1; k < need; ++k) mo &= mo - 1u;
+                const int e = __ffs((int)mo) - 1;
+                const uint32_t mi = inm & keep & ((1u << e) - 1u);  // in-range samples in [pos, e)
+                const int perr = mi ? e - (32 - __clz((int)mi)) : run + (e - pos);
+                const int i = i0 + e;
+                if (i - start >= keep_min) candidate(start, i - perr, i - start);
+                opn = 0; err = 0; run = 0; pos = e + 1;
+            }
+        }
+    };
+    // bit e set: sample e ends a streak of at least E1 out-of-range samples (oc_in of them in front of the block):
+    // behind it the automaton is closed (E1 <= 32)
+    auto sync_bits = [&](uint32_t outm, int oc_in) -> uint32_t {
+        const uint32_t prev = oc_in >= 32 ? 0xffffffffu : ~(0xffffffffu >> oc_in);  // the oc_in samples in front
+        unsigned long long x = ((unsigned long long)outm << 32) | prev;
+        for (int k = 1; k < E1;) {
+            const int st = k < E1 - k ? k : E1 - k;
+            x &= x << st;
+            k += st;
+        }
+        return (uint32_t)(x >> 32);
+    };
+
+    // Every lane streams its own chunk with 16-byte loads, the next block in flight under the current one.  (Measured
+    // alternatives, both slower at 4-5 waves per SIMD: whole 128-byte lines per lane -- 64 more registers; the LDS row
+    // stager of the lane-per-read kernels -- its barriers and the LDS round trip.)
+    uint32_t w[JW_BLOCK / 2], wn[JW_BLOCK / 2];
+    auto load_block = [&](uint32_t (&x)[JW_BLOCK / 2], int64_t q) {
         const int64_t last = wr.n_total - 8;
 #pragma unroll
         for (int v = 0; v < JW_BLOCK / 8; ++v) {
             int64_t pp = wr.rb + q + 8 * v;
             pp = pp < last ? pp : last;
             pp = pp < 0 ? 0 : pp;
-            const uint4 x = *reinterpret_cast<const uint4 *>(wr.samples + pp);
-            w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+            const uint4 u = *reinterpret_cast<const uint4 *>(wr.samples + pp);
+            x[4 * v] = u.x; x[4 * v + 1] = u.y; x[4 * v + 2] = u.z; x[4 * v + 3] = u.w;
         }
     };
-    // one sample: q its position, v the raw value, vm the validity mask (-1: the sample belongs to the read)
-    int pastm = 0;  // -1 in the blocks that reach the end of this lane's nominal chunk
-    auto step = [&](int64_t q64, int i, int16_t v, int vm) {
-        const int iv = clampi_raw(v);
-        const int in = (((iv - hi_i) & (lo_i - iv)) >> 31) & vm;
-        const int out = ~in & vm;
-        oc = (oc - out) & ~in;                       // consecutive out-of-range samples
-        const int syncm = (E1 - 1 - oc) >> 31;       // more than `error` of them: the automaton is closed behind this sample
-        const int inr = in & runm, outr = out & runm;
-        const int errlt = (err - p.error) >> 31;
-        const int tol = outr & opn & errlt;
-        const int endm = outr & opn & ~errlt;
-        const int opening = inr & ~opn;
-        start = (opening & i) | (~opening & start);
-        err -= tol;
-        run = (run - tol) & ~inr;
-        const int kept = endm & ((keep_min - 1 - (i - start)) >> 31);
-        const int armed = syncm & (srchm | (runm & pastm));
-        if (__any((kept | armed) != 0)) {
-            if (kept) {
-                const int c = i - start, end = i - run;
-                const int strong = c >= p.window ? 1 : 0;
-                if (!has_first) { has_first = 1; fx = start; fy = end; fstrong = strong; }
-                else if (strong) {
-                    if (cnt < capL) { stage_x[cnt] = start; stage_y[cnt] = end; }
-                    else overflow = true;
-                    ++cnt;
-                }
-            }
-            if (armed) {
-                const int64_t pnext = q64 + 1;
-                if (srchm) {
-                    if (pnext >= cs) { srchm = 0; runm = pnext >= ce ? 0 : -1; }
-                } else if (pnext >= ce) runm = 0;
-            }
-        }
-        opn = (opn | inr) & ~endm;
-        err &= ~endm;
-        run &= ~endm;
-    };
-
-    uint32_t w[JW_BLOCK / 2], wn[JW_BLOCK / 2];
     load_block(w, qb);
     for (;;) {
         const bool busy = active && (srchm | runm) && qb < nq;
         if (!__any(busy)) break;
         load_block(wn, qb + JW_BLOCK);
-        const bool full = qb >= wr.skip && qb + JW_BLOCK <= nq;
-        pastm = qb + JW_BLOCK > ce ? -1 : 0;
-        const int i0 = (int)(qb - wr.skip);
-        if (__all(full || !busy)) {
-            if (busy) {
-#pragma unroll
-                for (int e = 0; e < JW_BLOCK; ++e)
-                    step(qb + e, i0 + e, (e & 1) ? (int16_t)(w[e / 2] >> 16) : (int16_t)(w[e / 2] & 0xffffu), -1);
-            }
-        } else if (busy) {
+        if (busy) {
+            uint32_t inm = 0u;
 #pragma unroll
             for (int e = 0; e < JW_BLOCK; ++e) {
-                const int64_t q = qb + e;
-                step(q, i0 + e, (e & 1) ? (int16_t)(w[e / 2] >> 16) : (int16_t)(w[e / 2] & 0xffffu),
-                     (q >= wr.skip && q < nq) ? -1 : 0);
+                const int iv = (e & 1) ? (int)(int16_t)(w[e / 2] >> 16) : (int)(int16_t)(w[e / 2] & 0xffffu);
+                inm |= ((uint32_t)((iv - hi_r) & (lo_r - iv)) >> 31) << e;
             }
+            uint32_t vmask = 0xffffffffu;
+            if (qb < wr.skip || qb + JW_BLOCK > nq) {  // a block on the read's edge
+                const int64_t a0 = wr.skip - qb, a1 = nq - qb;
+                const int lo = a0 < 0 ? 0 : (a0 > 32 ? 32 : (int)a0), hi = a1 > 32 ? 32 : (a1 < 0 ? 0 : (int)a1);
+                vmask = (lo >= 32 ? 0u : (0xffffffffu >> lo) << lo) & (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u));
+            }
+            inm &= vmask;
+            const uint32_t outm = ~inm & vmask;
+            int lo = 0, hi = 32;
+            if (srchm || qb + JW_BLOCK > ce) {  // the sync logic is in play: where this lane's run starts / ends
+                const uint32_t sy = sync_bits(outm, oc);
+                if (srchm) {  // the run starts behind the first sync sample at position >= cs - 1
+                    const int64_t f = cs - qb - 1;
+                    const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
+                    if (m) {
+                        lo = __ffs((int)m);  // position behind that sample
+                        srchm = 0;
+                        runm = qb + lo >= ce ? 0 : -1;
+                    } else lo = 32;
+                }
+                if (runm && qb + JW_BLOCK > ce) {  // ... and ends with the first sync sample at position >= ce - 1
+                    int64_t f = ce - qb - 1;
+                    if (f < lo) f = lo;
+                    const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
+                    if (m) hi = __ffs((int)m);
+                }
+            }
+            if (runm && lo < hi) run_block(inm, outm, (int)(qb - wr.skip), lo, hi);
+            if (hi < 32) runm = 0;  // done
+            const uint32_t stop = inm | ~vmask;  // samples that are not out of range
+            oc = stop ? __clz((int)stop) : oc + 32;
         }
         qb += JW_BLOCK;
 #pragma unroll
@@ -1677,7 +1731,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
-    const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 62 && p.window >= 128;
+    const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
     if (lane_per_read() || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
     SGK_HIP_TRY(hipGetLastError());
