@@ -806,6 +806,9 @@ JnnP jnn_preset(int rna) {  // JNNV1_DRNA_R9_PARAM / JNNV1_CDNA_R9_PARAM, src/jn
     else { p.window = 150; p.stall_len = 0.25f; }
     return p;
 }
+__host__ __device__ inline JnnP jnn_polya_params() {  // JNNV1_R9_POLYA == JNNV1_RNA004_POLYA, src/jnn.h:52-72
+    return JnnP{-1.0f, 50, 200, 250, 1.0f, 30, 0.0f, 0.0f};
+}
 JnnP jnn_polya_preset() {  // src/jnn.h:52-72
     JnnP p;
     p.std_scale = -1.0f; p.corrector = 50; p.seg_dist = 200; p.window = 250; p.stall_len = 1.0f; p.error = 30;
@@ -910,85 +913,24 @@ __device__ __forceinline__ void ss_tile1(float &m, const WaveRead &wr, const Wav
 
 constexpr int JW_BLOCK = 32;  // samples a lane takes per step of the chunked pass
 
-__global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t r = blockIdx.x * 4 + wv;
-    if (r >= a.b.n_reads) return;
-    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
-    const int64_t n = g.len;
-    if (n <= 0) {
-        if (lane == 0) a.n_segs[r] = 0u;
-        return;
-    }
-    WaveRead wr;
-    wr.init(a.b, g);
-    float top = p.top, bot = p.bot;
-    if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
-        const float nf = (float)(int)n;
-        float s = 0.0f, q = 0.0f;
-        {
-            WaveTile cur, nxt;
-            wr.load(cur, 0);
-            for (int t = 0; t < wr.ntiles; ++t) {
-                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
-                ss_tile1<false>(s, wr, cur, t, [&](auto b) { return TermClamp<decltype(b)::interior>{b}; });
-                cur = nxt;
-            }
-        }
-        const float mn = s / nf;
-        {
-            WaveTile cur, nxt;
-            wr.load(cur, 0);
-            for (int t = 0; t < wr.ntiles; ++t) {
-                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
-                ss_tile1<false>(q, wr, cur, t, [&](auto b) { return TermDevClamp<decltype(b)::interior>{b, mn}; });
-                cur = nxt;
-            }
-        }
-        const float band = sqrtf(q / nf) * p.std_scale;
-        top = mn + band;
-        bot = mn - band;
-    }
-    // integer form of the tests (JnnAuto::init above): in <=> lo_i < iv < hi_i for the clamped integer sample iv
-    const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
-    const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
-    // the same test on the UNCLAMPED sample: lo_i < clamp(v) < hi_i  <=>  lo_r < v < hi_r
-    const int hi_r = hi_i <= 0 ? -40000 : (hi_i > 1200 ? 40000 : hi_i);
-    const int lo_r = lo_i >= 1200 ? 40000 : (lo_i < 0 ? -40000 : lo_i);
-    const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
-    const int keep_min = first_min_i < p.window ? first_min_i : p.window;
-    const int E1 = p.error + 1;
-
+// The chunked pass of jnn_core shared by k_jnn_wave and k_polya_wave: in <=> lo_r < raw < hi_r; `candidate(x, y, c)`
+// is called, per lane in sample order, for every segment that ended after c >= keep_min samples.
+__device__ __forceinline__ int jnn_chunk_lanes(int64_t nq) { return nq >= 2048 ? (nq / 1024 >= 64 ? 64 : (int)(nq / 1024)) : 1; }
+template <typename CAND>
+__device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi_r, int lo_r, int error, int keep_min,
+                                           CAND &candidate) {
+    const int lane = lane_id();
+    const int E1 = error + 1;
     // ---- chunks in q space (q = sample index + wr.skip; chunk bounds are multiples of 8 -> 16-byte aligned loads)
     const int64_t nq = wr.skip + n;
-    const int C = nq >= 2048 ? (nq / 1024 >= 64 ? 64 : (int)(nq / 1024)) : 1;
+    const int C = jnn_chunk_lanes(nq);
     const int64_t K = ((nq + C - 1) / C + 7) & ~(int64_t)7;
     const int LEAD = (E1 + 7) & ~7;
     const bool active = lane < C;
     const int64_t cs = (int64_t)lane * K, ce = cs + K;            // nominal chunk of this lane
     int64_t qb = lane == 0 ? 0 : cs - LEAD;                      // where this lane starts reading
-    // slots: kept segments are staged in the upper half, the merged segments go to the lower half
-    const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
-    const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
-    int32_t *stage_x = a.seg_x + slot0 + half + (uint64_t)lane * capL, *stage_y = a.seg_y + slot0 + half + (uint64_t)lane * capL;
-
     int runm = (lane == 0) ? -1 : 0, srchm = (active && lane != 0) ? -1 : 0;  // -1 / 0 lane masks
     int opn = 0, err = 0, run = 0, start = 0, oc = 0;
-    int fx = 0, fy = 0, fstrong = 0, has_first = 0;
-    uint32_t cnt = 0u;
-    bool overflow = false;
-
-    // a segment that ended with c >= keep_min samples: the lane's first one is kept in registers (whether it is kept
-    // depends on the lanes in front), later ones only matter if c >= window
-    auto candidate = [&](int sx, int sy, int c) {
-        const int strong = c >= p.window ? 1 : 0;
-        if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
-        else if (strong) {
-            if (cnt < capL) { stage_x[cnt] = sx; stage_y[cnt] = sy; }
-            else overflow = true;
-            ++cnt;
-        }
-    };
     // A block of 32 samples as bit masks (bit e: sample e is in / out of range; samples outside the read are neither).
     // The automaton goes from EVENT to event -- a segment opens at the next set bit of `inm`; it ends at the
     // (error + 1 - err)-th set bit of `outm` behind that -- instead of sample by sample: a segment lives for ~13 samples
@@ -1007,7 +949,7 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
                 start = i0 + e; opn = -1; err = 0; run = 0; pos = e + 1;
             } else {
                 uint32_t mo = outm & keep;
-                const int need = p.error - err + 1;
+                const int need = error - err + 1;
                 const int pc = __popc(mo);
                 if (pc < need) {
                     err += pc;
@@ -1102,6 +1044,82 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
         for (int k = 0; k < JW_BLOCK / 2; ++k) w[k] = wn[k];
     }
 
+}
+
+__global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t r = blockIdx.x * 4 + wv;
+    if (r >= a.b.n_reads) return;
+    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+    const int64_t n = g.len;
+    if (n <= 0) {
+        if (lane == 0) a.n_segs[r] = 0u;
+        return;
+    }
+    WaveRead wr;
+    wr.init(a.b, g);
+    float top = p.top, bot = p.bot;
+    if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
+        const float nf = (float)(int)n;
+        float s = 0.0f, q = 0.0f;
+        {
+            WaveTile cur, nxt;
+            wr.load(cur, 0);
+            for (int t = 0; t < wr.ntiles; ++t) {
+                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+                ss_tile1<false>(s, wr, cur, t, [&](auto b) { return TermClamp<decltype(b)::interior>{b}; });
+                cur = nxt;
+            }
+        }
+        const float mn = s / nf;
+        {
+            WaveTile cur, nxt;
+            wr.load(cur, 0);
+            for (int t = 0; t < wr.ntiles; ++t) {
+                if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+                ss_tile1<false>(q, wr, cur, t, [&](auto b) { return TermDevClamp<decltype(b)::interior>{b, mn}; });
+                cur = nxt;
+            }
+        }
+        const float band = sqrtf(q / nf) * p.std_scale;
+        top = mn + band;
+        bot = mn - band;
+    }
+    // integer form of the tests (JnnAuto::init above): in <=> lo_i < iv < hi_i for the clamped integer sample iv
+    const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
+    const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
+    // the same test on the UNCLAMPED sample: lo_i < clamp(v) < hi_i  <=>  lo_r < v < hi_r
+    const int hi_r = hi_i <= 0 ? -40000 : (hi_i > 1200 ? 40000 : hi_i);
+    const int lo_r = lo_i >= 1200 ? 40000 : (lo_i < 0 ? -40000 : lo_i);
+    const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
+    const int keep_min = first_min_i < p.window ? first_min_i : p.window;
+
+    // ---- the automaton, in chunks between sync points (jnn_chunks); kept segments are staged in the upper half of the
+    // read's slots (a part per lane), the merged segments go to the lower half
+    const int64_t nq = wr.skip + n;
+    const int C = jnn_chunk_lanes(nq);
+    // slots: kept segments are staged in the upper half, the merged segments go to the lower half
+    const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
+    const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
+    int32_t *stage_x = a.seg_x + slot0 + half + (uint64_t)lane * capL, *stage_y = a.seg_y + slot0 + half + (uint64_t)lane * capL;
+
+    int fx = 0, fy = 0, fstrong = 0, has_first = 0;
+    uint32_t cnt = 0u;
+    bool overflow = false;
+
+    // a segment that ended with c >= keep_min samples: the lane's first one is kept in registers (whether it is kept
+    // depends on the lanes in front), later ones only matter if c >= window
+    auto candidate = [&](int sx, int sy, int c) {
+        const int strong = c >= p.window ? 1 : 0;
+        if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
+        else if (strong) {
+            if (cnt < capL) { stage_x[cnt] = sx; stage_y[cnt] = sy; }
+            else overflow = true;
+            ++cnt;
+        }
+    };
+    jnn_chunks(wr, n, hi_r, lo_r, p.error, keep_min, candidate);
+
     // ---- the kept segments in order: [a lane's first candidate, if it is strong or the first of the read] + its staged ones
     const unsigned long long hasf = __ballot(has_first != 0);
     const int firstlane = hasf ? __ffsll((long long)hasf) - 1 : -1;
@@ -1171,6 +1189,77 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     }
     if (lane == 0) a.n_segs[r] = total < half ? total : half;
     if (__any(overflow) && lane == 0) atomicAdd(a.err_count, 1u);
+}
+
+// ---------------------------------------------------------------- find_polya, one WAVE per read
+// jnn_pa on pA[adapt_y .. n) with the fixed thresholds of cfunc.c:191 and the polyA preset (src/jnn.h:52-72), first
+// merged segment only.  x -> rm_outlierf(signal_in_picoamps(x)) is monotone in the raw value, so the in-range test
+// bot < pA < top is an interval test on the raw sample (its bounds by bisection over the 65 536 raw values, with the
+// float expression itself): the pass is jnn_chunks on packed int16, no pA is formed.  A lane keeps its first merged group
+// in registers (start, end, whether a gap of seg_dist or more follows inside the lane, end of its last kept segment);
+// the read's first merged segment is put together from them in lane order.
+template <typename PRED>
+__device__ inline int first_true_i16(PRED pred) {  // smallest v in [-32768, 32767] with pred(v), 32768 if none (pred monotone)
+    int lo = -32768, hi = 32768;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pred(mid)) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_polya_wave(StatArgs a) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t r = blockIdx.x * 4 + wv;
+    if (r >= a.b.n_reads) return;
+    const Region g = get_region(REG_TAIL, a.b, a.prefix, r);
+    int px = -1, py = -1;
+    if (g.len > 0) {
+        const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+        const float mid = a.prefix[r].adapt_mean + 30.0f;
+        const float top = mid + 20.0f, bot = mid - 20.0f;
+        const JnnP pp = jnn_polya_params();
+        auto f = [&](int v) { return clampf_pa(to_pa((int16_t)v, sc)); };
+        int vlo, vhi;  // in range <=> vlo <= raw <= vhi
+        if (sc.unit >= 0.0f) {
+            vlo = first_true_i16([&](int v) { return f(v) > bot; });
+            vhi = first_true_i16([&](int v) { return !(f(v) < top); }) - 1;
+        } else {
+            vlo = first_true_i16([&](int v) { return f(v) < top; });
+            vhi = first_true_i16([&](int v) { return !(f(v) > bot); }) - 1;
+        }
+        // a NaN anywhere (unit, offset, thresholds) makes every comparison of the reference false: nothing is in range
+        if (!(sc.unit == sc.unit) || !(sc.offf == sc.offf) || !(top == top)) { vlo = 1; vhi = 0; }
+        WaveRead wr;
+        wr.init(a.b, g);
+        int nk = 0, gx = 0, gy = 0, gdone = 0, ly = 0;
+        auto candidate = [&](int sx, int sy, int) {  // (stall_len = 1: only segments of window samples or more get here)
+            if (nk == 0) { gx = sx; gy = sy; }
+            else if (!gdone) {
+                if (sx - ly < pp.seg_dist) gy = sy; else gdone = 1;
+            }
+            ly = sy;
+            ++nk;
+        };
+        jnn_chunks(wr, g.len, vhi + 1, vlo - 1, pp.error, pp.window, candidate);
+        unsigned long long have = __ballot(nk > 0);
+        bool found = false;
+        int prev_ly = 0;
+        while (have) {
+            const int l = __ffsll((long long)have) - 1;
+            have &= have - 1ull;
+            const int x = __builtin_amdgcn_readlane(gx, l), y = __builtin_amdgcn_readlane(gy, l);
+            if (found && !(x - prev_ly < pp.seg_dist)) break;
+            if (!found) { px = x; found = true; }
+            py = y;
+            if (__builtin_amdgcn_readlane(gdone, l)) break;
+            prev_ly = __builtin_amdgcn_readlane(ly, l);
+        }
+    }
+    if (lane == 0) {
+        a.prefix[r].polya_x = px;
+        a.prefix[r].polya_y = py;
+    }
 }
 
 // jnn_pa (src/jnn.c:295-306) on ONE float array: jnn_core over rm_outlierf(x).  A compatibility entry (the batched
@@ -1779,7 +1868,13 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     }
     SGK_HIP_TRY(hipGetLastError());
     if (rna) {
-        SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
+        // find_polya tolerates 30 out-of-range samples: its sync points (31 in a row) are rare, the chunks of
+        // k_polya_wave degenerate and the lane-per-read kernel, which stops at the first final segment, is faster
+        // when it can fill the GPU: large batches of reads of similar length (measured on 50 000 x 100 000 samples:
+        // 5.8 ms against 11.3 ms); small or ragged batches go to the wave kernel
+        const bool polya_lanes = lanes || (nr >= 16384u && (uint64_t)a.b.max_read_len * nr <= 2u * a.b.n_samples);
+        if (polya_lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
+        else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
         if (lanes) {
             SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
