@@ -164,6 +164,8 @@ int sgk_stat_pa(const sgk_batch_t *batch, sgk_stat_rec_t *out, float *pa_out, vo
 /* ---- jnn: state-machine segmenter on raw signal (src/jnn.c:190-350) --------------- */
 /* Segments of read r go to slots seg_slots[r].. (same arena convention as events);
  * seg_x/seg_y are jnn_pair_t (src/jnn.h:13-16) as SoA with 32-bit members. */
+/* sgk_jnn may use ALL slots of a read as scratch (the wave-per-read kernel stages kept segments in the upper half
+ * before merging them into the lower half): only the first n_segs[r] entries are results afterwards. */
 static inline uint64_t sgk_jnn_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 32 + 2; }
 size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 int sgk_jnn(const sgk_batch_t *batch, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,

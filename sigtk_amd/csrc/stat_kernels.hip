@@ -584,14 +584,42 @@ __global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
 #define SS_CNT(i) nullptr
 #endif
 
-    // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative)
+    // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative); fused stat + pa: the pA of
+    // every sample is written here, under the lighter arithmetic of the two passes
     float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
     {
         WaveTile cur, nxt;
         if (wr.ntiles > 0) wr.load(cur, 0);
+        float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
         for (int t = 0; t < wr.ntiles; ++t) {
             if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+            int q_lo, q_hi;
+            wr.range(t, 0, q_lo, q_hi);
+            const bool pa_interior = q_lo == 0 && q_hi == SS_TILE;
             const Scale so = {sc.offf, sc.unit * sg};
+            if (PA) {
+                // pA of every sample, written as whole cache lines: the tile is read once more as 4 x 256 samples with
+                // 8 bytes per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the chains' layout,
+                // 64 bytes per lane, would make every store instruction touch 32 lines partially)
+#pragma unroll
+                for (int sub = 0; sub < SS_TILE / 256; ++sub) {
+                    const int qs = sub * 256 + lane * 4;
+                    int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
+                    const int64_t last = wr.n_total - 4;
+                    pp = pp < last ? pp : last;
+                    const uint2 rw = *reinterpret_cast<const uint2 *>(wr.samples + pp);
+                    const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
+                                                 to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
+                    float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
+                    if (pa_interior) *reinterpret_cast<float4 *>(dst) = o;
+                    else {
+                        if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
+                        if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
+                        if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
+                        if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
+                    }
+                }
+            }
             ss_tile2<true>(
                 m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b}; },
                 [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
@@ -616,7 +644,6 @@ __global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
     {
         WaveTile cur, nxt;
         if (wr.ntiles > 0) wr.load(cur, 0);
-        float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
         for (int t = 0; t < wr.ntiles; ++t) {
             if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
             int q_lo, q_hi;
@@ -635,29 +662,6 @@ __global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
             };
             if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
             else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
-            if (PA) {
-                // pA of every sample, written as whole cache lines: the tile is read once more as 4 x 256 samples with
-                // 8 bytes per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the chains' layout,
-                // 64 bytes per lane, would make every store instruction touch 32 lines partially)
-#pragma unroll
-                for (int sub = 0; sub < SS_TILE / 256; ++sub) {
-                    const int qs = sub * 256 + lane * 4;
-                    int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
-                    const int64_t last = wr.n_total - 4;
-                    pp = pp < last ? pp : last;
-                    const uint2 rw = *reinterpret_cast<const uint2 *>(wr.samples + pp);
-                    const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
-                                                 to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
-                    float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
-                    if (interior) *reinterpret_cast<float4 *>(dst) = o;
-                    else {
-                        if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
-                        if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
-                        if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
-                        if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
-                    }
-                }
-            }
             ss_tile2<false>(
                 q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
                 [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));

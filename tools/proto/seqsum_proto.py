@@ -122,7 +122,7 @@ def tile_chain(m, x, st, neg_lane=None):
     return m
 
 
-def seq_sum_wave(x, st=None, head=64, sign_aware=True, neg_possible=True):
+def seq_sum_wave(x, st=None, head=256, sign_aware=True, neg_possible=True):
     """Exact emulation of `s = 0; for v in x: s = fl(s + v)` for float32 x."""
     st = st or Stats()
     x = np.asarray(x, dtype=np.float32)
