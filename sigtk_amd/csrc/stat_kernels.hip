@@ -566,7 +566,7 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
 }
 
 template <int MODE, bool PA>
-__global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
+__global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
     __shared__ uint32_t hist_all[4][WH_BINS];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t r = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_stat_wave(StatArgs a) {
                 // pA of every sample, written as whole cache lines: the tile is read once more as 4 x 256 samples with
                 // 8 bytes per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the chains' layout,
                 // 64 bytes per lane, would make every store instruction touch 32 lines partially)
-#pragma unroll
+#pragma unroll 1
                 for (int sub = 0; sub < SS_TILE / 256; ++sub) {
                     const int qs = sub * 256 + lane * 4;
                     int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
