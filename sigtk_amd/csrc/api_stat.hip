@@ -19,37 +19,39 @@ static StatArgs make_args(const sgk_batch_t *b) {
 
 extern "C" {
 
-size_t sgk_stat_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
-size_t sgk_jnn_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
-size_t sgk_prefix_workspace_bytes(uint32_t, uint64_t, uint32_t) { return 64; }
+// 64 bytes of counters + room for the longest-first dispatch order (a smaller workspace, down to 64 bytes -- none for
+// stat / prefix -- is accepted: the kernels then take the reads in batch order)
+size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
+size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
+size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
 
 int sgk_stat(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream) {
-    (void)ws; (void)ws_bytes;
-    const int rc = check_batch(b);
+    int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
     a.stat = out;
+    if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
 int sgk_stat_pa(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream) {
-    (void)ws; (void)ws_bytes;
-    const int rc = check_batch(b);
+    int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out || !pa_out) return SGK_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(pa_out) & 15u) return SGK_ERR_ALIGN;
     StatArgs a = make_args(b);
     a.stat = out;
-    a.pa_out = pa_out;  // the median pass streams every sample anyway: it writes the pA values as it goes
+    a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
+    if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
 int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
             uint32_t *n_segs, void *ws, size_t ws_bytes, void *stream) {
-    const int rc = check_batch(b);
+    int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!seg_slots || !seg_x || !seg_y || !n_segs || !ws) return SGK_ERR_ARG;
@@ -60,18 +62,19 @@ int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *s
     a.seg_y = seg_y;
     a.n_segs = n_segs;
     a.err_count = static_cast<uint32_t *>(ws);
+    if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
 int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
                void *stream) {
-    (void)ws; (void)ws_bytes;
-    const int rc = check_batch(b);
+    int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
     a.prefix = out;
+    if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
 }
 

@@ -15,7 +15,15 @@ struct StatArgs {
     uint32_t *n_segs;
     uint32_t *err_count;         // workspace: number of reads whose segments overflowed their slots
     float *pa_out;               // stat+pa fused: pA of every sample, written by the median pass (or null)
+    const uint32_t *order;       // wave-per-read kernels: wave i takes read order[i] (longest reads first), or null
 };
+
+// workspace layout of stat / jnn / prefix: [0, 64) counters (jnn: overflow count), then the dispatch order of the
+// wave-per-read kernels (n_reads x 4 bytes) and the 2 x 128 words of its counting sort
+constexpr uint32_t ORDER_MIN_READS = 1024;  // below that a batch is one round of waves anyway
+size_t order_workspace_bytes(uint32_t n_reads);
+// fills a.order from the workspace when it is large enough (else leaves it null) and launches the sort
+int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st);
 
 // jnn_param_t (src/jnn.h:18-27) and the run-finder part of jnnv2_param_t (src/jnn.h:74-81; its window is fixed at
 // 2000, the value of both presets: the rolling mean divides by it with the exact constant division)

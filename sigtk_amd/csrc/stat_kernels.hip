@@ -569,8 +569,9 @@ template <int MODE, bool PA>
 __global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
     __shared__ uint32_t hist_all[4][WH_BINS];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t r = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
-    if (r >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
+    const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
+    if (widx >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
+    const uint32_t r = a.order ? a.order[widx] : widx;
     uint32_t *hist = hist_all[wv];
     const Region g = get_region(MODE, a.b, a.prefix, r);
     const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
@@ -640,7 +641,6 @@ __global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float q_raw = 0.0f, q_pa = 0.0f;
-#ifndef SGK_EXP_PASS1
     {
         WaveTile cur, nxt;
         if (wr.ntiles > 0) wr.load(cur, 0);
@@ -652,13 +652,11 @@ __global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
             const int q0 = lane * SS_SPL;
             // histogram of the raw values; pA of every sample
             auto each = [&]<int E>(int16_t v, bool valid) {
-#ifndef SGK_EXP_NOHIST
                 if (valid) {
                     int b = (int)v - lo;
                     b = b < 0 ? 0 : (b > WH_BINS - 1 ? WH_BINS - 1 : b);
                     atomicAdd(&hist[b], 1u);
                 }
-#endif
             };
             if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
             else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
@@ -668,7 +666,6 @@ __global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
             cur = nxt;
         }
     }
-#endif
     const float sdraw = sqrtf(q_raw / nf), sdpa = sqrtf(q_pa / nf);
 
     // ---- the order statistics of ranks k (raw median) and, for a negative unit, n-1-k (the pA median's raw value)
@@ -1052,8 +1049,9 @@ __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi
 
 __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t r = blockIdx.x * 4 + wv;
-    if (r >= a.b.n_reads) return;
+    const uint32_t widx = blockIdx.x * 4 + wv;
+    if (widx >= a.b.n_reads) return;
+    const uint32_t r = a.order ? a.order[widx] : widx;
     const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
     if (n <= 0) {
@@ -1214,8 +1212,9 @@ __device__ inline int first_true_i16(PRED pred) {  // smallest v in [-32768, 327
 
 __global__ __launch_bounds__(256) void k_polya_wave(StatArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t r = blockIdx.x * 4 + wv;
-    if (r >= a.b.n_reads) return;
+    const uint32_t widx = blockIdx.x * 4 + wv;
+    if (widx >= a.b.n_reads) return;
+    const uint32_t r = a.order ? a.order[widx] : widx;
     const Region g = get_region(REG_TAIL, a.b, a.prefix, r);
     int px = -1, py = -1;
     if (g.len > 0) {
@@ -1640,8 +1639,9 @@ __device__ __forceinline__ int mask_last(uint32_t m16, int cur, int hi) {
 
 __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t r = blockIdx.x * 4 + wv;
-    if (r >= a.b.n_reads) return;
+    const uint32_t widx = blockIdx.x * 4 + wv;
+    if (widx >= a.b.n_reads) return;
+    const uint32_t r = a.order ? a.order[widx] : widx;
     const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
     sgk_prefix_rec_t *o = a.prefix + r;
@@ -1785,6 +1785,57 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
         if (found) { o->adapt_x = ans_x + ADW / 2 - 1; o->adapt_y = ans_y + ADW / 2 - 1; }
         else { o->adapt_x = 0; o->adapt_y = 0; }
     }
+}
+
+// ---------------------------------------------------------------- dispatch order of the wave-per-read kernels
+// A wave-per-read kernel cannot finish before its longest read has: reads are handed to the waves longest first
+// (workgroups start in index order), by a counting sort of the read lengths into 128 buckets (4 per octave).
+__device__ inline uint32_t len_bucket(uint32_t n) {
+    if (n < 4u) return n;
+    const uint32_t e = 31u - (uint32_t)__clz((int)n);
+    return 4u * e + ((n >> (e - 2u)) & 3u);  // <= 127
+}
+// (per-workgroup LDS histograms first: a batch of equal-length reads would otherwise send every atomic to one word)
+__global__ __launch_bounds__(256) void k_order_count(const uint32_t *lengths, uint32_t n, uint32_t *hist) {
+    __shared__ uint32_t h[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n) atomicAdd(&h[len_bucket(lengths[r])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_order_scan(uint32_t *hist /* 128 counts -> cursors, longest bucket first */) {
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0u;
+        for (int b = 127; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = acc; acc += c; }
+    }
+}
+__global__ __launch_bounds__(256) void k_order_fill(const uint32_t *lengths, uint32_t n, uint32_t *cursor, uint32_t *order) {
+    __shared__ uint32_t h[128], base[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    uint32_t b = 0u, local = 0u;
+    if (r < n) { b = len_bucket(lengths[r]); local = atomicAdd(&h[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (r < n) order[base[b] + local] = r;
+}
+size_t order_workspace_bytes(uint32_t n_reads) { return 64 + ((size_t)n_reads * 4 + 128 * 4 + 63) / 64 * 64; }
+int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
+    a.order = nullptr;
+    const uint32_t nr = a.b.n_reads;
+    if (!ws || nr < ORDER_MIN_READS || ws_bytes < order_workspace_bytes(nr) || (reinterpret_cast<uintptr_t>(ws) & 3u)) return SGK_OK;
+    uint32_t *order = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + 64), *hist = order + nr;
+    SGK_HIP_TRY(hipMemsetAsync(hist, 0, 128 * 4, st));
+    hipLaunchKernelGGL(k_order_count, dim3((nr + 255) / 256), dim3(256), 0, st, a.b.lengths, nr, hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, hist);
+    hipLaunchKernelGGL(k_order_fill, dim3((nr + 255) / 256), dim3(256), 0, st, a.b.lengths, nr, hist, order);
+    SGK_HIP_TRY(hipGetLastError());
+    a.order = order;
+    return SGK_OK;
 }
 
 // ---------------------------------------------------------------- launchers

@@ -141,12 +141,24 @@ def event(b: DeviceReads, arena: EventArena, rna: int) -> None:
 
 # ---------------------------------------------------------------------- stat / jnn / prefix / pa (device API)
 
+def _workspace(b: "DeviceReads", size_fn_name: str) -> torch.Tensor:
+    """the workspace sgk_<tool>_workspace_bytes asks for (counters + the longest-first dispatch order of the
+    wave-per-read kernels), allocated once per batch"""
+    cache = b.__dict__.setdefault("_ws_cache", {})
+    if size_fn_name not in cache:
+        L = api.load_library()
+        n = int(getattr(L, size_fn_name)(b.n_reads, b.n_samples, b.max_read_len))
+        cache[size_fn_name] = torch.zeros(max(n, 64), dtype=torch.uint8, device=b.samples.device)
+    return cache[size_fn_name]
+
+
 def stat(b: DeviceReads) -> torch.Tensor:
     """sgk_stat -> uint8 tensor holding n_reads sgk_stat_rec_t (view it with api.STAT_DTYPE)."""
     L = api.load_library()
     out = torch.zeros(max(b.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
     view = b.view()
-    api.check(L.sgk_stat(C.byref(view), _ptr(out), None, 0, _stream_ptr()), "sgk_stat")
+    ws = _workspace(b, "sgk_stat_workspace_bytes")
+    api.check(L.sgk_stat(C.byref(view), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_stat")
     return out
 
 
@@ -158,7 +170,8 @@ def stat_pa(b: DeviceReads, pa_out: Optional[torch.Tensor] = None):
     if pa_out is None:
         pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=b.samples.device)
     view = b.view()
-    api.check(L.sgk_stat_pa(C.byref(view), _ptr(out), _ptr(pa_out), None, 0, _stream_ptr()), "sgk_stat_pa")
+    ws = _workspace(b, "sgk_stat_workspace_bytes")
+    api.check(L.sgk_stat_pa(C.byref(view), _ptr(out), _ptr(pa_out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_stat_pa")
     return out, pa_out
 
 
@@ -166,7 +179,8 @@ def prefix(b: DeviceReads, rna: int, pore: int) -> torch.Tensor:
     L = api.load_library()
     out = torch.zeros(max(b.n_reads, 1) * api.PREFIX_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
     view = b.view()
-    api.check(L.sgk_prefix(C.byref(view), int(rna), int(pore), _ptr(out), None, 0, _stream_ptr()), "sgk_prefix")
+    ws = _workspace(b, "sgk_prefix_workspace_bytes")
+    api.check(L.sgk_prefix(C.byref(view), int(rna), int(pore), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_prefix")
     return out
 
 
@@ -180,14 +194,15 @@ class SegArena:
         self.x = torch.empty(max(int(slots[-1]), 1), dtype=torch.int32, device=dev)
         self.y = torch.empty(max(int(slots[-1]), 1), dtype=torch.int32, device=dev)
         self.n_segs = torch.zeros(max(b.n_reads, 1), dtype=torch.int32, device=dev)
-        self.ws = torch.zeros(64, dtype=torch.uint8, device=dev)
+        n = int(api.load_library().sgk_jnn_workspace_bytes(b.n_reads, b.n_samples, b.max_read_len))
+        self.ws = torch.zeros(max(n, 64), dtype=torch.uint8, device=dev)
 
 
 def jnn(b: DeviceReads, arena: SegArena, rna: int) -> None:
     L = api.load_library()
     view = b.view()
     api.check(L.sgk_jnn(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.x), _ptr(arena.y),
-                        _ptr(arena.n_segs), _ptr(arena.ws), 64, _stream_ptr()), "sgk_jnn")
+                        _ptr(arena.n_segs), _ptr(arena.ws), arena.ws.numel(), _stream_ptr()), "sgk_jnn")
 
 
 def pa(b: DeviceReads, out: torch.Tensor) -> None:
