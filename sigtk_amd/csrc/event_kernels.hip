@@ -565,6 +565,8 @@ struct LazyPass {
     unsigned long long *bm;       // read's bitmap (global)
     RepairCtx rep;                // FLAGGED only
     int next_t;                   // FLAGGED only
+    int dirty;                    // FLAGGED only: block-relative index up to which this lane's own window sums are
+                                  // not trusted (an addition of ITS running prefix was inexact, see tstep)
 
     // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are redirected to the
     // nearest readable group: whatever value a position yields is used consistently (it enters the prefix sum once),
@@ -597,7 +599,22 @@ struct LazyPass {
         // short window: its A side was ringed W1 indices ago
         bool ok;
         const float v = sgk_tstat_try_ab<W1>(b1, b1q, ar[(U + NA - W1) % NA], ok);
-        if constexpr (FLAGGED) ok = ok && sgk_try_domain<W1>(b1, b1q, ar[(U + NA - W1) % NA]);
+        bool clean = true;
+        if constexpr (FLAGGED) {
+            ok = ok && sgk_try_domain<W1>(b1, b1q, ar[(U + NA - W1) % NA]);
+            // A flagged read failed the magnitude guard: the lane's running prefix can round as well, and not where
+            // the reference's sequential scan did (other origin, other magnitudes), so `rep` does not list those
+            // places.  TwoSum residual of the two additions above; after an inexact one the window sums of the next
+            // 2 * W2 indices (every window with x[i + W2] inside) are taken from the reference's prefix arrays.
+            // (Found by the soak: a 2e-5 pA sample 22 indices in front of a plateau of two equal statistics.)
+            const double a_s = Ps[(U + W2) % NP], b_s = (double)xn, r_s = Ps[(U + W2 + 1) % NP];
+            const double a_q = Pq[(U + W2) % NP], b_q = (double)xqn, r_q = Pq[(U + W2 + 1) % NP];
+            const double t_s = r_s - a_s, t_q = r_q - a_q;
+            const double e_s = (a_s - (r_s - t_s)) + (b_s - t_s), e_q = (a_q - (r_q - t_q)) + (b_q - t_q);
+            clean = U > dirty;
+            if (e_s != 0.0 || e_q != 0.0) dirty = dirty > U + 2 * W2 ? dirty : U + 2 * W2;
+            ok = ok && clean;
+        }
         ar[U % NA] = sgk_arole<W1>(b1, b1q);
         // long window: bound only
 #ifdef SGK_EXP_NO_LONG
@@ -606,7 +623,7 @@ struct LazyPass {
 #else
         const SgkLSide lb = sgk_lside<W2>(b2, b2q);
         bool cold = sgk_long_cold<W2>(ls[(U + NL - W2) % NL], lb);
-        if constexpr (FLAGGED) cold = cold && sgk_lside_domain(ls[(U + NL - W2) % NL]) && sgk_lside_domain(lb);
+        if constexpr (FLAGGED) cold = cold && clean && sgk_lside_domain(ls[(U + NL - W2) % NL]) && sgk_lside_domain(lb);
         ls[U % NL] = lb;
 #endif
         t1[U & 3] = v;
@@ -904,6 +921,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool first, int 
     f.done = ~__ballot(active);
     f.flushed = 0;
     if constexpr (FLAGGED) {
+        f.dirty = 2 * W2;  // the ring was filled by a handful of additions that were not checked
         f.rep = *rep;
         // first event whose influence [t-W2+1, t+W2] is not entirely before this pass' first index
         f.next_t = 0x7fffffff;
@@ -955,6 +973,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool first, int 
         f.sp -= R;
         f.lm = f.lm < LZ_NONE ? LZ_NONE : f.lm - R;
         f.r0 -= R;
+        if constexpr (FLAGGED) f.dirty = f.dirty < -(1 << 20) ? f.dirty : f.dirty - R;
         jb += R;
         {
             // state snapshots live in LDS (they are only needed after the pass)
@@ -1603,7 +1622,11 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
         rep.ev = events.ev;
         rep.nev = events.count < REP_MAX_EVENTS ? events.count : REP_MAX_EVENTS;
         rep.all_dirty = events.count > REP_MAX_EVENTS;
+#ifdef SGK_EXP_FB_GENERIC
+        const int rcode = 1;
+#else
         const int rcode = detect_read_lazy<W1, T, true>(rc, a.hdr, &Lz, &rep);
+#endif
         if (rcode) detect_read<W1, T>(rc, a.hdr);
         __threadfence();
         __syncthreads();

@@ -172,6 +172,9 @@ def _adversarial_reads(gpu, seed):
     rng[39] = 0.0                                                            # unit = 0: every pA is 0
     rng[40] = 1e-30                                                          # tiny pA
     rng[41] = 1e38                                                           # huge pA: the sum overflows to inf
+    # every pA is -0.0 (raw = -offset, negative unit): the reference's sum stays +0 (soak seed 2024, batch 2376)
+    reads[2] = np.full(2, -18, dtype=np.int16); off[2] = 18.0; rng[2] = -abs(rng[2])
+    reads[3] = np.full(15, -2, dtype=np.int16); off[3] = 2.0; rng[3] = -abs(rng[3])
     return reads, dig, off, rng
 
 
