@@ -61,6 +61,7 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.off_hdr = o;     o += sizeof(EvHeader);
     w.off_flags = o;   o += round_up(nr, 64);
     w.off_list = o;    o += round_up(nr * 4, 64);
+    w.off_order = o;   o += round_up(nr * 4 + 128 * 4, 64);
     w.off_bitmap = o;  o += round_up((n_samples / 64 + nr + 2) * 8, 64);
     w.off_scratch = o;
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
@@ -128,6 +129,8 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.hdr = reinterpret_cast<EvHeader *>(base + w.off_hdr);
     a.flags = reinterpret_cast<uint8_t *>(base + w.off_flags);
     a.flag_list = reinterpret_cast<uint32_t *>(base + w.off_list);
+    // longest-first dispatch only pays when lengths differ: a batch of equal-length reads is launched in batch order
+    a.order = ((uint64_t)max_read_len * n_reads > n_samples + n_samples / 4) ? reinterpret_cast<uint32_t *>(base + w.off_order) : nullptr;
     a.bitmap = reinterpret_cast<unsigned long long *>(base + w.off_bitmap);
     a.scratch = reinterpret_cast<double *>(base + w.off_scratch);
     a.scratch_stride = w.scratch_stride;

@@ -33,11 +33,12 @@ struct EvArgs {
     unsigned long long *bitmap;     // word base of read r: offsets[r]/64 + r
     double *scratch;                // fallback: per block scratch_stride doubles
     uint64_t scratch_stride;        // 2 * (max_read_len + 1), rounded up to even
+    uint32_t *order;                // n_reads + 128: workgroup i of k_event takes read order[i] (longest first)
 };
 
 // workspace carving shared by sgk_event_workspace_bytes and sgk_event
 struct EvWorkspace {
-    size_t off_hdr, off_flags, off_list, off_bitmap, off_scratch, total;
+    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_scratch, total;
     uint64_t scratch_stride;
     uint32_t n_fb_blocks;
 };

@@ -35,6 +35,7 @@
 #include <utility>
 
 #include "event_args.h"
+#include "stat_args.h"
 #include "sgk_common.h"
 #include "tstat_math.h"
 
@@ -1584,7 +1585,9 @@ union EventLds {
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
     __shared__ EventLds L;
-    const uint32_t r = blockIdx.x;
+    // reads are taken longest first (launch_order): a kernel cannot end before its longest read has, so that one
+    // should start first, not wherever it sits in the batch
+    const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
     const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L.lz, nullptr);
     // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
@@ -1649,10 +1652,15 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     ProfScope whole("path:event", st);
     SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
 #if SGK_EVENT_FUSED
+    EvArgs ao = a;
+    if (a.n_reads >= ORDER_MIN_READS && a.order) {
+        const int rc = launch_order(a.lengths, a.n_reads, a.order, a.order + a.n_reads, st);
+        if (rc != SGK_OK) return rc;
+    } else ao.order = nullptr;
     {
         ProfScope ps("k_event", st);
-        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
 #else

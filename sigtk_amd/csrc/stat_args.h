@@ -24,6 +24,8 @@ constexpr uint32_t ORDER_MIN_READS = 1024;  // below that a batch is one round o
 size_t order_workspace_bytes(uint32_t n_reads);
 // fills a.order from the workspace when it is large enough (else leaves it null) and launches the sort
 int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st);
+// the sort itself: order[0 .. n) = read indices, longest reads first; scratch: 128 words
+int launch_order(const uint32_t *lengths, uint32_t n, uint32_t *order, uint32_t *scratch128, hipStream_t st);
 
 // jnn_param_t (src/jnn.h:18-27) and the run-finder part of jnnv2_param_t (src/jnn.h:74-81; its window is fixed at
 // 2000, the value of both presets: the rolling mean divides by it with the exact constant division)

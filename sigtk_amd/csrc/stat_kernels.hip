@@ -1829,16 +1829,23 @@ __global__ __launch_bounds__(256) void k_order_fill(const uint32_t *lengths, uin
     if (r < n) order[base[b] + local] = r;
 }
 size_t order_workspace_bytes(uint32_t n_reads) { return 64 + ((size_t)n_reads * 4 + 128 * 4 + 63) / 64 * 64; }
+int launch_order(const uint32_t *lengths, uint32_t nr, uint32_t *order, uint32_t *hist, hipStream_t st) {
+    SGK_HIP_TRY(hipMemsetAsync(hist, 0, 128 * 4, st));
+    hipLaunchKernelGGL(k_order_count, dim3((nr + 255) / 256), dim3(256), 0, st, lengths, nr, hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, hist);
+    hipLaunchKernelGGL(k_order_fill, dim3((nr + 255) / 256), dim3(256), 0, st, lengths, nr, hist, order);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
 int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
     a.order = nullptr;
     const uint32_t nr = a.b.n_reads;
     if (!ws || nr < ORDER_MIN_READS || ws_bytes < order_workspace_bytes(nr) || (reinterpret_cast<uintptr_t>(ws) & 3u)) return SGK_OK;
+    // (a batch of near-equal lengths -- the longest read at most 1.25 x the mean -- is taken in batch order)
+    if ((uint64_t)a.b.max_read_len * nr <= a.b.n_samples + a.b.n_samples / 4) return SGK_OK;
     uint32_t *order = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + 64), *hist = order + nr;
-    SGK_HIP_TRY(hipMemsetAsync(hist, 0, 128 * 4, st));
-    hipLaunchKernelGGL(k_order_count, dim3((nr + 255) / 256), dim3(256), 0, st, a.b.lengths, nr, hist);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, hist);
-    hipLaunchKernelGGL(k_order_fill, dim3((nr + 255) / 256), dim3(256), 0, st, a.b.lengths, nr, hist, order);
-    SGK_HIP_TRY(hipGetLastError());
+    const int rc = launch_order(a.b.lengths, nr, order, hist, st);
+    if (rc != SGK_OK) return rc;
     a.order = order;
     return SGK_OK;
 }

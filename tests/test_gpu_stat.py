@@ -235,3 +235,42 @@ def test_jnn_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
                 np.testing.assert_array_equal(wave[r][1], lane[r][1], err_msg="kind %d rna %d read %d (n=%d) y" % (kind, rna, r, reads[r].size))
             sub = list(range(0, 27))
             _check_jnn(oracle, [reads[i] for i in sub], rna, [wave[i] for i in sub])
+
+
+def test_wave_kernels_longest_first_dispatch(gpu, oracle, monkeypatch):
+    """>= 1024 reads through the job API: the wave-per-read kernels take the reads in the order of a device-side
+    counting sort of their lengths (longest first).  Same records as the lane-per-read kernels, and as the oracle."""
+    rs = np.random.RandomState(12)
+    nr = 1500
+    lens = [int(v) for v in np.clip(np.exp(rs.normal(7.5, 1.3, size=nr)), 0, 60000)]
+    lens[7] = 0; lens[8] = 1; lens[9] = 150000
+    reads, dig, off, rng = gpu.synth_reads_host(nr, lens, seed=77, kind=1)
+    out = {}
+    for mode in ("wave", "lane"):
+        if mode == "lane":
+            monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+        else:
+            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        job = gpu.Job(0)
+        job.stage(reads, dig, off, rng, None)
+        job.launch(gpu.TOOL_STAT); st = job.wait()["stat"]
+        job.launch(gpu.TOOL_JNN, rna=1); sg = job.wait()["segs"]
+        job.launch(gpu.TOOL_PREFIX, rna=1, pore=0); pf = job.wait()["prefix"]
+        out[mode] = (st.copy(), [(x.copy(), y.copy()) for x, y in sg], pf.copy())
+        job.close()
+    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    for r in range(nr):
+        assert out["wave"][0][r].tobytes() == out["lane"][0][r].tobytes(), "stat read %d" % r
+        np.testing.assert_array_equal(out["wave"][1][r][0], out["lane"][1][r][0], err_msg="jnn x read %d" % r)
+        np.testing.assert_array_equal(out["wave"][1][r][1], out["lane"][1][r][1], err_msg="jnn y read %d" % r)
+        w, l = out["wave"][2][r], out["lane"][2][r]
+        for name in ("adapt_x", "adapt_y", "polya_x", "polya_y"):
+            assert int(w[name]) == int(l[name]), "prefix read %d %s" % (r, name)
+        if int(w["adapt_y"]) > 0:
+            for name in ("adapt_mean", "adapt_std", "adapt_median"):
+                assert np.float32(w[name]).view(np.uint32) == np.float32(l[name]).view(np.uint32), "prefix read %d %s" % (r, name)
+    sub = [i for i in range(0, nr, 37) if lens[i] > 0] + [9]
+    with np.errstate(all="ignore"):
+        _check_stat(oracle, [reads[i] for i in sub], dig[sub], off[sub], rng[sub], [out["wave"][0][i] for i in sub])
+        _check_jnn(oracle, [reads[i] for i in sub], 1, [out["wave"][1][i] for i in sub])
+        _check_prefix(oracle, [reads[i] for i in sub], dig[sub], off[sub], rng[sub], 1, 0, [out["wave"][2][i] for i in sub])
