@@ -1428,7 +1428,7 @@ __device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
-    bool overflow = false, dense = false;
+    bool overflow = false;
     uint32_t rank = 0, prevp = 0;
     const int64_t nwords = (n + 31) >> 5;
     for (int64_t w0 = 0; w0 < nwords; w0 += 64) {

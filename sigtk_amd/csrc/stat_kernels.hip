@@ -428,13 +428,20 @@ struct WaveTile {
         return (E & 1) ? (int16_t)(w[E / 2] >> 16) : (int16_t)(w[E / 2] & 0xffffu);
     }
 };
-// this lane's 16 samples at base-relative index p (a multiple of 8, as is n_total >= 8).  Both 16-byte loads are
-// unconditional -- a half that lies beyond the buffer reads the buffer's last 16 bytes instead; such samples are outside
-// the region and masked by the term functors -- so that the load of tile t + 1 stays in flight under tile t.
-__device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int64_t n_total, int64_t p) {
+// This lane's 16 samples of the tile that starts at base-relative index `tile0` (wave-uniform, >= 0, a multiple of 8, as
+// is n_total >= 8).  Both 16-byte loads are unconditional, so that the load of tile t + 1 stays in flight under tile t,
+// and addressed as uniform base + 32-bit lane offset (scalar address arithmetic).  Near the end of the buffer the
+// offsets are clamped to its last 16 bytes: such samples are outside the region and masked by the term functors.
+__device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int64_t n_total, int64_t tile0) {
     const int64_t last = n_total - 8;
-    const int64_t p0 = p < last ? p : last, p1 = p + 8 < last ? p + 8 : last;
-    const uint4 q0 = *reinterpret_cast<const uint4 *>(samples + p0), q1 = *reinterpret_cast<const uint4 *>(samples + p1);
+    const int64_t t0 = tile0 < last ? tile0 : last;
+    const int64_t room64 = (last - t0) * (int64_t)sizeof(int16_t);
+    const uint32_t room = room64 > 4096 ? 4096u : (uint32_t)room64;  // largest legal byte offset, a multiple of 16
+    const char *tb = reinterpret_cast<const char *>(samples + t0);
+    const uint32_t lo = (uint32_t)lane_id() * (uint32_t)(SS_SPL * sizeof(int16_t));
+    const uint32_t o0 = lo < room ? lo : room, o1 = lo + 16u < room ? lo + 16u : room;
+    const uint4 q0 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o0, 16));
+    const uint4 q1 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o1, 16));
     t.w[0] = q0.x; t.w[1] = q0.y; t.w[2] = q0.z; t.w[3] = q0.w;
     t.w[4] = q1.x; t.w[5] = q1.y; t.w[6] = q1.z; t.w[7] = q1.w;
 }
@@ -461,8 +468,7 @@ struct WaveRead {  // wave-uniform description of the region a wave works on
         ntiles = (int)((skip + len + SS_TILE - 1) / SS_TILE);
     }
     __device__ __forceinline__ void load(WaveTile &t, int tile) const {
-        const int64_t q = (int64_t)tile * SS_TILE + lane_id() * SS_SPL;  // first sample of this lane, region-relative + skip
-        wt_load(t, samples, n_total, rb + q);
+        wt_load(t, samples, n_total, rb + (int64_t)tile * SS_TILE);
     }
     // a tile strictly inside the region (and not the first one, whose head is added natively): no predicates
     __device__ __forceinline__ bool interior(int tile) const {
@@ -1690,9 +1696,9 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
         int T0 = first_total;
         WaveTile tr, ld, trn, ldn;
         auto load2 = [&](WaveTile &x, WaveTile &y, int t) {
-            const int64_t q = (int64_t)t * SS_TILE + q0;
-            wt_load(x, wr.samples, wr.n_total, wr.rb + q);
-            wt_load(y, wr.samples, wr.n_total, wr.rb + q + ADW);
+            const int64_t tile0 = wr.rb + (int64_t)t * SS_TILE;
+            wt_load(x, wr.samples, wr.n_total, tile0);
+            wt_load(y, wr.samples, wr.n_total, tile0 + ADW);
         };
         load2(tr, ld, 0);
         for (int t = 0; t < wr.ntiles; ++t) {
