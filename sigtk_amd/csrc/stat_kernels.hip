@@ -571,8 +571,11 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
     if (!ss_fast<NEG>(mb, wb)) mb = ss_finish<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wb, cb);
 }
 
+#ifndef SGK_STAT_WAVES
+#define SGK_STAT_WAVES 4  // waves per SIMD the register allocation aims at (5: spills, measured slower)
+#endif
 template <int MODE, bool PA>
-__global__ __launch_bounds__(256, 4) void k_stat_wave(StatArgs a) {
+__global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     __shared__ uint32_t hist_all[4][WH_BINS];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
