@@ -1366,11 +1366,8 @@ __global__ __launch_bounds__(256) void k_stat_f32(const float *x, int n, float *
 // top = (m_a+30)+20, bot = (m_a+30)-20 (src/cfunc.c:191); polyA preset src/jnn.h:52-72.
 __global__ __launch_bounds__(64) void k_polya(StatArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
-    const uint32_t ridx = blockIdx.x * 64 + lane_id();
-    const bool valid = ridx < a.b.n_reads;
-    // with the longest-first order the 64 reads of a wavefront are neighbours in length (same 19 % bucket): a ragged
-    // batch then costs this lane-per-read kernel what a uniform one does
-    const uint32_t r = (valid && a.order) ? a.order[ridx] : ridx;
+    const uint32_t r = blockIdx.x * 64 + lane_id();
+    const bool valid = r < a.b.n_reads;
     Region g = {0, 0};
     Scale sc = {0.0f, 1.0f};
     float m_a = 0.0f;
@@ -1947,9 +1944,9 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
         // find_polya tolerates 30 out-of-range samples: its sync points (31 in a row) are rare, the chunks of
         // k_polya_wave degenerate and the lane-per-read kernel, which stops at the first final segment, is faster
         // when it can fill the GPU: large batches of reads of similar length (measured on 50 000 x 100 000 samples:
-        // 5.8 ms against 11.3 ms) -- or ragged ones when the longest-first order is available, which makes the reads
-        // of a wavefront neighbours in length; small batches go to the wave kernel
-        const bool polya_lanes = lanes || (nr >= 16384u && (a.order || (uint64_t)a.b.max_read_len * nr <= 2u * a.b.n_samples));
+        // 5.8 ms against 11.3 ms); small or ragged batches go to the wave kernel.  (Feeding the lane kernel the sorted
+        // order instead was measured: its 64 row streams then lie all over the buffer and it takes 74 ms, not 66.)
+        const bool polya_lanes = lanes || (nr >= 16384u && (uint64_t)a.b.max_read_len * nr <= 2u * a.b.n_samples);
         if (polya_lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
