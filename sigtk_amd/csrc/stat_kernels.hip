@@ -1313,15 +1313,50 @@ __global__ __launch_bounds__(64) void k_jnn_f32(const float *x, int64_t n, JnnP 
 // meanf / stdvf / medianf (src/stat.h:17-27, 36-44, 56-63) of ONE float array, for the reference-signature shims:
 // the sequential float sums on every lane of the wave (lane 0 stores), the order statistic of rank n/2 by a
 // three-level (11 + 11 + 10 bit) radix select on the order-preserving integer image of the floats.
+struct TermArr {  // terms kept in registers
+    const float (&x)[SS_SPL];
+    __device__ __forceinline__ TermArr with(uint32_t) const { return *this; }
+    template <int E>
+    __device__ __forceinline__ float get() const { return x[E]; }
+};
+
+// one seqsum.h chain over a float array: term(x[i]) for i = 0 .. n-1, by one wave (the other waves of the workgroup
+// skip it).  Terms can have any sign: the chain is oriented by the sign of its accumulator, tiles holding a term of
+// the other sign are added natively.
+template <typename F>
+__device__ float ss_chain_f32(const float *x, int n, F term) {
+    const int lane = lane_id(), q0 = lane * SS_SPL;
+    float m = 0.0f, sg = 1.0f;
+    const int ntiles = (n + SS_TILE - 1) / SS_TILE;
+    const int head = n < SS_HEAD ? n : SS_HEAD;
+    for (int t = 0; t < ntiles; ++t) {
+        float v[SS_SPL], y[SS_SPL];
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) {
+            const int i = t * SS_TILE + q0 + e;
+            v[e] = i < n ? term(x[i]) * sg : 0.0f;  // (* +-1: exact)
+        }
+        if (t == 0) {  // the head natively; its terms are zeroed for the tile chain
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) y[e] = (q0 + e < head) ? v[e] : 0.0f;
+            if (head > 0) m = ss_serial(m, TermArr{y}, 0, (head - 1) / SS_SPL);
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) v[e] = (q0 + e < head) ? 0.0f : v[e];
+        }
+        const SsWalk w = ss_walk<true>(m, TermArr{v});
+        if (!ss_fast<true>(m, w)) m = ss_finish<true>(m, TermArr{v}, w);
+        if (m < 0.0f) { m = -m; sg = -sg; }
+    }
+    return m == 0.0f ? 0.0f : m * sg;
+}
+
 __global__ __launch_bounds__(256) void k_stat_f32(const float *x, int n, float *out3) {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t sel_prefix, sel_rank;
-    if (threadIdx.x < 64) {
-        float s = 0.0f;
-        for (int j = 0; j < n; ++j) s = s + x[j];
+    if (threadIdx.x < 64) {  // wave 0: the sequential float sums through seqsum.h
+        const float s = ss_chain_f32(x, n, [](float v) { return v; });
         const float mn = s / n;
-        float q = 0.0f;
-        for (int j = 0; j < n; ++j) q = q + (x[j] - mn) * (x[j] - mn);
+        const float q = ss_chain_f32(x, n, [&](float v) { return (v - mn) * (v - mn); });
         if (threadIdx.x == 0) { out3[0] = mn; out3[1] = sqrtf(q / n); }
     }
     auto key = [](float f) -> uint32_t {
@@ -1595,13 +1630,6 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, AdaptP ap) {
 // seqsum.h.  Three passes: sum of the means; sum of their squared deviations; the run finder (src/jnn.c:126-158), whose
 // state only changes where the below / above-threshold flags flip: the wave jumps from flip to flip over 16-bit lane
 // masks and stops at the first qualifying segment that can no longer change.
-struct TermArr {  // terms kept in registers
-    const float (&x)[SS_SPL];
-    __device__ __forceinline__ TermArr with(uint32_t) const { return *this; }
-    template <int E>
-    __device__ __forceinline__ float get() const { return x[E]; }
-};
-
 // rolling totals of this lane's 16 window indices.  T0: total of the tile's first index (wave-uniform), advanced to
 // the next tile's.  d_lo: tile-local indices below it have no difference (they lie in front of the read).
 template <bool MASKED>

@@ -72,3 +72,36 @@ def test_adaptor_and_polya_shims(gpu, oracle):
     # a window the kernels do not implement is refused, not approximated
     (xy, rc) = gpu.shim_jnnv2(reads[2], gpu.Jnnv2Param(0.5, 1500, 1000, 0.0, 200000, 2000))
     assert xy == (-1, -1) and rc != 0
+
+
+def test_seqsum_chains_on_hostile_float_arrays(gpu, oracle):
+    """sgk_meanf / sgk_stdvf run the reference's sequential float sums through seqsum.h (surrogate starts, parity maps,
+    binade crossings, native fallbacks) on ARBITRARY float input: mixed signs, cancellation, ties at every step, sums
+    through zero, denormals, overflow to inf, NaN.  Bit-identical to the oracle's plain loops."""
+    rs = np.random.RandomState(21)
+    arrays = []
+    for n in (1, 2, 15, 16, 17, 255, 256, 257, 1023, 1024, 1025, 4999, 70000, 300000):
+        arrays.append(rs.normal(90, 12, size=n).astype(np.float32))
+        arrays.append(rs.normal(0, 50, size=n).astype(np.float32))                 # sum wanders through zero
+        arrays.append((-rs.gamma(2.0, 30.0, size=n)).astype(np.float32))            # all negative
+    arrays.append(np.full(200000, 333.0, dtype=np.float32))                        # integer sum beyond 2^24: ties
+    arrays.append(np.where(np.arange(100000) % 2 == 0, 0.5, 1.5).astype(np.float32))
+    arrays.append(np.concatenate([np.zeros(3000), np.full(500, 7.25), np.zeros(3000), np.full(4000, -7.25)]).astype(np.float32))
+    big = rs.normal(100, 10, size=50000).astype(np.float32); big[20000] = 3e7; big[30000] = -3e7; big[40000] = 1e-30
+    arrays.append(big)
+    arrays.append((rs.rand(5000) * 1e-38).astype(np.float32))                       # denormal sums
+    arrays.append((rs.rand(5000) * 3e38).astype(np.float32))                        # overflows to inf
+    nn = rs.normal(100, 10, size=5000).astype(np.float32); nn[2500] = np.nan
+    arrays.append(nn)
+    ii = rs.normal(100, 10, size=5000).astype(np.float32); ii[2500] = np.inf
+    arrays.append(ii)
+    ij = ii.copy(); ij[3000] = -np.inf
+    arrays.append(ij)
+    with np.errstate(all="ignore"):
+        for k, x in enumerate(arrays):
+            g = gpu.shim_stat_f32(x)
+            e = oracle.statf(x)
+            for name, a, b in (("mean", g[0], e[0]), ("std", g[1], e[1]), ("median", g[2], e[2])):
+                a, b = np.float32(a), np.float32(b)
+                assert (np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32), \
+                    "array %d (n=%d) %s: gpu %r oracle %r" % (k, x.size, name, a, b)
