@@ -1,22 +1,25 @@
 // stat_kernels.hip -- per-read statistics, the JNN segmenter and the adaptor/polyA finder.
 //
 // Reference semantics that shape these kernels:
-//   * meanf/meani16/stdvf/stdvi16 (src/stat.h:17-54) accumulate into ONE float, strictly in
-//     sample order; at 100k samples the result differs from the exact value by up to ~6e-5
-//     relative, so the order must be reproduced: one read per LANE, serial float chain.
-//     The lanes of a wave stream 64 different reads through the LDS row stager (row_stream.h),
-//     so global loads are still whole 128-byte line segments.
-//   * medians are order statistics (rank n/2, src/stat.h:56-73 + ksort.h:233-259): any exact
-//     selection works -> one 256-thread workgroup per read; whole reads take ONE pass (an LDS
-//     histogram with a bin per raw value over a window centred on the read's mean, which the
-//     moments kernel has just written; the same pass can write the pA values: fused stat + pa),
-//     regions and pathological reads a two-level radix select on the int16 keys; pA median =
-//     pA(raw order statistic) because the int16 -> pA map is monotone (non-increasing when
-//     range/digitisation < 0).
-//   * jnn_core (src/jnn.c:190-278) and jnnv2 (src/jnn.c:99-179) are serial automata with
-//     thresholds derived from those sequential float moments: one read per lane as well.  Their
-//     per-sample work is integer: mask algebra for jnn_core, integer rolling totals with the exact
-//     constant division (tstat_math.h) and integer thresholds for jnnv2's run finder.
+//   * meanf/meani16/stdvf/stdvi16 (src/stat.h:17-54) accumulate into ONE float, strictly in sample order; at 100k
+//     samples the result differs from the exact value by up to ~6e-5 relative, so the rounding sequence must be
+//     reproduced.  Two implementations live here:
+//       - round 2 (default): one WAVE per read.  seqsum.h evaluates the sequential sum exactly, 1024 terms at a time
+//         (surrogate starts in the sum's binade, parity maps, binade crossings repaired natively): k_stat_wave,
+//         k_adaptor_wave, k_jnn_wave, k_polya_wave, with the reads dispatched longest first (launch_order);
+//       - round 1 (SGK_LANE_PER_READ=1, and find_polya on large uniform batches): one read per LANE, serial float
+//         chain, the 64 reads of a wave streamed through the LDS row stager (row_stream.h): k_moments, k_jnn, k_adaptor,
+//         k_polya.  Kept as the independent second implementation the tests compare against, bit for bit.
+//   * medians are order statistics (rank n/2, src/stat.h:56-73 + ksort.h:233-259): any exact selection works -> a
+//     histogram with one bin per raw value over a window centred on the read's mean (k_stat_wave: 2048 bins per wave,
+//     fused into its second pass; k_median: 8192 bins per 256-thread workgroup), a two-level radix select for regions
+//     and for reads whose order statistic falls outside the window; pA median = pA(raw order statistic) because the
+//     int16 -> pA map is monotone (non-increasing when range/digitisation < 0).
+//   * jnn_core (src/jnn.c:190-278) and jnnv2 (src/jnn.c:99-179) are serial automata with thresholds derived from those
+//     sequential float moments.  Their per-sample work is integer: in / out-of-range flags of the raw samples, integer
+//     rolling totals with the exact constant division (tstat_math.h) and integer thresholds for jnnv2's run finder.
+//     Wave-per-read forms: jnn_core in 64 chunks between data-determined sync points, from event to event on 32-bit
+//     masks (jnn_chunks); jnnv2's run finder from threshold flip to flip (k_adaptor_wave).
 #include <stdlib.h>
 
 #include "row_stream.h"
@@ -1028,7 +1031,8 @@ __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi
             inm &= vmask;
             const uint32_t outm = ~inm & vmask;
             int lo = 0, hi = 32;
-            if (srchm || qb + JW_BLOCK > ce) {  // the sync logic is in play: where this lane's run starts / ends
+            bool ends_here = false;
+            if (srchm || qb + JW_BLOCK >= ce) {  // the sync logic is in play (the block holds sample ce - 1 or lies behind it)
                 const uint32_t sy = sync_bits(outm, oc);
                 if (srchm) {  // the run starts behind the first sync sample at position >= cs - 1
                     const int64_t f = cs - qb - 1;
@@ -1039,15 +1043,15 @@ __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi
                         runm = qb + lo >= ce ? 0 : -1;
                     } else lo = 32;
                 }
-                if (runm && qb + JW_BLOCK > ce) {  // ... and ends with the first sync sample at position >= ce - 1
+                if (runm && qb + JW_BLOCK >= ce) {  // ... and ends with the first sync sample at position >= ce - 1
                     int64_t f = ce - qb - 1;
                     if (f < lo) f = lo;
                     const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
-                    if (m) hi = __ffs((int)m);
+                    if (m) { hi = __ffs((int)m); ends_here = true; }  // (hi can be 32: the sync sample is the block's last)
                 }
             }
             if (runm && lo < hi) run_block(inm, outm, (int)(qb - wr.skip), lo, hi);
-            if (hi < 32) runm = 0;  // done
+            if (ends_here) runm = 0;  // done
             const uint32_t stop = inm | ~vmask;  // samples that are not out of range
             oc = stop ? __clz((int)stop) : oc + 32;
         }
@@ -1123,6 +1127,9 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     // a segment that ended with c >= keep_min samples: the lane's first one is kept in registers (whether it is kept
     // depends on the lanes in front), later ones only matter if c >= window
     auto candidate = [&](int sx, int sy, int c) {
+#ifdef SGK_JNN_DEBUG
+        printf("cand lane %d: %d %d c %d\n", lane, sx, sy, c);
+#endif
         const int strong = c >= p.window ? 1 : 0;
         if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
         else if (strong) {

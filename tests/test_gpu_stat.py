@@ -1,4 +1,6 @@
 """GPU parity: stat / jnn / prefix HIP paths against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -274,3 +276,15 @@ def test_wave_kernels_longest_first_dispatch(gpu, oracle, monkeypatch):
         _check_stat(oracle, [reads[i] for i in sub], dig[sub], off[sub], rng[sub], [out["wave"][0][i] for i in sub])
         _check_jnn(oracle, [reads[i] for i in sub], 1, [out["wave"][1][i] for i in sub])
         _check_prefix(oracle, [reads[i] for i in sub], dig[sub], off[sub], rng[sub], 1, 0, [out["wave"][2][i] for i in sub])
+
+
+def test_jnn_wave_regression_sync_sample_at_block_end(gpu, oracle):
+    """tests/soak_wave_vs_lane.py, seed 5, batches 431 and 797: the sync sample that ends a lane's run was the LAST
+    sample of a 32-sample block (position 32 = "whole block" was mistaken for "no end found"), the lane ran on into its
+    neighbour's chunk and both reported the segments there; the merge then produced (next start, previous end)."""
+    for name in ("soak_wvl_seed5_b431_r1525.npz", "soak_wvl_seed5_b797_r3354.npz"):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+        x = z["samples"].astype(np.int16)
+        dig, off, rng = np.array([float(z["dig"])]), np.array([float(z["off"])]), np.array([float(z["rng"])])
+        for rna in (0, 1):
+            _check_jnn(oracle, [x], rna, gpu.jnn([x], dig, off, rng, rna))
