@@ -259,6 +259,14 @@ def test_wave_kernels_longest_first_dispatch(gpu, oracle, monkeypatch):
         job.launch(gpu.TOOL_JNN, rna=1); sg = job.wait()["segs"]
         job.launch(gpu.TOOL_PREFIX, rna=1, pore=0); pf = job.wait()["prefix"]
         out[mode] = (st.copy(), [(x.copy(), y.copy()) for x, y in sg], pf.copy())
+        if mode == "wave":  # k_event takes the reads in the same order
+            job.launch(gpu.TOOL_EVENT, rna=1)
+            ev = job.wait()["events"]
+            for i in [i for i in range(0, nr, 41) if lens[i] > 0] + [9]:
+                e = oracle.event_raw(reads[i], dig[i], off[i], rng[i], 1)
+                g = ev[i]
+                assert g.start.size == e.start.size and np.array_equal(g.start.astype(np.uint64), e.start.astype(np.uint64)), "event read %d" % i
+                assert np.array_equal(g.mean.view(np.uint32), e.mean.view(np.uint32)), "event means read %d" % i
         job.close()
     monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
     for r in range(nr):
