@@ -410,6 +410,14 @@ __global__ __launch_bounds__(256) void k_median(StatArgs a) {
     }
 }
 
+// two samples per packed 16-bit instruction: the outlier clamp of rm_outlier (src/jnn.c:61-77)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
+    s16x2 v = __builtin_bit_cast(s16x2, w);
+    v = __builtin_elementwise_max(v, (s16x2){0, 0});
+    return __builtin_elementwise_min(v, (s16x2){1200, 1200});
+}
+
 // ---------------------------------------------------------------- one WAVE per read (seqsum.h)
 // The sequential float sums of a read (or of a region of it) by one wavefront: tiles of 64 x SS_SPL samples, every
 // lane loads its 32 contiguous bytes with two 16-byte loads (tile t + 1 is in flight while tile t is consumed), the
@@ -501,6 +509,11 @@ struct TermBase {
     __device__ __forceinline__ int16_t sample() const {
         const uint32_t w = t.w[E / 2] ^ z;
         return (E & 1) ? (int16_t)(w >> 16) : (int16_t)(w & 0xffffu);
+    }
+    template <int E>
+    __device__ __forceinline__ float clamped() const {  // rm_outlier of the sample: the clamp is packed, two per dword
+        const s16x2 c = clamp_raw2(t.w[E / 2] ^ z);
+        return (float)((E & 1) ? c.y : c.x);
     }
 };
 template <bool INTERIOR>
@@ -895,7 +908,7 @@ struct TermClamp {  // rm_outlier(raw), src/jnn.c:61-77
     __device__ __forceinline__ TermClamp with(uint32_t z) const { TermClamp r = *this; r.b.z = z; return r; }
     template <int E>
     __device__ __forceinline__ float get() const {
-        return b.template valid<E>() ? clampf_raw(b.template sample<E>()) : 0.0f;
+        return b.template valid<E>() ? b.template clamped<E>() : 0.0f;
     }
 };
 template <bool INTERIOR>
@@ -905,7 +918,7 @@ struct TermDevClamp {  // (rm_outlier(raw) - mean)^2
     __device__ __forceinline__ TermDevClamp with(uint32_t z) const { TermDevClamp r = *this; r.b.z = z; return r; }
     template <int E>
     __device__ __forceinline__ float get() const {
-        const float d = clampf_raw(b.template sample<E>()) - mean;
+        const float d = b.template clamped<E>() - mean;
         return b.template valid<E>() ? d * d : 0.0f;
     }
 };
@@ -1509,12 +1522,6 @@ __device__ __forceinline__ void rolling_elems(const uint32_t (&wl)[PART / 2], co
 }
 // all PART lead indices are in [ADW, n-1): no predicates.  Two samples per packed 16-bit instruction for the outlier
 // clamp and the lead - trail difference (|difference| <= 1200 fits int16).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
-    s16x2 v = __builtin_bit_cast(s16x2, w);
-    v = __builtin_elementwise_max(v, (s16x2){0, 0});
-    return __builtin_elementwise_min(v, (s16x2){1200, 1200});
-}
 template <int K, typename F>
 __device__ __forceinline__ void rolling_full(const uint32_t (&wl)[PART / 2], const uint32_t (&wt)[PART / 2], int i0,
                                              int &tot, F &f) {
