@@ -58,3 +58,23 @@ def test_jnn_adaptor_polya(oracle, ref, seed):
         pa = oracle.pa(raw, dig[r], off[r], rng[r])
         for top, bot in ((120.0, 80.0), (110.5, 90.25)):
             assert oracle.find_polya(pa, top, bot, 0) == ref.find_polya(pa, top, bot, 0)
+
+
+def test_soak_regression_fixtures_are_pinned(oracle, ref):
+    """the reads the round-2 soaks found GPU bugs on (tests/golden/soak_*.npz): what the GPU tests compare against --
+    the oracle -- equals the real reference on them (event, stat and jnn)."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name in ("soak_seed2024_b6003_r1407.npz", "soak_wvl_seed5_b431_r1525.npz", "soak_wvl_seed5_b797_r3354.npz"):
+        z = np.load(os.path.join(gold, name))
+        raw = z["samples"].astype(np.int16)
+        dig, off, rng = float(np.ravel(z["dig"])[0]), float(np.ravel(z["off"])[0]), float(np.ravel(z["rng"])[0])
+        for rna in (0, 1):
+            a = oracle.event_raw(raw, dig, off, rng, rna)
+            b = ref.event_raw(raw, dig, off, rng, rna)
+            assert np.array_equal(a.start, b.start) and np.array_equal(a.mean.view(np.uint32), b.mean.view(np.uint32))
+            ax, ay = oracle.jnn_raw(raw, rna)
+            bx, by = ref.jnn_raw(raw, rna)
+            assert np.array_equal(ax, bx) and np.array_equal(ay, by)
+        sa, sb = oracle.stat(raw, dig, off, rng), ref.stat(raw, dig, off, rng)
+        assert sa[4] == sb[4] and all(np.float32(sa[k]).view(np.uint32) == np.float32(sb[k]).view(np.uint32) for k in (0, 1, 2, 3, 5))
