@@ -1228,9 +1228,49 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
 // jnn_pa on pA[adapt_y .. n) with the fixed thresholds of cfunc.c:191 and the polyA preset (src/jnn.h:52-72), first
 // merged segment only.  x -> rm_outlierf(signal_in_picoamps(x)) is monotone in the raw value, so the in-range test
 // bot < pA < top is an interval test on the raw sample (its bounds by bisection over the 65 536 raw values, with the
-// float expression itself): the pass is jnn_chunks on packed int16, no pA is formed.  A lane keeps its first merged group
-// in registers (start, end, whether a gap of seg_dist or more follows inside the lane, end of its last kept segment);
-// the read's first merged segment is put together from them in lane order.
+// float expression itself): no pA is formed.  With error = 30 the automaton has next to no sync points (31 out-of-range
+// samples in a row), so instead of chunks the wave goes through the tail tile by tile (64 x 16 samples, coalesced) with
+// the automaton's state in scalars and JUMPS: a segment opens at the next in-range sample and ends at the
+// (error + 1 - err)-th out-of-range sample behind it, both found on the tile's 16-bit lane masks (next set bit; k-th set
+// bit by a popcount scan).  It stops as soon as the first merged segment can no longer change -- usually after a few
+// tiles, where the lane-per-read kernel waits for the slowest of 64 reads.
+// (jnn_chunks was tried first for this: its chunks degenerate, 11.3 ms against the lane kernel's 5.8 ms on 50 000 reads.)
+// first set bit at tile-local position >= cur of the 1024-bit mask held as 16 bits per lane (-1: none)
+__device__ __forceinline__ int mask_next(uint32_t m16, int cur) {
+    const int lo = cur - lane_id() * SS_SPL;
+    const uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
+    const unsigned long long has = __ballot(m != 0u);
+    if (!has) return -1;
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)has) - 1);
+    return l * SS_SPL + __builtin_amdgcn_readlane(__ffs((int)m) - 1, l);
+}
+// last set bit at a tile-local position in [cur, hi) (-1: none)
+__device__ __forceinline__ int mask_last(uint32_t m16, int cur, int hi) {
+    const int lo = cur - lane_id() * SS_SPL, up = hi - lane_id() * SS_SPL;
+    uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
+    m = up >= SS_SPL ? m : (up <= 0 ? 0u : m & ((1u << up) - 1u));
+    const unsigned long long has = __ballot(m != 0u);
+    if (!has) return -1;
+    const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)has));
+    return l * SS_SPL + __builtin_amdgcn_readlane(31 - __clz((int)m), l);
+}
+
+// set bits of the tile mask (16 bits per lane) at tile-local positions >= cur
+__device__ __forceinline__ uint32_t mask_from(uint32_t m16, int cur) {
+    const int lo = cur - lane_id() * SS_SPL;
+    return lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
+}
+// position of the k-th (k >= 1) set bit at a position >= cur, given that there are at least k
+__device__ __forceinline__ int mask_select(uint32_t m16, int cur, int k) {
+    uint32_t m = mask_from(m16, cur);
+    const int c = __popc(m), incl = wave_incl_scan_i(c), excl = incl - c;
+    const unsigned long long own = __ballot(excl < k && incl >= k);
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)own) - 1);
+    int kk = k - __builtin_amdgcn_readlane(excl, l);  // 1 .. 16, wave-uniform
+    for (; kk > 1; --kk) m &= m - 1u;
+    return l * SS_SPL + __builtin_amdgcn_readlane(__ffs((int)m) - 1, l);
+}
+
 template <typename PRED>
 __device__ inline int first_true_i16(PRED pred) {  // smallest v in [-32768, 32767] with pred(v), 32768 if none (pred monotone)
     int lo = -32768, hi = 32768;
@@ -1266,28 +1306,57 @@ __global__ __launch_bounds__(256) void k_polya_wave(StatArgs a) {
         if (!(sc.unit == sc.unit) || !(sc.offf == sc.offf) || !(top == top)) { vlo = 1; vhi = 0; }
         WaveRead wr;
         wr.init(a.b, g);
-        int nk = 0, gx = 0, gy = 0, gdone = 0, ly = 0;
-        auto candidate = [&](int sx, int sy, int) {  // (stall_len = 1: only segments of window samples or more get here)
-            if (nk == 0) { gx = sx; gy = sy; }
-            else if (!gdone) {
-                if (sx - ly < pp.seg_dist) gy = sy; else gdone = 1;
+        const int hi_r = vhi + 1, lo_r = vlo - 1;  // in range <=> lo_r < raw < hi_r
+        // automaton state (wave-uniform): open, errors so far, trailing tolerated errors, start; first merged segment
+        int opn = 0, err = 0, run = 0, start = 0, last_y = 0;
+        bool found = false, done = false;
+        WaveTile cur_t, nxt_t;
+        wr.load(cur_t, 0);
+        for (int t = 0; t < wr.ntiles && !done; ++t) {
+            if (t + 1 < wr.ntiles) wr.load(nxt_t, t + 1);
+            int q_lo, q_hi;
+            wr.range(t, 0, q_lo, q_hi);
+            uint32_t inm = 0u;
+#pragma unroll
+            for (int e = 0; e < SS_SPL; ++e) {
+                const int iv = (e & 1) ? (int)(int16_t)(cur_t.w[e / 2] >> 16) : (int)(int16_t)(cur_t.w[e / 2] & 0xffffu);
+                inm |= ((uint32_t)((iv - hi_r) & (lo_r - iv)) >> 31) << e;
             }
-            ly = sy;
-            ++nk;
-        };
-        jnn_chunks(wr, g.len, vhi + 1, vlo - 1, pp.error, pp.window, candidate);
-        unsigned long long have = __ballot(nk > 0);
-        bool found = false;
-        int prev_ly = 0;
-        while (have) {
-            const int l = __ffsll((long long)have) - 1;
-            have &= have - 1ull;
-            const int x = __builtin_amdgcn_readlane(gx, l), y = __builtin_amdgcn_readlane(gy, l);
-            if (found && !(x - prev_ly < pp.seg_dist)) break;
-            if (!found) { px = x; found = true; }
-            py = y;
-            if (__builtin_amdgcn_readlane(gdone, l)) break;
-            prev_ly = __builtin_amdgcn_readlane(ly, l);
+            const int l0 = q_lo - lane * SS_SPL, l1 = q_hi - lane * SS_SPL;
+            uint32_t vm = l0 <= 0 ? 0xffffu : (l0 >= SS_SPL ? 0u : (0xffffu >> l0) << l0);
+            vm = l1 >= SS_SPL ? vm : (l1 <= 0 ? 0u : vm & ((1u << l1) - 1u));
+            inm &= vm;
+            const uint32_t outm = ~inm & vm;
+            const int jbase = t * SS_TILE - wr.skip;  // sample index (in the tail) of tile-local position 0
+            int cur = q_lo;
+            for (;;) {
+                if (!opn) {
+                    const int ps = mask_next(inm, cur);
+                    if (ps < 0) break;
+                    start = jbase + ps; opn = 1; err = 0; run = 0; cur = ps + 1;
+                } else {
+                    const int need = pp.error + 1 - err;
+                    const int pc = wave_last_i(wave_incl_scan_i(__popc(mask_from(outm, cur))));
+                    if (pc < need) {  // the segment outlives the tile
+                        err += pc;
+                        const int li = mask_last(inm, cur, q_hi);
+                        run = li >= 0 ? q_hi - 1 - li : run + (q_hi - cur);
+                        break;
+                    }
+                    const int pe = mask_select(outm, cur, need);
+                    const int li = mask_last(inm, cur, pe);
+                    const int perr = li >= 0 ? pe - 1 - li : run + (pe - cur);
+                    const int i = jbase + pe, end = i - perr;
+                    if (i - start >= pp.window) {  // kept (stall_len = 1: the first-segment rule is the same)
+                        if (!found) { px = start; py = end; found = true; }
+                        else if (start - last_y < pp.seg_dist) py = end;
+                        else { done = true; break; }  // the first merged segment is final
+                        last_y = end;
+                    }
+                    opn = 0; err = 0; run = 0; cur = pe + 1;
+                }
+            }
+            cur_t = nxt_t;
         }
     }
     if (lane == 0) {
@@ -1670,26 +1739,6 @@ __device__ __forceinline__ void roll_tile(const WaveTile &trail, const WaveTile 
     T0 += wave_last_i(incl);
 }
 
-// first set bit at tile-local position >= cur of the 1024-bit mask held as 16 bits per lane (-1: none)
-__device__ __forceinline__ int mask_next(uint32_t m16, int cur) {
-    const int lo = cur - lane_id() * SS_SPL;
-    const uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
-    const unsigned long long has = __ballot(m != 0u);
-    if (!has) return -1;
-    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)has) - 1);
-    return l * SS_SPL + __builtin_amdgcn_readlane(__ffs((int)m) - 1, l);
-}
-// last set bit at a tile-local position in [cur, hi) (-1: none)
-__device__ __forceinline__ int mask_last(uint32_t m16, int cur, int hi) {
-    const int lo = cur - lane_id() * SS_SPL, up = hi - lane_id() * SS_SPL;
-    uint32_t m = lo <= 0 ? m16 : (lo >= SS_SPL ? 0u : (m16 >> lo) << lo);
-    m = up >= SS_SPL ? m : (up <= 0 ? 0u : m & ((1u << up) - 1u));
-    const unsigned long long has = __ballot(m != 0u);
-    if (!has) return -1;
-    const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)has));
-    return l * SS_SPL + __builtin_amdgcn_readlane(31 - __clz((int)m), l);
-}
-
 __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;
@@ -1983,12 +2032,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     }
     SGK_HIP_TRY(hipGetLastError());
     if (rna) {
-        // find_polya tolerates 30 out-of-range samples: its sync points (31 in a row) are rare, the chunks of
-        // k_polya_wave degenerate and the lane-per-read kernel, which stops at the first final segment, is faster
-        // when it can fill the GPU: large batches of reads of similar length (measured on 50 000 x 100 000 samples:
-        // 5.8 ms against 11.3 ms); small or ragged batches go to the wave kernel.  (Feeding the lane kernel the sorted
-        // order instead was measured: its 64 row streams then lie all over the buffer and it takes 74 ms, not 66.)
-        const bool polya_lanes = lanes || (nr >= 16384u && (uint64_t)a.b.max_read_len * nr <= 2u * a.b.n_samples);
+        const bool polya_lanes = lanes;
         if (polya_lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
