@@ -2032,8 +2032,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     }
     SGK_HIP_TRY(hipGetLastError());
     if (rna) {
-        const bool polya_lanes = lanes;
-        if (polya_lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
+        if (lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
         if (lanes) {
