@@ -7,7 +7,14 @@ namespace sgk {
 // ---------------------------------------------------------------- pa
 // One workgroup (256 threads) per 8192-sample slab of a read; 8 samples (16 B in, 32 B out) per
 // lane per step: purely streaming, 6 B/sample.
-constexpr int PA_SLAB = 8192;
+#ifndef SGK_PA_SLAB
+#define SGK_PA_SLAB 8192
+#endif
+#ifndef SGK_PA_UNROLL
+#define SGK_PA_UNROLL 4
+#endif
+constexpr int PA_SLAB = SGK_PA_SLAB;
+constexpr int PA_UNROLL = SGK_PA_UNROLL;
 
 // A launch holds at most SLAB_GRID_MAX workgroups (gridDim.x * 256 threads must stay below 2^32, and a ragged batch
 // with one very long read has n_reads * slabs_per_read far beyond that): every kernel of this shape strides over the
@@ -32,18 +39,30 @@ __global__ __launch_bounds__(256) void k_pa(const int16_t *samples, const uint64
         float *dst = out + o0;
         const bool vec = ((reinterpret_cast<uintptr_t>(src + b) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + b) & 15u) == 0);
         if (vec) {
-            for (uint64_t p = b + (uint64_t)threadIdx.x * 8; p < e; p += 256 * 8) {
-                if (p + 8 <= e) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(src + p);
-                    int16_t s[8];
-                    __builtin_memcpy(s, &q, 16);
-                    float4 a, c;
-                    a.x = to_pa(s[0], sc); a.y = to_pa(s[1], sc); a.z = to_pa(s[2], sc); a.w = to_pa(s[3], sc);
-                    c.x = to_pa(s[4], sc); c.y = to_pa(s[5], sc); c.z = to_pa(s[6], sc); c.w = to_pa(s[7], sc);
-                    *reinterpret_cast<float4 *>(dst + p) = a;
-                    *reinterpret_cast<float4 *>(dst + p + 4) = c;
-                } else {
-                    for (uint64_t k = p; k < e; ++k) dst[k] = to_pa(src[k], sc);
+            // four 16-byte loads in flight per lane before the first store (the loads of a plain loop wait behind the
+            // previous iteration's stores: the compiler cannot know that src and dst do not alias)
+            constexpr int UN = PA_UNROLL;
+            for (uint64_t p0 = b + (uint64_t)threadIdx.x * 8; p0 < e; p0 += (uint64_t)UN * 256 * 8) {
+                uint4 q[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const uint64_t p = p0 + (uint64_t)u * 256 * 8;
+                    q[u] = (p + 8 <= e) ? *reinterpret_cast<const uint4 *>(src + p) : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const uint64_t p = p0 + (uint64_t)u * 256 * 8;
+                    if (p + 8 <= e) {
+                        int16_t s[8];
+                        __builtin_memcpy(s, &q[u], 16);
+                        float4 a, c;
+                        a.x = to_pa(s[0], sc); a.y = to_pa(s[1], sc); a.z = to_pa(s[2], sc); a.w = to_pa(s[3], sc);
+                        c.x = to_pa(s[4], sc); c.y = to_pa(s[5], sc); c.z = to_pa(s[6], sc); c.w = to_pa(s[7], sc);
+                        *reinterpret_cast<float4 *>(dst + p) = a;
+                        *reinterpret_cast<float4 *>(dst + p + 4) = c;
+                    } else if (p < e) {
+                        for (uint64_t k = p; k < e; ++k) dst[k] = to_pa(src[k], sc);
+                    }
                 }
             }
         } else {
