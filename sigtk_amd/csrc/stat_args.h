@@ -16,7 +16,9 @@ struct StatArgs {
     uint32_t *err_count;         // workspace: number of reads whose segments overflowed their slots
     float *pa_out;               // stat+pa fused: pA of every sample, written by the median pass (or null)
     const uint32_t *order;       // wave-per-read kernels: wave i takes read order[i] (longest reads first), or null
+    uint32_t jnn_redo;           // k_jnn: 1 = only the reads k_jnn_wave gave up on (n_segs[r] == JNN_REDO_MARK)
 };
+constexpr uint32_t JNN_REDO_MARK = 0xffffffffu;
 
 // workspace layout of stat / jnn / prefix: [0, 64) counters (jnn: overflow count), then the dispatch order of the
 // wave-per-read kernels (n_reads x 4 bytes) and the 2 x 128 words of its counting sort

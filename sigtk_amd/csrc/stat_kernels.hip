@@ -856,7 +856,8 @@ AdaptP adaptor_preset(int pore) {  // JNNV2_RNA_R9_ADAPTOR / JNNV2_RNA_RNA004_AD
 __global__ __launch_bounds__(64) void k_jnn(StatArgs a, JnnP p) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
     const uint32_t r = blockIdx.x * 64 + lane_id();
-    const bool valid = r < a.b.n_reads;
+    const bool valid = r < a.b.n_reads && (!a.jnn_redo || a.n_segs[r] == JNN_REDO_MARK);
+    if (a.jnn_redo && !__any(valid)) return;
     Region g = {0, 0};
     if (valid) g = get_region(REG_WHOLE, a.b, nullptr, r);
     int skip;
@@ -943,7 +944,7 @@ constexpr int JW_BLOCK = 32;  // samples a lane takes per step of the chunked pa
 
 // The chunked pass of jnn_core shared by k_jnn_wave and k_polya_wave: in <=> lo_r < raw < hi_r; `candidate(x, y, c)`
 // is called, per lane in sample order, for every segment that ended after c >= keep_min samples.
-__device__ __forceinline__ int jnn_chunk_lanes(int64_t nq) { return nq >= 2048 ? (nq / 1024 >= 64 ? 64 : (int)(nq / 1024)) : 1; }
+__device__ __forceinline__ int jnn_chunk_lanes(int64_t nq) { return nq >= 512 ? (nq / 256 >= 64 ? 64 : (int)(nq / 256)) : 1; }
 template <typename CAND>
 __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi_r, int lo_r, int error, int keep_min,
                                            CAND &candidate) {
@@ -1220,8 +1221,10 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
             x = xn; y = yn;
         }
     }
-    if (lane == 0) a.n_segs[r] = total < half ? total : half;
-    if (__any(overflow) && lane == 0) atomicAdd(a.err_count, 1u);
+    // A lane's staging part is sized for chunks that end where they should; a read with too few sync points (a lane ran
+    // on through many chunks and kept more segments than its part holds) is handed to the lane-per-read kernel instead
+    const bool giveup = __any(overflow) || total > half;
+    if (lane == 0) a.n_segs[r] = giveup ? JNN_REDO_MARK : total;
 }
 
 // ---------------------------------------------------------------- find_polya, one WAVE per read
@@ -1950,9 +1953,16 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 // ---------------------------------------------------------------- launchers
 // SGK_LANE_PER_READ=1 selects the lane-per-read kernels of round 1 (kept as an independent second implementation:
 // tests compare the two; tools/bench_subtools.py times both)
-static bool lane_per_read() {
+// SGK_LANE_PER_READ=0 forces the wave-per-read kernels.  By default a batch takes them unless it is a LARGE batch of
+// SHORT reads of SIMILAR length (>= 65 536 reads of at most 16 384 samples, the longest at most 1.5 x the mean): there the
+// lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and no per-read costs
+// (native heads, binade crossings, chunk start-up), and are up to 4 x faster (400 000 x 5 000 samples: jnn 3.6 ms
+// against 14.5 ms); everywhere else -- ragged, small or long-read batches -- the wave kernels win by 1.5 - 40 x.
+static bool lane_per_read(const sgk_batch_t &b) {
     const char *e = getenv("SGK_LANE_PER_READ");
-    return e && e[0] == '1';
+    if (e && e[0] == '1') return true;
+    if (e && e[0] == '0') return false;
+    return b.n_reads >= 65536u && b.max_read_len <= 16384u && (uint64_t)b.max_read_len * b.n_reads <= b.n_samples + b.n_samples / 2;
 }
 
 #define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
@@ -1964,7 +1974,7 @@ static bool lane_per_read() {
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read()) {
+    if (lane_per_read(a.b)) {
         SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
         SGK_HIP_TRY(hipGetLastError());
         if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
@@ -1985,8 +1995,14 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
-    if (lane_per_read() || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
-    else SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
+    if (lane_per_read(a.b) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    else {
+        SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
+        SGK_HIP_TRY(hipGetLastError());
+        StatArgs redo = a;
+        redo.jnn_redo = 1u;  // the reads the wave kernel gave up on (none, usually: its wavefronts return at once)
+        SGK_LAUNCH("k_jnn_redo", k_jnn, (nr + 63) / 64, 64, redo, p);
+    }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -1994,7 +2010,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
 int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read()) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read(a.b)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
@@ -2017,7 +2033,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    const bool lanes = lane_per_read();
+    const bool lanes = lane_per_read(a.b);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
     SGK_HIP_TRY(hipGetLastError());

@@ -224,6 +224,8 @@ def test_jnn_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
         reads[16] = (500 + 3 * ((np.arange(5000) // 4) % 2)).astype(np.int16)       # short streaks only: no sync point
         sq = np.where((np.arange(100000) // 700) % 2 == 0, 480, 620) + rs.randint(-3, 4, size=100000)
         reads[23] = sq.astype(np.int16)                                           # long in-range stretches, clean edges
+        sm = (520 + 8 * np.sin(np.arange(100000) / 37.0)); sm[::40] += 500         # in range but for every 40th sample:
+        reads[22] = np.rint(sm).astype(np.int16)                                  # a segment every 240 samples, NO sync point
         nz = rs.normal(520, 40, size=100000); nz[::7] += 400                      # every 7th sample an outlier
         reads[24] = np.clip(np.rint(nz), 0, 4000).astype(np.int16)
         for rna in (0, 1):
