@@ -28,7 +28,10 @@ namespace sgk {
 
 constexpr int SS_SPL = 16;            // consecutive terms per lane per tile
 constexpr int SS_TILE = 64 * SS_SPL;  // terms per tile
-constexpr int SS_HEAD = 256;          // leading terms of a read that are added natively: the surrogates of a lane have
+#ifndef SGK_SS_HEAD
+#define SGK_SS_HEAD 256
+#endif
+constexpr int SS_HEAD = SGK_SS_HEAD;          // leading terms of a read that are added natively: the surrogates of a lane have
                                       // room for SS_SPL terms only once the sum is well beyond 4 * SS_SPL terms, and
                                       // every one of the first terms would be a binade crossing
 
