@@ -16,11 +16,13 @@
 // segmented xor scan on two 64-bit scalar masks, each lane picks its increment, a DPP scan adds them up, and
 // S + total <= 2^24 certifies that the true sum never left the binade (all terms of the fast path are non-negative).
 // If it did, the first crossing lane runs its terms natively from its true start (S_l * u, exact) and the lanes behind
-// it repeat with the new binade: about log2(n / 64) repeats per read.  Tiles the argument does not cover (a negative
-// term, a term comparable to the sum, a zero / huge / tiny / non-finite sum) are added one term at a time, natively.
+// it repeat with the new binade: about log2(n / SS_HEAD) repeats per read and sum.  Tiles the argument does not cover (a
+// negative term, a term comparable to the sum, a zero / huge / tiny / non-finite sum) are added one term at a time,
+// natively, as are the first SS_HEAD terms of a read (the sum is still of the order of a term there).
 //
-// tools/proto/seqsum_proto.py is the numpy model of this file (same algorithm, checked against the plain loop);
-// tests/test_gpu_stat.py compares the kernels built on it with the oracle and with the lane-per-read kernels.
+// tools/proto/seqsum_proto.py is the numpy model of this file (same algorithm, checked against the plain loop by
+// tests/test_seqsum_model.py); tests/test_gpu_stat.py compares the kernels built on it with the oracle and with the
+// lane-per-read kernels, tests/test_gpu_shims.py runs the chains on hostile float arrays (sgk_meanf / sgk_stdvf).
 #pragma once
 #include "sgk_common.h"
 
