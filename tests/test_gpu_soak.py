@@ -60,3 +60,13 @@ def test_soak_regression_lane_local_rounding_in_the_flagged_pass(gpu, oracle):
             assert np.array_equal(g.mean.view(np.uint32), e.mean.view(np.uint32))
             assert np.array_equal(g.stdv.view(np.uint32), e.stdv.view(np.uint32))
             job.close()
+
+
+def test_short_wave_vs_lane_soak(gpu):
+    """a short run of tests/soak_wave_vs_lane.py: stat / jnn / prefix of the wave-per-read kernels against the
+    lane-per-read kernels on batches of 1 000 - 6 000 ragged reads (longer runs are recorded under profiles/)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_wave_vs_lane.py"), "--minutes", "0.3", "--seed", "9"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    stats = json.loads(p.stdout.strip().splitlines()[-1])
+    assert stats["mismatches"] == [] and stats["reads"] > 5000
