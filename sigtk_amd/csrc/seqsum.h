@@ -145,35 +145,51 @@ __device__ __forceinline__ unsigned long long ss_parity_in(int f0, int f1, int S
     return (out << 1) | (p0 & 1ull);               // parity before each lane
 }
 
-// The common case of a tile, tried first: no negative term, every surrogate stayed in its binade, and so did the sum.
-// ~20 vector instructions (+ the parity scan when some lane met a tie); anything else -> ss_finish.
-template <bool NEG>
-__device__ __forceinline__ bool ss_fast(float &m, const SsWalk &w) {
+// The common case of a tile, tried first: no negative term, every surrogate stayed in its binade, and so did the sum
+// (~20 vector instructions, + the parity scan when some lane met a tie): returns 0, m advanced.  If the sum leaves its
+// binade inside the tile, the crossing is taken here as well, with the increments and the scan already at hand: the
+// first lane whose end value lies beyond the binade's top adds its terms natively from its true start (S_l * u, exact),
+// m becomes the accumulator behind that lane, `skip` the number of lanes that are done, and ss_finish repeats the lanes
+// behind with the new binade (return 2; 0 if that lane was the last).  Anything else -> return 1: ss_finish from scratch.
+template <bool NEG, typename TF>
+__device__ __forceinline__ int ss_fast(float &m, const SsWalk &w, const TF &tf, int &skip) {
+    skip = 0;
     const uint32_t mb = ss_bits(ss_uniform(m));
     const uint32_t ex = (mb >> 23) & 0xffu;
-    if ((mb >> 31) || ex < 27u || ex > 227u) return false;
+    if ((mb >> 31) || ex < 27u || ex > 227u) return 1;
     const uint32_t b0 = (ex << 23) | 0x400000u, b1 = b0 + 1u;
     const uint32_t c0 = ss_bits(w.a0), c1 = ss_bits(w.a1);
     const int f0 = (int)(c0 - b0), f1 = (int)(c1 - b1);
     uint32_t bad = ((c0 ^ b0) | (c1 ^ b1)) >> 23;
     if (NEG) bad |= w.neg >> 31;
-    if (__any(bad != 0u)) return false;
+    if (__any(bad != 0u)) return 1;
     const int S = (int)((mb & 0x7fffffu) | 0x800000u);
     int f = f0;
     if (__any(f0 != f1)) f = __builtin_amdgcn_inverse_ballot_w64(ss_parity_in(f0, f1, S)) ? f1 : f0;
-    const int tot = wave_last_i(wave_incl_scan_i(f));
-    if (S + tot > (1 << 24)) return false;
-    m = (float)(S + tot) * ss_float((ex - 23u) << 23);
-    return true;
+    const int incl = wave_incl_scan_i(f);
+    const int tot = wave_last_i(incl);
+    const float u = ss_float((ex - 23u) << 23);
+    if (S + tot <= (1 << 24)) {
+        m = (float)(S + tot) * u;
+        return 0;
+    }
+    const int Sl = S + incl - f;
+    const unsigned long long cm = __ballot(Sl + f > (1 << 24));
+    const int ls = (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+    float v = (float)Sl * u;
+    ss_native_terms<0>(v, tf.with(ss_opaque_zero()));
+    m = ss_readlane(v, ls);
+    skip = ls + 1;
+    return skip >= 64 ? 0 : 2;
 }
 
 // One tile of a chain.  m: the accumulator (wave-uniform; the caller keeps it non-negative by orienting the terms);
 // w: ss_walk(m, ...) of the same tile (so that the walks of several chains can be issued together, ahead of the
 // branching below); NEG: the terms can be negative.  Returns the accumulator after the tile's 64 * SS_SPL terms.
 template <bool NEG, typename TF>
-__device__ inline float ss_finish(float m, const TF &tf0, SsWalk w, SsCount *cnt = nullptr) {
+__device__ inline float ss_finish(float m, const TF &tf0, SsWalk w, int skip = 0 /* lanes already done (ss_fast) */,
+                                  SsCount *cnt = nullptr) {
     const int lane = lane_id();
-    int skip = 0;  // lanes below `skip` are done
     if (cnt) ++cnt->generic;
     for (;;) {
         m = ss_uniform(m);

@@ -583,8 +583,11 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
         wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
     }
     if (ca) { ++ca->tiles; ++cb->tiles; }
-    if (!ss_fast<NEG>(ma, wa)) ma = ss_finish<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wa, ca);
-    if (!ss_fast<NEG>(mb, wb)) mb = ss_finish<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wb, cb);
+    int ska, skb;
+    if (ss_fast<NEG>(ma, wa, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), ska))
+        ma = ss_finish<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wa, ska, ca);
+    if (ss_fast<NEG>(mb, wb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), skb))
+        mb = ss_finish<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wb, skb, cb);
 }
 
 #ifndef SGK_STAT_WAVES
@@ -937,7 +940,9 @@ __device__ __forceinline__ void ss_tile1(float &m, const WaveRead &wr, const Wav
     SsWalk w;
     if (wr.interior(t)) w = ss_walk<NEG>(m, mk(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
     else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
-    if (!ss_fast<NEG>(m, w)) m = ss_finish<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), w);
+    int sk;
+    if (ss_fast<NEG>(m, w, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), sk))
+        m = ss_finish<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), w, sk);
 }
 
 constexpr int JW_BLOCK = 32;  // samples a lane takes per step of the chunked pass
@@ -1436,7 +1441,8 @@ __device__ float ss_chain_f32(const float *x, int n, F term) {
             for (int e = 0; e < SS_SPL; ++e) v[e] = (q0 + e < head) ? 0.0f : v[e];
         }
         const SsWalk w = ss_walk<true>(m, TermArr{v});
-        if (!ss_fast<true>(m, w)) m = ss_finish<true>(m, TermArr{v}, w);
+        int sk;
+        if (ss_fast<true>(m, w, TermArr{v}, sk)) m = ss_finish<true>(m, TermArr{v}, w, sk);
         if (m < 0.0f) { m = -m; sg = -sg; }
     }
     return m == 0.0f ? 0.0f : m * sg;
@@ -1824,7 +1830,8 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
             for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
         }
         const SsWalk w = ss_walk<false>(acc, TermArr{x});
-        if (!ss_fast<false>(acc, w)) acc = ss_finish<false>(acc, TermArr{x}, w);
+        int sk;
+        if (ss_fast<false>(acc, w, TermArr{x}, sk)) acc = ss_finish<false>(acc, TermArr{x}, w, sk);
     };
 
     const float mf = (float)(int)m;

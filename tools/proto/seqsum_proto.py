@@ -8,7 +8,8 @@ SURROGATE starts inside the same binade, 1.5*2^E (S even) and 1.5*2^E + ulp (S o
 difference of the float bit patterns is the lane's increment f_p for either incoming parity p.  The lanes' parity
 maps (constant / identity / negation) are composed with a segmented xor scan on 64-bit masks, the chosen increments
 are summed, and S + sum <= 2^24 certifies that the sum stayed inside the binade.  Otherwise the first crossing lane
-is located by a scan and runs its terms natively from its true start; the remaining lanes repeat with the new binade.
+is located by a scan and runs its terms natively from its true start; the remaining lanes repeat with the new binade
+(in the HIP code the first of these steps happens in ss_fast, the repeats in ss_finish).
 """
 import numpy as np
 
