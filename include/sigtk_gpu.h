@@ -106,30 +106,36 @@ typedef struct sgk_batch {
 int sgk_pa(const sgk_batch_t *batch, float *pa_out, void *stream);
 
 /* ---- event: Scrappie-derived event detection (src/events.c:553) ------------------ */
-/* Events of read r are written to slots ev_slots[r] .. ev_slots[r]+n_events[r]-1 of the
- * four SoA arrays (start = first raw sample, length in samples, mean/stdv in pA):
- * event_t of src/sigtk.h:55-62 as structure-of-arrays with integer start/length.
- * ev_slots (device, n_reads+1, increasing) is an INPUT describing the arena: read r may
- * use at most ev_slots[r+1]-ev_slots[r] slots.  sgk_event_slots_for() gives a capacity
- * that can never overflow (peaks are at least 3 samples apart).  If a read would
- * overflow, its surplus events are dropped, n_events[r] still holds the true count and
- * the status word reports it (sgk_event_status -> SGK_ERR_CAPACITY).
+/* One event = event_t of src/sigtk.h:55-62 with integer start / length (16 bytes). */
+typedef struct sgk_event_rec {
+    uint32_t start;   /* first raw sample of the event                       */
+    uint32_t length;  /* samples (event_t.length is this number as a float)  */
+    float mean;       /* pA                                                  */
+    float stdv;       /* pA                                                  */
+} sgk_event_rec_t;
+/* Events of read r are written to events[ev_slots[r] .. ev_slots[r]+n_events[r]-1] (16-byte aligned array of
+ * records).  ev_slots (device, n_reads+1, increasing) is an INPUT describing the arena: read r may use at most
+ * ev_slots[r+1]-ev_slots[r] slots, ALL of which are scratch during the call (the detector's wavefront lanes first
+ * write their boundary records chunk by chunk into the read's slot range, a per-event pass then compacts them in
+ * place): only the first n_events[r] entries are results afterwards.  sgk_event_slots_for() gives a capacity that
+ * can never overflow and that the fast path can work in (peaks are at least 3 samples apart; up to 64 chunks each
+ * round their share up).  A read with fewer slots than that is still processed (by the slower exact path): if it
+ * overflows, its surplus events are dropped, n_events[r] still holds the true count and the status word reports it
+ * (sgk_event_status -> SGK_ERR_CAPACITY).
  * Where the reference aborts or is undefined the library defines: a read with no peak
  * (incl. reads shorter than 2*window) yields one event [0,n); empty reads yield none. */
-static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 2; }
+static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 68; }
 
 size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 
-int sgk_event(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
-              uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *workspace,
-              size_t workspace_bytes, void *stream);
+int sgk_event(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events,
+              uint32_t *n_events, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same path fed with pA floats instead of raw int16 (drop-in for getevents(), whose input
  * is the pA array): pa is packed like `samples` (float per sample, 16-byte aligned). */
 int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
-                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
-                 uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *workspace,
-                 size_t workspace_bytes, void *stream);
+                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
+                 sgk_event_rec_t *events, uint32_t *n_events, void *workspace, size_t workspace_bytes, void *stream);
 
 typedef struct sgk_event_status {
     uint32_t n_fallback_reads;   /* reads re-done by the sequential-prefix exact path (no room around the read,

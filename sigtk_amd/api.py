@@ -108,6 +108,11 @@ ABI_SYMBOLS = [
 ]
 
 
+def event_slots_for(n):
+    """sgk_event_slots_for() of include/sigtk_gpu.h (a static inline there): arena slots of a read of n samples."""
+    return np.asarray(n, dtype=np.int64) // 3 + 68
+
+
 class Events(NamedTuple):
     start: np.ndarray   # uint32
     length: np.ndarray  # uint32
@@ -135,9 +140,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(L, f)
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32]
-    L.sgk_event.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+    L.sgk_event.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_pa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int] + \
-                              [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+                              [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

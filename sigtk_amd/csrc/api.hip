@@ -84,6 +84,7 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
 
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
 unsigned long long debug_exact_redo_count(bool reset);
+void debug_fp_counters(unsigned long long out[10], bool reset);
 int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
                  double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed, int kind,
                  hipStream_t st);
@@ -100,13 +101,11 @@ int check_batch(const sgk_batch_t *b) {
 static int run_event(const void *samples, bool float_input, const uint64_t *offsets, const uint32_t *lengths,
                      const double *dig, const double *off, const double *rng, uint32_t n_reads,
                      uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
-                     uint32_t *ev_start, uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events,
-                     void *ws, size_t ws_bytes, void *stream) {
+                     sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
     if (n_reads == 0) return SGK_OK;
-    if (!samples || !offsets || !lengths || !ev_slots || !ev_start || !ev_length || !ev_mean || !ev_stdv ||
-        !n_events || !ws)
-        return SGK_ERR_ARG;
+    if (!samples || !offsets || !lengths || !ev_slots || !events || !n_events || !ws) return SGK_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(samples) & 15u) return SGK_ERR_ALIGN;
+    if (reinterpret_cast<uintptr_t>(events) & 15u) return SGK_ERR_ALIGN;
     if (reinterpret_cast<uintptr_t>(ws) & 63u) return SGK_ERR_ALIGN;
     const EvWorkspace w = event_workspace_layout(n_reads, n_samples, max_read_len, ws_bytes);
     if (w.n_fb_blocks == 0 || w.total > ws_bytes) return SGK_ERR_WORKSPACE;
@@ -121,10 +120,7 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.n_reads = n_reads;
     a.n_alloc = n_samples;
     a.ev_slots = ev_slots;
-    a.ev_start = ev_start;
-    a.ev_length = ev_length;
-    a.ev_mean = ev_mean;
-    a.ev_stdv = ev_stdv;
+    a.events = events;
     a.n_events = n_events;
     a.hdr = reinterpret_cast<EvHeader *>(base + w.off_hdr);
     a.flags = reinterpret_cast<uint8_t *>(base + w.off_flags);
@@ -235,21 +231,19 @@ size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t 
     return event_workspace_layout(n_reads, n_samples, max_read_len, 0).total;
 }
 
-int sgk_event(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, uint32_t *ev_start, uint32_t *ev_length,
-              float *ev_mean, float *ev_stdv, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
+int sgk_event(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
+              void *ws, size_t ws_bytes, void *stream) {
     const int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     return run_event(b->samples, false, b->offsets, b->lengths, b->digitisation, b->offset, b->range, b->n_reads,
-                     b->max_read_len, b->n_samples, rna, ev_slots, ev_start, ev_length, ev_mean, ev_stdv, n_events,
-                     ws, ws_bytes, stream);
+                     b->max_read_len, b->n_samples, rna, ev_slots, events, n_events, ws, ws_bytes, stream);
 }
 
 int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
-                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots, uint32_t *ev_start,
-                 uint32_t *ev_length, float *ev_mean, float *ev_stdv, uint32_t *n_events, void *ws, size_t ws_bytes,
-                 void *stream) {
+                 uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
+                 sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
     return run_event(pa, true, offsets, lengths, nullptr, nullptr, nullptr, n_reads, max_read_len, n_samples, rna,
-                     ev_slots, ev_start, ev_length, ev_mean, ev_stdv, n_events, ws, ws_bytes, stream);
+                     ev_slots, events, n_events, ws, ws_bytes, stream);
 }
 
 int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
@@ -268,6 +262,18 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
 
 // diagnostics (not part of the stable ABI): t-statistic evaluations redone by the exact path
 unsigned long long sgk_debug_exact_redo_count(int reset) { return sgk::debug_exact_redo_count(reset != 0); }
+// library built with -DSGK_DIAG: decisions inside the uncertainty band / of those, taken on the reference expression
+void sgk_debug_fp_counters(unsigned long long out[10], int reset) { sgk::debug_fp_counters(out, reset != 0); }
+// why[0..4] of the last sgk_event on this workspace (event_args.h)
+int sgk_debug_event_why(const void *ws, uint32_t out[5], void *stream) {
+    if (!ws || !out) return SGK_ERR_ARG;
+    sgk::EvHeader h;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SGK_HIP_TRY(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, st));
+    SGK_HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 5; ++k) out[k] = h.why[k];
+    return SGK_OK;
+}
 
 // ---------------------------------------------------------------- synthetic reads
 int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
@@ -322,24 +328,21 @@ static int event_collect(const void *d_samples, bool float_input, const DeviceBa
     if (nr == 0) return SGK_OK;
     const std::vector<uint64_t> slots = make_slots(db.lengths, [](uint32_t n) { return sgk_event_slots_for(n); });
     const uint64_t nslots = slots[nr];
-    DevBuf d_slots, d_start, d_len, d_mean, d_sd, d_nev, d_ws;
+    DevBuf d_slots, d_ev, d_nev, d_ws;
     int rc;
     if ((rc = d_slots.alloc((nr + 1) * sizeof(uint64_t))) != SGK_OK) return rc;
-    if ((rc = d_start.alloc(nslots * 4)) != SGK_OK) return rc;
-    if ((rc = d_len.alloc(nslots * 4)) != SGK_OK) return rc;
-    if ((rc = d_mean.alloc(nslots * 4)) != SGK_OK) return rc;
-    if ((rc = d_sd.alloc(nslots * 4)) != SGK_OK) return rc;
+    if ((rc = d_ev.alloc(nslots * sizeof(sgk_event_rec_t))) != SGK_OK) return rc;
     if ((rc = d_nev.alloc((size_t)nr * 4)) != SGK_OK) return rc;
     const size_t wsb = sgk_event_workspace_bytes(nr, db.n_samples, db.max_len);
     if ((rc = d_ws.alloc(wsb)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (float_input)
         rc = sgk_event_pa(static_cast<const float *>(d_samples), view->offsets, view->lengths, nr, db.max_len,
-                          db.n_samples, rna, d_slots.as<uint64_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>(),
-                          d_mean.as<float>(), d_sd.as<float>(), d_nev.as<uint32_t>(), d_ws.p, wsb, nullptr);
+                          db.n_samples, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(),
+                          d_ws.p, wsb, nullptr);
     else
-        rc = sgk_event(view, rna, d_slots.as<uint64_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>(),
-                       d_mean.as<float>(), d_sd.as<float>(), d_nev.as<uint32_t>(), d_ws.p, wsb, nullptr);
+        rc = sgk_event(view, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(), d_ws.p, wsb,
+                       nullptr);
     if (rc != SGK_OK) return rc;
     rc = sgk_event_status(d_ws.p, &out->status, nullptr);
     if (rc != SGK_OK) return rc;
@@ -356,15 +359,21 @@ static int event_collect(const void *d_samples, bool float_input, const DeviceBa
     out->mean = (float *)malloc((tot ? tot : 1) * 4);
     out->stdv = (float *)malloc((tot ? tot : 1) * 4);
     if (!out->start || !out->length || !out->mean || !out->stdv) return SGK_ERR_NOMEM;
-    // one bulk copy per array (capacity layout), compacted on the host
-    std::vector<uint32_t> tmp((size_t)nslots ? (size_t)nslots : 1);
-    void *dev[4] = {d_start.p, d_len.p, d_mean.p, d_sd.p};
-    void *dst[4] = {out->start, out->length, out->mean, out->stdv};
-    for (int a = 0; a < 4; ++a) {
-        SGK_HIP_TRY(hipMemcpy(tmp.data(), dev[a], (size_t)nslots * 4, hipMemcpyDeviceToHost));
-        uint32_t *o = static_cast<uint32_t *>(dst[a]);
-        for (uint32_t r = 0; r < nr; ++r)
-            if (nev[r]) memcpy(o + out->ev_offsets[r], tmp.data() + slots[r], (size_t)nev[r] * 4);
+    // one bulk copy of the records (capacity layout), compacted and split into the four arrays on the host
+    std::vector<sgk_event_rec_t> tmp((size_t)nslots ? (size_t)nslots : 1);
+    SGK_HIP_TRY(hipMemcpy(tmp.data(), d_ev.p, (size_t)nslots * sizeof(sgk_event_rec_t), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < nr; ++r) {
+        // an overflowing read keeps what fitted
+        const uint64_t cap = slots[r + 1] - slots[r];
+        const uint64_t k = nev[r] < cap ? nev[r] : cap;
+        const sgk_event_rec_t *src = tmp.data() + slots[r];
+        const uint64_t o = out->ev_offsets[r];
+        for (uint64_t i = 0; i < k; ++i) {
+            out->start[o + i] = src[i].start;
+            out->length[o + i] = src[i].length;
+            out->mean[o + i] = src[i].mean;
+            out->stdv[o + i] = src[i].stdv;
+        }
     }
     return SGK_OK;
 }

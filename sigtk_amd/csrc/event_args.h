@@ -11,7 +11,9 @@ struct EvHeader {
     uint32_t fb_next;     // work counter of the persistent fallback kernel
     unsigned long long n_events_total;
     uint32_t n_hot_runs;  // lanes that replayed long-detector runs exactly (lazy long detector)
-    uint32_t pad[9];
+    uint32_t why[5];      // diagnostics, reads handed to the fallback: [1] no room / alignment / slots, [2] too many hot
+                          // runs, [3] the long detector emits, [4] exactness guard
+    uint32_t pad[4];
 };
 static_assert(sizeof(EvHeader) == 64, "header is one 64-byte block");
 
@@ -23,8 +25,7 @@ struct EvArgs {
     uint32_t n_reads;
     uint64_t n_alloc;               // readable samples: the batch's n_samples
     const uint64_t *ev_slots;
-    uint32_t *ev_start, *ev_length;
-    float *ev_mean, *ev_stdv;
+    sgk_event_rec_t *events;        // 16-byte records; slots of read r: [ev_slots[r], ev_slots[r+1])
     uint32_t *n_events;
     // workspace
     EvHeader *hdr;

@@ -1164,258 +1164,15 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
     const float dsq = (float)dsumsq;
     const float var = dsq / len - m * m;
     const float sd = sqrtf(fmaxf(var, 0.0f));
-    a.ev_start[slot0 + k] = ps;
-    a.ev_length[slot0 + k] = pe - ps;
-    a.ev_mean[slot0 + k] = m;
-    a.ev_stdv[slot0 + k] = sd;
+    sgk_event_rec_t e;
+    e.start = ps;
+    e.length = pe - ps;
+    e.mean = m;
+    e.stdv = sd;
+    a.events[slot0 + k] = e;
 }
 
-constexpr int BT = 32;      // samples per lane per builder tile: 64 bytes of int16, one 32-bit bitmap word
-// create_event (events.c:457-473) for the fast builder: the two divisions by the event length share one refined
-// reciprocal (tstat_math.h: bit-identical to `/` inside the range guard); SoA stores through per-read base pointers.
-struct EvOut {
-    uint32_t *start, *length;
-    float *mean, *stdv;
-    uint32_t cap;
-};
-__device__ __forceinline__ void store_event_fast(const EvOut &o, uint32_t k, uint32_t ps, uint32_t pe, double dsum,
-                                                 double dsumsq, bool &overflow) {
-    if (k >= o.cap) { overflow = true; return; }
-    const float len = (float)(pe - ps);
-    const float r1 = sgk_refined_rcp(len);
-    const float m = sgk_div_with_rcp((float)dsum, len, r1);
-    const float var = sgk_div_with_rcp((float)dsumsq, len, r1) - m * m;
-    const float sd = sqrtf(fmaxf(var, 0.0f));
-    o.start[k] = ps;
-    o.length[k] = pe - ps;
-    o.mean[k] = m;
-    o.stdv[k] = sd;
-}
-
-#ifndef SGK_BREC
-#define SGK_BREC 576
-#endif
-// Boundary records per tile in LDS: {S, S2} as one 16-byte record + a 16-bit tile-relative position (10.6 KB per
-// wave with the lane prefixes).  The detector can emit a boundary every 3 samples (683 per tile), but sizing LDS for
-// that costs occupancy; a tile with more than BREC boundaries (events shorter than 3.6 samples on average over 2048
-// samples: never seen on nanopore data, sp1 peaks at 425) sends its read to k_event_fallback instead.
-constexpr int BREC = SGK_BREC;
-struct __attribute__((aligned(16))) BuildRec {
-    double S, S2;
-};
-struct BuildLds {
-    BuildRec rec[BREC];
-    double pt[64];
-    double pt2[64];
-    uint16_t p[BREC];  // tile-relative sample index of the boundary
-};
-static_assert(sizeof(BuildLds) <= 11776, "builder LDS budget: 13 waves per CU");
-
-// min non-zero |x| / max |x| of a read from the extremes of its raw samples (x = (raw + off) * unit is monotone in
-// raw); returns false when the read crosses or touches zero pA (the smallest non-zero magnitude is then not known
-// from the extremes; such reads fail the guard anyway: it tolerates a ratio of ~64 between the magnitudes)
-__device__ inline bool raw_extremes_to_pa(int rmin, int rmax, const Scale &sc, float &mn, float &mx) {
-    const float a = ((float)rmin + sc.offf), b = ((float)rmax + sc.offf);
-    const float xa = fabsf(a * sc.unit), xb = fabsf(b * sc.unit);
-    mn = fminf(xa, xb);
-    mx = fmaxf(xa, xb);
-    const bool same_sign = (a > 0.0f && b > 0.0f) || (a < 0.0f && b < 0.0f);
-    return same_sign && mn > 0.0f && mx < __builtin_inff();
-}
-
-typedef short sgk_s2 __attribute__((ext_vector_type(2)));
-
-// One lane's walk over its 32 samples of a tile: lane-relative double prefix sums, one record per boundary bit.
-// FULL: every sample of the tile is inside the read (no per-sample validity select).
-template <typename T, bool FULL>
-__device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, int nvalid, const Scale &sc, int l,
-                                           int excl, BuildLds *L, double &S, double &S2, uint32_t &mnb,
-                                           uint32_t &mxb) {
-    char *rr = reinterpret_cast<char *>(L->rec) + excl * 16;
-    char *rp = reinterpret_cast<char *>(L->p) + excl * 2;
-#pragma unroll
-    for (int k = 0; k < BT; ++k) {
-        float x = to_pa(buf[k], sc);
-        if (!FULL && k >= nvalid) x = 0.0f;
-        const float xq = x * x;
-        if constexpr (std::is_same<T, float>::value) {
-            // pA input: the guard's extremes are tracked on the bit patterns (non-negative floats order like
-            // unsigned integers; zero - 1 wraps to the top, so it never wins the minimum; inf / nan end up above
-            // every finite value and fail the guard)
-            const uint32_t ab = __float_as_uint(x) & 0x7fffffffu;
-            mxb = ab > mxb ? ab : mxb;
-            mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
-        }
-        if ((bits >> k) & 1u) {
-            BuildRec rc;
-            rc.S = S;
-            rc.S2 = S2;
-            *reinterpret_cast<BuildRec *>(rr) = rc;
-            *reinterpret_cast<uint16_t *>(rp) = (uint16_t)(l * BT + k);
-            rr += 16;
-            rp += 2;
-        }
-        S = S + (double)x;
-        S2 = S2 + (double)xq;
-    }
-}
-
-template <typename T>
-__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined) {
-    const int64_t n = rc.n;
-    const int l = lane_id();
-    const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
-    if (n <= 0) {
-        if (l == 0) { a.n_events[r] = 0; a.flags[r] = 0; }
-        return;
-    }
-    const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
-    EvOut eo;
-    eo.start = a.ev_start + slot0;
-    eo.length = a.ev_length + slot0;
-    eo.mean = a.ev_mean + slot0;
-    eo.stdv = a.ev_stdv + slot0;
-    eo.cap = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
-    bool overflow = false, dense = false;
-    uint32_t rank = 0, prevp = 0;
-    double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary, relative to the current tile start
-    // exactness guard inputs: int16 reads track the extremes of the RAW samples (packed 16-bit min / max, two samples
-    // per instruction); pA reads the extremes of the float bit patterns
-    uint32_t mnb = 0xffffffffu, mxb = 0u;
-    sgk_s2 rmin2 = {32767, 32767}, rmax2 = {-32768, -32768};
-    constexpr int NV = BT * (int)sizeof(T) / 16;
-    // tile loader: this lane's 32 samples and its 32 bitmap bits.  The next tile is fetched while the
-    // current one is processed (register double buffer).
-    auto load_tile = [&](int64_t tb, T (&buf)[BT], uint32_t &bits, int &nvalid) {
-        const int64_t pos0 = tb + (int64_t)l * BT;
-        bits = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
-        const int64_t rem = n - pos0;
-        nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
-        if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
-        if (pos0 >= n) {
-            // lanes behind the read's end (every read's last tile has some): nothing to load
-#pragma unroll
-            for (int k = 0; k < BT; ++k) buf[k] = (T)0;
-        } else if (rc.vec_ok && pos0 + BT <= rc.hi) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(rc.base + pos0);
-            uint4 v[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] = src[k];
-            __builtin_memcpy(buf, v, sizeof(buf));
-        } else {
-#pragma unroll
-            for (int k = 0; k < BT; ++k) buf[k] = (k < nvalid) ? rc.base[pos0 + k] : (T)0;
-        }
-    };
-    T nbuf[BT];
-    uint32_t nbits;
-    int nnvalid;
-    load_tile(0, nbuf, nbits, nnvalid);
-    for (int64_t tb = 0; tb < n; tb += 64 * BT) {
-        T buf[BT];
-#pragma unroll
-        for (int k = 0; k < BT; ++k) buf[k] = nbuf[k];
-        const uint32_t bits = nbits;
-        const int nvalid = nnvalid;
-        if (tb + 64 * BT < n) load_tile(tb + 64 * BT, nbuf, nbits, nnvalid);
-        const int cnt = __popc(bits);
-        const int incl = wave_incl_scan_i(cnt);
-        const int excl = incl - cnt;
-        const int total = wave_last_i(incl);
-        const bool full = tb + 64 * BT <= n;
-        if constexpr (std::is_same<T, int16_t>::value) {
-            // raw extremes (samples behind the read's end repeat a valid one)
-            sgk_s2 w[BT / 2];
-            __builtin_memcpy(w, buf, sizeof(w));
-            if (!full) {
-                const sgk_s2 first = {(short)rc.base[0], (short)rc.base[0]};
-#pragma unroll
-                for (int k = 0; k < BT / 2; ++k) {
-                    if (2 * k + 1 >= nvalid) w[k] = (2 * k >= nvalid) ? first : sgk_s2{w[k].x, w[k].x};
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < BT / 2; ++k) {
-                rmin2 = __builtin_elementwise_min(rmin2, w[k]);
-                rmax2 = __builtin_elementwise_max(rmax2, w[k]);
-            }
-        }
-        // walk: lane-relative prefix sums, boundary records.  A tile with more than BREC boundaries is not recorded:
-        // its read is redone by the fallback.
-        double S = 0.0, S2 = 0.0;
-        if (total > BREC) dense = true;
-        const uint32_t wbits = total > BREC ? 0u : bits;
-        if (full) build_walk<T, true>(buf, wbits, nvalid, rc.sc, l, excl, L, S, S2, mnb, mxb);
-        else build_walk<T, false>(buf, wbits, nvalid, rc.sc, l, excl, L, S, S2, mnb, mxb);
-        const double inS = wave_incl_scan_d(S), inS2 = wave_incl_scan_d(S2);
-        L->pt[l] = inS - S;
-        L->pt2[l] = inS2 - S2;
-        const double tileS = wave_last_d(inS), tileS2 = wave_last_d(inS2);
-        __syncthreads();
-        const int tot = total > BREC ? 0 : total;
-        // one event per lane per round.  Prefix sums are kept relative to the tile start (exact under the guard, so
-        // no absolute base is needed); the previous boundary of lane l is lane l-1's record, lane 0 takes the
-        // carry: the last record of the previous round / tile.
-        for (int k0 = 0; k0 < tot; k0 += 64) {
-            const int k = k0 + l;
-            const bool act = k < tot;
-            const int kk = act ? k : tot - 1;
-            const uint32_t pr = L->p[kk], p = (uint32_t)tb + pr;
-            const int ln = (int)(pr / BT);
-            const BuildRec rcd = L->rec[kk];
-            const double G = L->pt[ln] + rcd.S;
-            const double G2 = L->pt2[ln] + rcd.S2;
-            const uint32_t pp = (uint32_t)wave_shr1_i((int)p, (int)prevp);
-            const double Gp = wave_shr1_d(G, Gprev), G2p = wave_shr1_d(G2, G2prev);
-            if (act) store_event_fast(eo, rank + (uint32_t)k, pp, p, G - Gp, G2 - G2p, overflow);
-            const int last = (tot - k0) < 64 ? (tot - k0 - 1) : 63;  // wave-uniform
-            prevp = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
-            Gprev = readlane_d(G, last);
-            G2prev = readlane_d(G2, last);
-        }
-        rank += (uint32_t)tot;
-        // rebase the carry to the next tile's start
-        Gprev = Gprev - tileS;
-        G2prev = G2prev - tileS2;
-        __syncthreads();
-    }
-    // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
-    float mn, mx;
-    bool known = true;
-    if constexpr (std::is_same<T, int16_t>::value) {
-        int rmn = rmin2.x < rmin2.y ? rmin2.x : rmin2.y, rmxv = rmax2.x > rmax2.y ? rmax2.x : rmax2.y;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int o1 = __shfl_xor(rmn, d, 64), o2 = __shfl_xor(rmxv, d, 64);
-            rmn = o1 < rmn ? o1 : rmn;
-            rmxv = o2 > rmxv ? o2 : rmxv;
-        }
-        known = raw_extremes_to_pa(rmn, rmxv, rc.sc, mn, mx);
-    } else {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o1 = (uint32_t)__shfl_xor((int)mnb, d, 64), o2 = (uint32_t)__shfl_xor((int)mxb, d, 64);
-            mnb = o1 < mnb ? o1 : mnb;
-            mxb = o2 > mxb ? o2 : mxb;
-        }
-        mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
-        mx = __uint_as_float(mxb);
-        known = mxb < 0x7f800000u;
-    }
-    const bool flagged = dense || !known || !guard_ok(mn, mx, n) || declined;
-    if (l == 0) {
-        a.flags[r] = flagged ? 1 : 0;
-        if (flagged) {
-            const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
-            a.flag_list[k] = r;
-        } else {
-            store_event_fast(eo, rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
-            a.n_events[r] = rank + 1;
-            atomicAdd(&a.hdr->n_events_total, (unsigned long long)(rank + 1));
-        }
-    }
-    if (!flagged && __any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
-}
+#include "event_fast.h"
 
 // fallback builder: event sums are differences of the sequential prefix arrays, as in the reference
 template <typename T>
@@ -1551,52 +1308,83 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 // ---------------------------------------------------------------- kernels
 
-// DNA preset: 168 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): 242 VGPRs -> 2
-template <int W1, typename T>
+// DNA preset: 3 waves per SIMD; RNA preset (deeper rings): 2
 #ifndef SGK_DET_WAVES_DNA
 #define SGK_DET_WAVES_DNA 3
 #endif
 #ifndef SGK_DET_WAVES_RNA
 #define SGK_DET_WAVES_RNA 2
 #endif
-__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_detect(EvArgs a) {
-    __shared__ LzLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L, nullptr);
-    if (lane_id() == 0) a.flags[r] = rcode ? 2 : 0;  // 2: declined by the fast pass -> exact fallback
+// exactness guard of the fast path: guard_ok (exact double sums in any order, no subnormal intermediates) and a
+// magnitude ratio of at most 2^16 within the read (sgk_a3's constant division, tstat_math.h)
+__device__ inline bool guard_ok_fast(float mn, float mx, int64_t n) {
+    if (!guard_ok(mn, mx, n)) return false;
+    if (!(mx > 0.0f)) return true;
+    return ilogbf(mx) - ilogbf(mn) <= 16;
 }
 
-template <typename T>
-__global__ __launch_bounds__(64, 3) void k_event_build(EvArgs a) {
-    __shared__ BuildLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    build_read<T>(a, rc, r, &L, a.flags[r] == 2);
-}
-
-// Detector and builder of one read in one wave, back to back (SGK_EVENT_FUSED, the default): the builder's phases
-// that wait on memory (sample tiles, event stores) run under other waves' detector arithmetic instead of in a
-// kernel of their own.  The bitmap goes through memory (L2) between the two phases of the same wave.
-union EventLds {
-    LzLds lz;
-    BuildLds b;
-};
+// One wavefront per read: the fast pass (boundary records into the read's event slots), the exactness guard on the
+// extremes of the samples that passed through the lanes, the per-event finish.
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
-    __shared__ EventLds L;
+    __shared__ FpLds<W1> L;
     // reads are taken longest first (launch_order): a kernel cannot end before its longest read has, so that one
     // should start first, not wherever it sits in the batch
     const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L.lz, nullptr);
-    // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
-    // them back.  Workgroup scope: the wave's own CU only -- an agent-scope release / acquire pair here writes back and
-    // invalidates L2 once per read, which made 5 000-sample reads 1.7x slower than with two kernels.
+    const int l = lane_id();
+    if (rc.n <= 0) {
+        if (l == 0) { a.n_events[r] = 0; a.flags[r] = 0; }
+        return;
+    }
+    FpExt<T> ext;
+    ext.init();
+    int K = 16;
+    const int rcode = detect_read_fast<W1, T>(a, rc, r, &L, ext, K);
+    // exactness guard (see the file header): reads that fail it are redone by k_event_fallback
+    float mn, mx;
+    bool known = true;
+    if constexpr (std::is_same<T, int16_t>::value) {
+        int rmn = ext.mn.x < ext.mn.y ? ext.mn.x : ext.mn.y, rmxv = ext.mx.x > ext.mx.y ? ext.mx.x : ext.mx.y;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o1 = __shfl_xor(rmn, d, 64), o2 = __shfl_xor(rmxv, d, 64);
+            rmn = o1 < rmn ? o1 : rmn;
+            rmxv = o2 > rmxv ? o2 : rmxv;
+        }
+        known = rmn <= rmxv && raw_extremes_to_pa(rmn, rmxv, rc.sc, mn, mx);
+    } else {
+        uint32_t mnb = ext.mnb, mxb = ext.mxb;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)mnb, d, 64), o2 = (uint32_t)__shfl_xor((int)mxb, d, 64);
+            mnb = o1 < mnb ? o1 : mnb;
+            mxb = o2 > mxb ? o2 : mxb;
+        }
+        mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
+        mx = __uint_as_float(mxb);
+        known = mxb < 0x7f800000u;
+    }
+    const bool flagged = rcode != 0 || !known || !guard_ok_fast(mn, mx, rc.n);
+    if (flagged) {
+        if (l == 0) {
+            a.flags[r] = 1;
+            const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
+            a.flag_list[k] = r;
+            atomicAdd(&a.hdr->why[rcode ? rcode : 4], 1u);  // diagnostics: why the fast path handed the read over
+        }
+        return;
+    }
+    // every lane's records are in memory before any lane of this wave reads them.  Workgroup scope (the wave's own CU):
+    // the record lines were only ever WRITTEN by this kernel before this point, so no stale copy of them can sit in
+    // the CU's vector cache, and an agent-scope release / acquire pair would write back and invalidate L2 per read.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    build_read<T>(a, rc, r, &L.b, rcode != 0);
+#ifndef SGK_EXP_NO_FINISH
+    finish_read<W1, T>(a, rc, r, &L, K);
+#endif
+    if (l == 0) a.flags[r] = 0;
 }
 
 template <int W1, typename T>
@@ -1640,18 +1428,11 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 
 // ---------------------------------------------------------------- launcher
 
-#ifndef SGK_EVENT_FUSED
-#define SGK_EVENT_FUSED 1
-#endif
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
     if (a.n_reads == 0) return SGK_OK;
-    // (Tried in round 1: cutting the batch into read slices and running the builder of slice s on a side
-    // stream under the detector of slice s+1.  Both kernels contend for VALU issue and the detector needs
-    // >= 3072 reads in flight to fill its 12 waves/CU, so the overlapped step was 8.8 ms against 7.8 ms.)
     ProfScope whole("path:event", st);
     SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
-#if SGK_EVENT_FUSED
     EvArgs ao = a;
     if (a.n_reads >= ORDER_MIN_READS && a.order) {
         const int rc = launch_order(a.lengths, a.n_reads, a.order, a.order + a.n_reads, st);
@@ -1663,19 +1444,6 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
-#else
-    {
-        ProfScope ps("k_event_detect", st);
-        if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_event_detect<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
-    {
-        ProfScope ps("k_event_build", st);
-        hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
-#endif
     {
         ProfScope ps("k_event_fallback", st);
         if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);
@@ -1683,6 +1451,17 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
+}
+
+void debug_fp_counters(unsigned long long out[10], bool reset) {
+    for (int k = 0; k < 10; ++k) out[k] = 0;
+    (void)hipMemcpyFromSymbol(&out[0], HIP_SYMBOL(g_fp_calls), sizeof(unsigned long long));
+    (void)hipMemcpyFromSymbol(&out[1], HIP_SYMBOL(g_fp_resolved), sizeof(unsigned long long));
+    if (reset) {
+        const unsigned long long z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fp_calls), &z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fp_resolved), &z, sizeof z);
+    }
 }
 
 unsigned long long debug_exact_redo_count(bool reset) {

@@ -288,6 +288,25 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, int narr, const ui
         for (uint32_t i = threadIdx.x; i < c; i += 256) g.dst[k][d + i] = g.src[k][s + i];
 }
 
+// events of read r: records src[slots[r] .. +counts[r]) -> the four dense arrays dst[k][doffs[r] ..), k < narr
+// (start, length, mean, stdv as 4-byte items; narr = 2 for `event -c`, which prints lengths only)
+__global__ __launch_bounds__(256) void k_gather_events(const sgk_event_rec_t *src, GatherArgs g, int narr,
+                                                       const uint64_t *slots, const uint32_t *counts,
+                                                       const uint64_t *doffs) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t s = slots[r], d = doffs[r], cap = slots[r + 1] - s;
+    const uint32_t c = counts[r] < cap ? counts[r] : (uint32_t)cap;  // an overflowing read keeps what fitted
+    for (uint32_t i = threadIdx.x; i < c; i += 256) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + s + i);
+        g.dst[0][d + i] = v.x;
+        g.dst[1][d + i] = v.y;
+        if (narr > 2) {
+            g.dst[2][d + i] = v.z;
+            g.dst[3][d + i] = v.w;
+        }
+    }
+}
+
 int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
     if (!j || !j->begun || j->submitted) return SGK_ERR_ARG;
     if (tool < SGK_TOOL_PA || tool > SGK_TOOL_ENT) return SGK_ERR_ARG;
@@ -326,22 +345,25 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             slots[nr] = s;
             if ((rc = h2d(j->d_slots, j->h_slots, (nr + 1) * 8, st)) != SGK_OK) return rc;
             const int narr = ev ? 4 : 2;
-            for (int k = 0; k < narr; ++k)
-                if ((rc = j->d_out[k].ensure(s * 4)) != SGK_OK) return rc;
+            if (ev) {
+                if ((rc = j->d_out[0].ensure(s * sizeof(sgk_event_rec_t))) != SGK_OK) return rc;
+            } else {
+                for (int k = 0; k < narr; ++k)
+                    if ((rc = j->d_out[k].ensure(s * 4)) != SGK_OK) return rc;
+            }
             if ((rc = j->d_cnt.ensure(nr * 4)) != SGK_OK) return rc;
             j->ws_bytes = ev ? sgk_event_workspace_bytes(j->n_reads, j->n_samples, j->max_len)
                              : sgk_jnn_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
             if (ev)
-                rc = sgk_event(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<uint32_t>(),
-                               j->d_out[1].as<uint32_t>(), j->d_out[2].as<float>(), j->d_out[3].as<float>(),
+                rc = sgk_event(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<sgk_event_rec_t>(),
                                j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
             else
                 rc = sgk_jnn(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<int32_t>(),
                              j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
             if (rc != SGK_OK) return rc;
             if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
-            // the arena is capacity-sized (n/3+2 slots per read): gather what was produced into dense ranges on the
+            // the arena is capacity-sized (sgk_event_slots_for(n) slots per read): gather what was produced into dense ranges on the
             // device and download only that (sgk_job_wait fetches the arrays once the total is known)
             const int ncopy = (ev && (flags & SGK_JOB_EVENTS_COMPACT)) ? 2 : narr;
             if ((rc = j->d_doffs.ensure((nr + 1) * 8)) != SGK_OK) return rc;
@@ -352,11 +374,15 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             for (int k = 0; k < 4; ++k) { g.src[k] = nullptr; g.dst[k] = nullptr; }
             for (int k = 0; k < ncopy; ++k) {
                 if ((rc = j->d_dense[k].ensure(s * 4)) != SGK_OK) return rc;
-                g.src[k] = j->d_out[k].as<uint32_t>();
+                g.src[k] = ev ? nullptr : j->d_out[k].as<uint32_t>();
                 g.dst[k] = j->d_dense[k].as<uint32_t>();
             }
-            hipLaunchKernelGGL(k_gather, dim3(j->n_reads), dim3(256), 0, st, g, ncopy, j->d_slots.as<uint64_t>(),
-                               j->d_cnt.as<uint32_t>(), j->d_doffs.as<uint64_t>());
+            if (ev)
+                hipLaunchKernelGGL(k_gather_events, dim3(j->n_reads), dim3(256), 0, st, j->d_out[0].as<sgk_event_rec_t>(),
+                                   g, ncopy, j->d_slots.as<uint64_t>(), j->d_cnt.as<uint32_t>(), j->d_doffs.as<uint64_t>());
+            else
+                hipLaunchKernelGGL(k_gather, dim3(j->n_reads), dim3(256), 0, st, g, ncopy, j->d_slots.as<uint64_t>(),
+                                   j->d_cnt.as<uint32_t>(), j->d_doffs.as<uint64_t>());
             SGK_HIP_TRY(hipGetLastError());
             if ((rc = d2h(j->h_doffs, j->d_doffs, (nr + 1) * 8, st)) != SGK_OK) return rc;
             if (!ev) {  // sgk_jnn counts the reads whose segments overflowed their slots in the workspace's first word

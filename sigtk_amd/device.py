@@ -101,14 +101,13 @@ class EventArena:
         L = api.load_library()
         dev = b.samples.device
         slots = np.zeros(b.n_reads + 1, dtype=np.int64)
-        np.cumsum(b.lengths_host.astype(np.int64) // 3 + 2, out=slots[1:])
+        np.cumsum(api.event_slots_for(b.lengths_host), out=slots[1:])
         self.slots_host = slots
         self.n_slots = int(slots[-1])
         self.slots = torch.from_numpy(slots).to(dev)
-        self.start = torch.empty(max(self.n_slots, 1), dtype=torch.int32, device=dev)
-        self.length = torch.empty(max(self.n_slots, 1), dtype=torch.int32, device=dev)
-        self.mean = torch.empty(max(self.n_slots, 1), dtype=torch.float32, device=dev)
-        self.stdv = torch.empty(max(self.n_slots, 1), dtype=torch.float32, device=dev)
+        # sgk_event_rec_t[n_slots]: (start u32, length u32, mean f32, stdv f32) per slot
+        self.events = torch.empty((max(self.n_slots, 1), 4), dtype=torch.int32, device=dev)
+        assert self.events.data_ptr() % 16 == 0
         self.n_events = torch.zeros(max(b.n_reads, 1), dtype=torch.int32, device=dev)
         self.ws_bytes = int(L.sgk_event_workspace_bytes(b.n_reads, b.n_samples, b.max_read_len))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
@@ -125,18 +124,34 @@ class EventArena:
     def read_events(self, r: int) -> api.Events:
         k = int(self.n_events[r].item())
         s = int(self.slots_host[r])
-        return api.Events(self.start[s:s + k].cpu().numpy().view(np.uint32),
-                          self.length[s:s + k].cpu().numpy().view(np.uint32),
-                          self.mean[s:s + k].cpu().numpy(), self.stdv[s:s + k].cpu().numpy())
+        rec = self.events[s:s + k].cpu().numpy()
+        return api.Events(rec[:, 0].copy().view(np.uint32), rec[:, 1].copy().view(np.uint32),
+                          rec[:, 2].copy().view(np.float32), rec[:, 3].copy().view(np.float32))
+
+    # column views of the record array (device tensors; mean / stdv as float32)
+    @property
+    def start(self) -> torch.Tensor:
+        return self.events[:, 0]
+
+    @property
+    def length(self) -> torch.Tensor:
+        return self.events[:, 1]
+
+    @property
+    def mean(self) -> torch.Tensor:
+        return self.events.view(torch.float32)[:, 2]
+
+    @property
+    def stdv(self) -> torch.Tensor:
+        return self.events.view(torch.float32)[:, 3]
 
 
 def event(b: DeviceReads, arena: EventArena, rna: int) -> None:
     """Enqueue one pass of the event path over the batch on the current stream (async)."""
     L = api.load_library()
     view = b.view()
-    api.check(L.sgk_event(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.start), _ptr(arena.length),
-                          _ptr(arena.mean), _ptr(arena.stdv), _ptr(arena.n_events), _ptr(arena.ws),
-                          arena.ws_bytes, _stream_ptr()), "sgk_event")
+    api.check(L.sgk_event(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.events), _ptr(arena.n_events),
+                          _ptr(arena.ws), arena.ws_bytes, _stream_ptr()), "sgk_event")
 
 
 # ---------------------------------------------------------------------- stat / jnn / prefix / pa (device API)

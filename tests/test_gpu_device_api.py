@@ -20,7 +20,7 @@ STALE = np.array([4096, 961, 31966, 0, -8192, -12610, 31957, 0, 16, 0, 0, 0, 0, 
                   0, 512, 0, 9, 0, 13, 0, 0, -26880, 31957, 0] + [0] * 32, dtype=np.int16)
 
 
-def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n: n // 3 + 2, gap_fill=None):
+def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=None, gap_fill=None):
     """Place reads at the given sample offsets of one buffer and run sgk_event through the device API."""
     torch = _torch()
     from sigtk_amd import device
@@ -48,7 +48,7 @@ def _run_layout(gpu, oracle, reads, offsets, n_samples, rna, slots_for=lambda n:
         arena.slots = torch.from_numpy(slots).to(dev)
     if gap_fill is not None:  # nothing may depend on what the workspace or the output arena held before
         arena.ws.fill_(0xA5)
-        arena.start.fill_(-1); arena.length.fill_(-1); arena.n_events.fill_(-1)
+        arena.events.fill_(-1); arena.n_events.fill_(-1)
     device.event(b, arena, rna)
     torch.cuda.synchronize()
     return b, arena
