@@ -115,16 +115,12 @@ typedef struct sgk_event_rec {
 } sgk_event_rec_t;
 /* Events of read r are written to events[ev_slots[r] .. ev_slots[r]+n_events[r]-1] (16-byte aligned array of
  * records).  ev_slots (device, n_reads+1, increasing) is an INPUT describing the arena: read r may use at most
- * ev_slots[r+1]-ev_slots[r] slots, ALL of which are scratch during the call (the detector's wavefront lanes first
- * write their boundary records chunk by chunk into the read's slot range, a per-event pass then compacts them in
- * place): only the first n_events[r] entries are results afterwards.  sgk_event_slots_for() gives a capacity that
- * can never overflow and that the fast path can work in (peaks are at least 3 samples apart; up to 64 chunks each
- * round their share up).  A read with fewer slots than that is still processed (by the slower exact path): if it
- * overflows, its surplus events are dropped, n_events[r] still holds the true count and the status word reports it
- * (sgk_event_status -> SGK_ERR_CAPACITY).
+ * ev_slots[r+1]-ev_slots[r] slots.  sgk_event_slots_for() gives a capacity that can never overflow (peaks are at
+ * least 3 samples apart).  If a read would overflow, its surplus events are dropped, n_events[r] still holds the
+ * true count and the status word reports it (sgk_event_status -> SGK_ERR_CAPACITY).
  * Where the reference aborts or is undefined the library defines: a read with no peak
  * (incl. reads shorter than 2*window) yields one event [0,n); empty reads yield none. */
-static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 68; }
+static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 2; }
 
 size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 

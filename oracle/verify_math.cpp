@@ -50,6 +50,7 @@ static inline float perturbed_rcp32(float v) {
 }
 #define SGK_RCP32(v) perturbed_rcp32(v)
 #include "../sigtk_amd/csrc/tstat_math.h"
+#include "../tools/proto/event_r3/tstat_math_r3.h"   // round-3 experiment (not in the product): checks #10..#12
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -306,7 +307,8 @@ static uint64_t check_div_len(uint64_t count) {
 
 
 // ---------------------------------------------------------------- round 3 ("robust decisions", tstat_math.h)
-// 9. the A-side mean: (float)(S * RN64(1/W)) == (float)(S / (double)W) for exact sums of W floats spanning <= 2^16
+// 9. the A-side mean (sgk_arole<W, SHORT = true>): (float)(S * RN64(1/W)) == (float)(S / (double)W) for exact sums of W
+//    floats spanning <= 2^16
 template <int W>
 static uint64_t check_mean1(uint64_t count) {
     uint64_t bad = 0;
@@ -326,9 +328,10 @@ static uint64_t check_mean1(uint64_t count) {
                 S += (double)f;
                 Sq += (double)(f * f);
             }
-            const SgkA3 a = sgk_a3<W>(S, Sq);
+            const SgkARole a = sgk_arole<W, true>(S, Sq);   // the product's form (event_kernels.hip: LazyPass, fast path)
+            const SgkA3 a3 = sgk_a3<W>(S, Sq);               // the round-3 experiment's
             const float want = (float)(S / (double)(float)W);
-            if (f2u(a.mean1) != f2u(want)) bad++;
+            if (f2u(a.mean1) != f2u(want) || f2u(a3.mean1) != f2u(want)) bad++;
         }
     }
     return bad;

@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
 
 def event_slots_for(n):
     """sgk_event_slots_for() of include/sigtk_gpu.h (a static inline there): arena slots of a read of n samples."""
-    return np.asarray(n, dtype=np.int64) // 3 + 68
+    return np.asarray(n, dtype=np.int64) // 3 + 2
 
 
 class Events(NamedTuple):

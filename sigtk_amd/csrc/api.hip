@@ -84,7 +84,6 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
 
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
 unsigned long long debug_exact_redo_count(bool reset);
-void debug_fp_counters(unsigned long long out[10], bool reset);
 int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
                  double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed, int kind,
                  hipStream_t st);
@@ -262,18 +261,6 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
 
 // diagnostics (not part of the stable ABI): t-statistic evaluations redone by the exact path
 unsigned long long sgk_debug_exact_redo_count(int reset) { return sgk::debug_exact_redo_count(reset != 0); }
-// library built with -DSGK_DIAG: decisions inside the uncertainty band / of those, taken on the reference expression
-void sgk_debug_fp_counters(unsigned long long out[10], int reset) { sgk::debug_fp_counters(out, reset != 0); }
-// why[0..4] of the last sgk_event on this workspace (event_args.h)
-int sgk_debug_event_why(const void *ws, uint32_t out[5], void *stream) {
-    if (!ws || !out) return SGK_ERR_ARG;
-    sgk::EvHeader h;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    SGK_HIP_TRY(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, st));
-    SGK_HIP_TRY(hipStreamSynchronize(st));
-    for (int k = 0; k < 5; ++k) out[k] = h.why[k];
-    return SGK_OK;
-}
 
 // ---------------------------------------------------------------- synthetic reads
 int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,

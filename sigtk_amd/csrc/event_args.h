@@ -11,9 +11,7 @@ struct EvHeader {
     uint32_t fb_next;     // work counter of the persistent fallback kernel
     unsigned long long n_events_total;
     uint32_t n_hot_runs;  // lanes that replayed long-detector runs exactly (lazy long detector)
-    uint32_t why[5];      // diagnostics, reads handed to the fallback: [1] no room / alignment / slots, [2] too many hot
-                          // runs, [3] the long detector emits, [4] exactness guard
-    uint32_t pad[4];
+    uint32_t pad[9];
 };
 static_assert(sizeof(EvHeader) == 64, "header is one 64-byte block");
 

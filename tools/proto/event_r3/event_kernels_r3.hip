@@ -616,7 +616,7 @@ struct LazyPass {
             if (e_s != 0.0 || e_q != 0.0) dirty = dirty > U + 2 * W2 ? dirty : U + 2 * W2;
             ok = ok && clean;
         }
-        ar[U % NA] = sgk_arole<W1, !FLAGGED>(b1, b1q);
+        ar[U % NA] = sgk_arole<W1>(b1, b1q);
         // long window: bound only
 #ifdef SGK_EXP_NO_LONG
         bool cold = true;
@@ -798,7 +798,7 @@ struct LazyPass {
         // short window position p = o + k1 - W1 in [i_begin - W1, i_begin): sums P(o + k1) - P(o + k1 - W1)
         if constexpr (k1 >= W2 && k1 < W2 + W1) {
             constexpr int pr = k1 - W1;
-            ar[((k1 - W1 - W2) % NA + NA) % NA] = sgk_arole<W1, !FLAGGED>(ps - hs[pr], pq - hq[pr]);
+            ar[((k1 - W1 - W2) % NA + NA) % NA] = sgk_arole<W1>(ps - hs[pr], pq - hq[pr]);
         }
         // long window position p = o + k1 - W2 in [i_begin - W2, i_begin)
         if constexpr (k1 >= W2 && k1 < 2 * W2) {
@@ -1124,9 +1124,7 @@ __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
     const float mnq = mn * mn, mxq = mx * mx;
     if (mnq < FLT_MIN) return false;
     const int ebq = ilogb((double)n * (double)mxq), emq = ilogb((double)mnq);
-    if (ebq - emq > 29) return false;
-    // the A side's mean is formed with one multiply (tstat_math.h: sgk_arole<W, SHORT>): magnitudes within 2^16
-    return ilogbf(mx) - ilogbf(mn) <= 16;
+    return ebq - emq <= 29;
 }
 
 // Generic detector over one read by one wave (prefix arrays required).
@@ -1174,6 +1172,9 @@ __device__ inline void store_event(const EvArgs &a, uint64_t slot0, uint64_t cap
     a.events[slot0 + k] = e;
 }
 
+#include "event_fast.h"
+
+// ---------------------------------------------------------------- event builder (fast path)
 constexpr int BT = 32;      // samples per lane per builder tile: 64 bytes of int16, one 32-bit bitmap word
 // create_event (events.c:457-473) for the fast builder: the two divisions by the event length share one refined
 // reciprocal (tstat_math.h: bit-identical to `/` inside the range guard); one 16-byte store per event.
@@ -1419,6 +1420,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     if (!flagged && __any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
 }
 
+
 // fallback builder: event sums are differences of the sequential prefix arrays, as in the reference
 template <typename T>
 __device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r) {
@@ -1553,53 +1555,60 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 
 // ---------------------------------------------------------------- kernels
 
-// DNA preset: 168 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): 242 VGPRs -> 2
-template <int W1, typename T>
+// DNA preset: 3 waves per SIMD; RNA preset (deeper rings): 2
 #ifndef SGK_DET_WAVES_DNA
 #define SGK_DET_WAVES_DNA 3
 #endif
 #ifndef SGK_DET_WAVES_RNA
 #define SGK_DET_WAVES_RNA 2
 #endif
-__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_detect(EvArgs a) {
-    __shared__ LzLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L, nullptr);
-    if (lane_id() == 0) a.flags[r] = rcode ? 2 : 0;  // 2: declined by the fast pass -> exact fallback
-}
-
-template <typename T>
-__global__ __launch_bounds__(64, 3) void k_event_build(EvArgs a) {
-    __shared__ BuildLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    build_read<T>(a, rc, r, &L, a.flags[r] == 2);
-}
-
-// Detector and builder of one read in one wave, back to back (SGK_EVENT_FUSED, the default): the builder's phases
-// that wait on memory (sample tiles, event stores) run under other waves' detector arithmetic instead of in a
-// kernel of their own.  The bitmap goes through memory (L2) between the two phases of the same wave.
+// Detector and builder of one read in one wave, back to back: the builder's phases that wait on memory (sample
+// tiles, event stores) run under other waves' detector arithmetic instead of in a kernel of their own.  The bitmap
+// goes through memory (L2) between the two phases of the same wave.
+template <int W1>
 union EventLds {
-    LzLds lz;
+    FpLds<W1> fp;
     BuildLds b;
 };
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
-    __shared__ EventLds L;
+    __shared__ EventLds<W1> L;
     // reads are taken longest first (launch_order): a kernel cannot end before its longest read has, so that one
     // should start first, not wherever it sits in the batch
     const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L.lz, nullptr);
-    // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
+    const int rcode = detect_read_fast<W1, T>(rc, a.hdr, &L.fp);
+    if (rcode != 0 && lane_id() == 0) atomicAdd(&a.hdr->why[rcode], 1u);  // diagnostics
+    // the bitmap units of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
     // them back.  Workgroup scope: the wave's own CU only -- an agent-scope release / acquire pair here writes back and
-    // invalidates L2 once per read, which made 5 000-sample reads 1.7x slower than with two kernels.
+    // invalidates L2 once per read, which made 5 000-sample reads 1.7x slower than with two kernels.  The bitmap lines
+    // were only ever WRITTEN (plain 16-bit stores, atomics) by this kernel before this point, so no stale copy of
+    // them can sit in the CU's vector cache.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifndef SGK_EXP_NO_BUILD
     build_read<T>(a, rc, r, &L.b, rcode != 0);
+#endif
 }
+
+#ifdef SGK_EVENT_UNFUSED
+template <int W1, typename T>
+__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_detect(EvArgs a) {
+    __shared__ FpLds<W1> L;
+    const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
+    const int rcode = detect_read_fast<W1, T>(rc, a.hdr, &L);
+    if (lane_id() == 0) a.flags[r] = rcode ? 2 : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(64, 3) void k_event_build(EvArgs a) {
+    __shared__ BuildLds L;
+    const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
+    build_read<T>(a, rc, r, &L, a.flags[r] == 2);
+}
+#endif
 
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
@@ -1642,42 +1651,34 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 
 // ---------------------------------------------------------------- launcher
 
-#ifndef SGK_EVENT_FUSED
-#define SGK_EVENT_FUSED 1
-#endif
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
     if (a.n_reads == 0) return SGK_OK;
-    // (Tried in round 1: cutting the batch into read slices and running the builder of slice s on a side
-    // stream under the detector of slice s+1.  Both kernels contend for VALU issue and the detector needs
-    // >= 3072 reads in flight to fill its 12 waves/CU, so the overlapped step was 8.8 ms against 7.8 ms.)
     ProfScope whole("path:event", st);
     SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
-#if SGK_EVENT_FUSED
     EvArgs ao = a;
     if (a.n_reads >= ORDER_MIN_READS && a.order) {
         const int rc = launch_order(a.lengths, a.n_reads, a.order, a.order + a.n_reads, st);
         if (rc != SGK_OK) return rc;
     } else ao.order = nullptr;
+#ifdef SGK_EVENT_UNFUSED
+    {
+        ProfScope ps("k_event_detect", st);
+        if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
+        else hipLaunchKernelGGL((k_event_detect<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
+    }
+    {
+        ProfScope ps("k_event_build", st);
+        hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, ao);
+    }
+#else
     {
         ProfScope ps("k_event", st);
         if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
         else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
     }
-    SGK_HIP_TRY(hipGetLastError());
-#else
-    {
-        ProfScope ps("k_event_detect", st);
-        if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_event_detect<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
-    {
-        ProfScope ps("k_event_build", st);
-        hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
 #endif
+    SGK_HIP_TRY(hipGetLastError());
     {
         ProfScope ps("k_event_fallback", st);
         if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);
@@ -1685,6 +1686,17 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
+}
+
+void debug_fp_counters(unsigned long long out[10], bool reset) {
+    for (int k = 0; k < 10; ++k) out[k] = 0;
+    (void)hipMemcpyFromSymbol(&out[0], HIP_SYMBOL(g_fp_calls), sizeof(unsigned long long));
+    (void)hipMemcpyFromSymbol(&out[1], HIP_SYMBOL(g_fp_resolved), sizeof(unsigned long long));
+    if (reset) {
+        const unsigned long long z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fp_calls), &z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fp_resolved), &z, sizeof z);
+    }
 }
 
 unsigned long long debug_exact_redo_count(bool reset) {

@@ -18,9 +18,6 @@ b = device.synth_reads(a.reads, a.read_len, seed=1, kind=a.rna if a.kind is None
 arena = device.EventArena(b)
 device.event(b, arena, a.rna)
 torch.cuda.synchronize()
-if hasattr(L, "sgk_debug_fp_counters"):
-    out = (C.c_ulonglong * 10)()
-    L.sgk_debug_fp_counters(out, 1)
 L.sgk_profile_enable(1)
 for _ in range(a.steps):
     device.event(b, arena, a.rna)
