@@ -9,7 +9,8 @@ its own batch of the same size (reads shard embarrassingly; no data-path collect
 Other BASELINE configurations (secondary lines, same JSON contract):
   --config 3   `event` with RNA parameters + `prefix` on 50 000 RNA-like reads x 100 000 samples
   --config 4   fused `stat` + `pa` on 125 000 DNA reads x 100 000 samples per GPU (the per-GPU shard of 1 M reads)
-  --config 5   pa -> event -> stat over a resident pool of 125 000 DNA reads per GPU
+  --config 5   the pa / event / stat pipeline over a resident pool of 125 000 DNA reads per GPU: one fused stat+pa pass
+               (the per-read statistics and the pA array), then event on the raw samples (it scales on the fly)
   --ragged S   (config 2) log-normal read lengths, sigma S, same mean: the mixed-length line
 
 The oracle is used only in the CPU-baseline leg (rank 0, N=1): as the checker of the benched output and as the
@@ -167,8 +168,10 @@ def main():
         kern = {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("path:")}
         paths = {k: v[0] / args.steps for k, v in prof.items() if k.startswith("path:")}
         path_ms = sum(paths.values()) if paths else sum(kern.values())
-        if args.config in (4, 5):
-            path_ms = sum(kern.values())  # stat/pa launch without a path bracket
+        if args.config in (3, 4, 5):
+            # prefix / stat / pa launch without a path bracket: the step's device time is the sum of its kernels
+            # (config 3 counts the prefix kernels' bytes in `alg`, so their time belongs in the denominator too)
+            path_ms = sum(kern.values())
         dominant = max(kern, key=kern.get) if kern else None
         alg = {2: 2 * S + 16 * E + 40 * R,
                3: (2 * S + 16 * E + 40 * R) + (2 * S + 48 * R),
@@ -194,8 +197,12 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
                     "traffic": None, "algorithmic_bytes": alg,
-                    "limiter": "vector instruction issue (bit-exact f64/f32 expression tree; see DESIGN.md 3.1), "
-                               "not HBM: `bound` names the roofline the contract prices against",
+                    # what the PMC passes of profiles/ show for the dominant kernel of each configuration
+                    "limiter": {2: "vector instruction issue (bit-exact f64/f32 expression tree; DESIGN.md 3.1), not "
+                                   "HBM: `bound` names the roofline the contract prices against",
+                                3: "vector instruction issue (k_event, RNA parameters: 2 waves per SIMD)",
+                                4: "HBM (k_stat_wave with pA output: 100 GB in 21.7 ms, 57 % VALU busy)",
+                                5: "vector instruction issue (k_event) after the HBM-bound stat+pa pass"}[args.config],
                     "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
                     "dominant_kernel": dominant, "path_ms": round(path_ms, 4), "recorded_pmc": recorded}
 

@@ -19,6 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIB = os.path.join(PKG, "libsigtk_gpu.so")
 CLI = os.path.join(PKG, "sigtk-amd")
+CLI_ASAN = os.path.join(PKG, "sigtk-amd-asan")
 
 HIP_SOURCES = ["api.hip", "api_stat.hip", "event_kernels.hip", "stat_kernels.hip", "misc_kernels.hip",
                "svb_kernels.hip", "ent_kernels.hip", "qts_kernels.hip", "job.hip", "shims.hip"]
@@ -72,6 +73,27 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     return CLI
 
 
+def build_cli_asan(force: bool = False, verbose: bool = False) -> str:
+    """The host sources (CLI, BLOW5 reader, formatter) under -fsanitize=address,undefined -- the counterpart of the
+    reference's `make asan=1` (Makefile:31-34).  CPU side only: the GPU library is linked as it is (GPU
+    AddressSanitizer is not available on this pool); tests/test_cli_cpu.py runs the reader's hostile-input cases
+    through this binary."""
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".c"))
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "sigtk_gpu.h"))
+    if not os.path.exists(LIB):
+        build_lib(verbose=verbose)
+    if not force and _newer(CLI_ASAN, deps) and _newer(CLI_ASAN, [LIB]):
+        return CLI_ASAN
+    cmd = ["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI_ASAN, *srcs,
+           "-L", PKG, "-lsigtk_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lm", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI_ASAN
+
+
 def build_tools(force: bool = False, verbose: bool = False) -> None:
     """the stand-alone HIP programs of tools/ (issue-rate microbenchmark, hardware accuracy check of v_rsq_f32)"""
     tdir = os.path.join(ROOT, "tools")
@@ -91,3 +113,5 @@ if __name__ == "__main__":
     build_tools(force="--force" in sys.argv, verbose=True)
     build_lib(force="--force" in sys.argv, verbose=True)
     build_cli(force="--force" in sys.argv, verbose=True)
+    if "--asan" in sys.argv:
+        build_cli_asan(force="--force" in sys.argv, verbose=True)

@@ -519,10 +519,13 @@ struct TermBase {
 template <bool INTERIOR>
 struct TermRaw {  // (float)raw, src/stat.h:29-33
     TermBase<INTERIOR> b;
+    int sm;  // -1 while the accumulator runs on the negated chain (orientation, as TermPa's unit), else 0
     __device__ __forceinline__ TermRaw with(uint32_t z) const { TermRaw r = *this; r.b.z = z; return r; }
     template <int E>
     __device__ __forceinline__ float get() const {
-        return b.template valid<E>() ? (float)b.template sample<E>() : 0.0f;
+        // negated as an integer: a zero sample stays +0 (a -0.0 term would count as negative and end the fast walk)
+        const int v = (int)b.template sample<E>();
+        return b.template valid<E>() ? (float)((v ^ sm) - sm) : 0.0f;
     }
 };
 template <bool INTERIOR>
@@ -615,7 +618,10 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
 
     // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative); fused stat + pa: the pA of
     // every sample is written here, under the lighter arithmetic of the two passes
+    // (both chains: a read whose running raw sum is negative -- signed ADC codes -- would otherwise fail the fast
+    // walk's sign test on every tile and be added term by term)
     float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
+    int sraw = 0;
     {
         WaveTile cur, nxt;
         if (wr.ntiles > 0) wr.load(cur, 0);
@@ -650,15 +656,17 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
                 }
             }
             ss_tile2<true>(
-                m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b}; },
+                m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
                 [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
             if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
+            if (m_raw < 0.0f) { m_raw = -m_raw; sraw = ~sraw; }
             cur = nxt;
         }
     }
     // (a zero accumulator stands for +0: the reference's sum starts at +0 and x + (-x), +0 + -0 are +0 under
     // round-to-nearest, whichever way the chain was oriented)
-    const float mraw = m_raw / nf, mpa = (m_pa == 0.0f ? 0.0f : m_pa * sg) / nf;
+    const float mraw = (m_raw == 0.0f ? 0.0f : (sraw ? -m_raw : m_raw)) / nf;
+    const float mpa = (m_pa == 0.0f ? 0.0f : m_pa * sg) / nf;
 
     // ---- pass 2: squared deviations, window histogram, pA
     const int64_t k = g.len / 2;

@@ -220,6 +220,15 @@ static char *idx_path(const b5_file_t *f) {
 static int idx_load(b5_file_t *f) {
     char *ip = idx_path(f);
     if (!ip) return B5_ERR_MEM;
+    /* an index older than its BLOW5 describes another file of that name (slow5lib warns "Index file is older",
+     * slow5_idx.c:43, and goes on; here the file is scanned again and the index rewritten) */
+    struct stat st_idx, st_dat;
+    if (stat(ip, &st_idx) == 0 && stat(f->path, &st_dat) == 0 &&
+        (st_idx.st_mtim.tv_sec < st_dat.st_mtim.tv_sec ||
+         (st_idx.st_mtim.tv_sec == st_dat.st_mtim.tv_sec && st_idx.st_mtim.tv_nsec < st_dat.st_mtim.tv_nsec))) {
+        free(ip);
+        return B5_ERR_NOTFOUND;
+    }
     FILE *fp = fopen(ip, "rb");
     free(ip);
     if (!fp) return B5_ERR_NOTFOUND;
@@ -240,8 +249,9 @@ static int idx_load(b5_file_t *f) {
         char *id = (char *)malloc((size_t)idl + 1);
         if (!id) { rc = B5_ERR_MEM; goto done; }
         uint64_t off_size[2];
+        /* (offset and size are untrusted 64-bit values: compared without forming their sum) */
         if (fread(id, 1, idl, fp) != idl || fread(off_size, 8, 2, fp) != 2 || off_size[0] < f->first_rec ||
-            off_size[1] < 8 || off_size[0] + off_size[1] > fsize) {
+            off_size[1] < 8 || off_size[0] > fsize || off_size[1] > fsize - off_size[0]) {
             free(id);
             goto done;
         }
@@ -299,13 +309,22 @@ static void idx_write(const b5_file_t *f, const b5_idx_entry_t *in_file_order, u
     free(ip);
 }
 
-int b5_index(b5_file_t *f) {
+static void idx_drop(b5_file_t *f) {
+    for (uint64_t i = 0; i < f->n_idx; i++) free(f->idx[i].id);
+    free(f->idx);
+    f->idx = NULL;
+    f->n_idx = 0;
+}
+
+static int index_build(b5_file_t *f, int trust_disk) {
     if (f->idx) return 0;
     const long keep = ftell(f->fp);
-    if (idx_load(f) == 0) {
+    if (trust_disk && idx_load(f) == 0) {
+        f->idx_from_disk = 1;
         fseek(f->fp, keep, SEEK_SET);
         return 0;
     }
+    f->idx_from_disk = 0;
     if (fseek(f->fp, (long)f->first_rec, SEEK_SET) != 0) return B5_ERR_IO;
     b5_rec_t tmp;
     memset(&tmp, 0, sizeof tmp);
@@ -343,18 +362,33 @@ int b5_index(b5_file_t *f) {
     return 0;
 }
 
+int b5_index(b5_file_t *f) { return index_build(f, 1); }
+
+/* An index loaded from disk is only as good as the file it was written for: what it points at must be the record it
+ * names, of the size it says.  On a mismatch the index is dropped, the file scanned, the lookup repeated once. */
 int b5_get(b5_file_t *f, const char *read_id, b5_rec_t *rec) {
-    if (!f->idx) {
-        const int rc = b5_index(f);
-        if (rc) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!f->idx) {
+            const int rc = index_build(f, attempt == 0);
+            if (rc) return rc;
+        }
+        b5_idx_entry_t key;
+        key.id = (char *)read_id;
+        key.offset = 0;
+        const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
+        if (!e) {
+            if (f->idx_from_disk && attempt == 0) { idx_drop(f); continue; }
+            return B5_ERR_NOTFOUND;
+        }
+        const uint64_t esize = e->size;
+        if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
+        const int rc = read_record(f, rec, 0);
+        const int fits = rc == 0 && rec->read_id && strcmp(rec->read_id, read_id) == 0 &&
+                         (uint64_t)ftell(f->fp) - e->offset == esize;
+        if (fits || !f->idx_from_disk || attempt == 1) return rc == 0 && !fits ? B5_ERR_FORMAT : rc;
+        idx_drop(f);
     }
-    b5_idx_entry_t key;
-    key.id = (char *)read_id;
-    key.offset = 0;
-    const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
-    if (!e) return B5_ERR_NOTFOUND;
-    if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
-    return read_record(f, rec, 0);
+    return B5_ERR_FORMAT;
 }
 
 void b5_rec_free(b5_rec_t *rec) {
@@ -387,18 +421,42 @@ int b5_next_raw(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint6
     return read_raw_here(f, buf, len, cap, size);
 }
 
+/* raw bytes of the record `read_id` (as b5_next_raw).  The record is not parsed here, so an index from disk is checked
+ * as far as the bytes allow: the size it records, and, when records are not compressed, the id stored in the record
+ * (b5_parse_raw's caller sees the id of compressed records and compares it itself). */
 int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size) {
-    if (!f->idx) {
-        const int rc = b5_index(f);
-        if (rc) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!f->idx) {
+            const int rc = index_build(f, attempt == 0);
+            if (rc) return rc;
+        }
+        b5_idx_entry_t key;
+        key.id = (char *)read_id;
+        key.offset = 0;
+        const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
+        if (!e) {
+            if (f->idx_from_disk && attempt == 0) { idx_drop(f); continue; }
+            return B5_ERR_NOTFOUND;
+        }
+        const uint64_t esize = e->size, len0 = *len;
+        if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
+        const int rc = read_raw_here(f, buf, len, cap, size);
+        int fits = rc == 0 && *size + 8 == esize;
+        if (fits && f->record_press == 0) {
+            const uint8_t *r = *buf + len0;
+            const size_t idl = strlen(read_id);
+            uint16_t have;
+            fits = *size >= 2 + idl;
+            if (fits) {
+                memcpy(&have, r, 2);
+                fits = have == idl && memcmp(r + 2, read_id, idl) == 0;
+            }
+        }
+        if (fits || !f->idx_from_disk || attempt == 1) return rc == 0 && !fits ? B5_ERR_FORMAT : rc;
+        *len = len0;
+        idx_drop(f);
     }
-    b5_idx_entry_t key;
-    key.id = (char *)read_id;
-    key.offset = 0;
-    const b5_idx_entry_t *e = (const b5_idx_entry_t *)bsearch(&key, f->idx, f->n_idx, sizeof key, idx_cmp);
-    if (!e) return B5_ERR_NOTFOUND;
-    if (fseek(f->fp, (long)e->offset, SEEK_SET) != 0) return B5_ERR_IO;
-    return read_raw_here(f, buf, len, cap, size);
+    return B5_ERR_FORMAT;
 }
 
 int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,

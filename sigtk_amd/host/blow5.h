@@ -41,6 +41,7 @@ typedef struct {
     uint64_t first_rec;   /* file offset of the first record */
     b5_idx_entry_t *idx;  /* built lazily by b5_index (sorted by id) */
     uint64_t n_idx;
+    int idx_from_disk;    /* the index was loaded from "<file>.idx" (checked against what it points at) */
     const uint8_t *map;   /* the whole file mapped read-only (b5_map), or NULL */
     uint64_t map_len, map_pos;
 } b5_file_t;

@@ -17,6 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=3.0)
+    ap.add_argument("--batches", type=int, default=0,
+                    help="run exactly this many batches (the same work on every box) instead of a time box")
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     import torch
@@ -34,7 +36,7 @@ def main():
         stats["mismatches"].append(msg)
         print("MISMATCH", msg, flush=True)
 
-    while time.time() < t_end and len(stats["mismatches"]) < 5:
+    while (stats["batches"] < a.batches if a.batches else time.time() < t_end) and len(stats["mismatches"]) < 5:
         kind = int(rs.randint(0, 2))
         if rs.rand() < 0.1:   # many tiny reads: slot / offset arithmetic, reads shorter than every window
             nr = int(rs.randint(200, 2000))

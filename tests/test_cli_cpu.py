@@ -205,3 +205,100 @@ def test_index_file_is_written_reused_and_checked(cli, tmp_path, sp1):
     assert open(path + ".idx", "rb").read() == idx
     # unknown id
     assert run(cli, "_dump", "--id", "no-such-read", path).returncode == 1
+
+
+def test_index_of_another_file_is_detected(cli, tmp_path, sp1):
+    """an "<file>.idx" that passes the format checks but belongs to ANOTHER file of that name (same
+    records in another order: every offset + size is inside the file) must not return the wrong read -- the record
+    fetched through the index is compared with the entry (id, size); an index older than the BLOW5 is not used at
+    all (slow5lib only warns, slow5_idx.c:43)."""
+    import shutil
+    import time
+    a = str(tmp_path / "a.blow5")
+    shutil.copy(os.path.join(GOLDEN, "sp1_dna.blow5"), a)
+    want = {r.read_id: fnv(r.raw) for r in sp1.reads}
+    assert run(cli, "_dump", "--id", sp1.reads[0].read_id, a).returncode == 0      # writes a.blow5.idx
+    good = open(a + ".idx", "rb").read()
+    # the same reads in reverse order under the same name, with the OLD index made newer than the file
+    blow5.write_blow5(a, list(reversed(sp1.reads)), {k: v[0] for k, v in sp1.attrs.items()}, 1, 1)
+    open(a + ".idx", "wb").write(good)
+    future = time.time() + 100
+    os.utime(a + ".idx", (future, future))
+    for rid in (sp1.reads[3].read_id, sp1.reads[97].read_id):
+        for extra in ([], ["--split"]):
+            p = run(cli, "_dump", *extra, "--id", rid, a)
+            assert p.returncode == 0, p.stderr
+            assert p.stdout.split("\t")[0] == rid and int(p.stdout.split("\t")[5], 16) == want[rid]
+        # the stale index was replaced by one of the new file
+        assert open(a + ".idx", "rb").read() != good
+        open(a + ".idx", "wb").write(good)
+        os.utime(a + ".idx", (future, future))
+    # an index older than the data file is ignored outright
+    past = time.time() - 1000
+    os.utime(a + ".idx", (past, past))
+    p = run(cli, "_dump", "--id", sp1.reads[50].read_id, a)
+    assert p.returncode == 0 and int(p.stdout.split("\t")[5], 16) == want[sp1.reads[50].read_id]
+
+
+@pytest.fixture(scope="module")
+def cli_asan():
+    try:
+        return build.build_cli_asan()
+    except (subprocess.CalledProcessError, OSError) as e:  # no libasan in this toolchain
+        pytest.skip("sanitizer build not available: %s" % e)
+
+
+def test_hostile_inputs_under_asan_ubsan(cli_asan, tmp_path, sp1):
+    """The host sources built with -fsanitize=address,undefined (`python -m sigtk_amd.build --asan`, the counterpart
+    of the reference's `make asan=1`, Makefile:31-34): the reader's hostile-input cases -- crafted length fields,
+    truncations, bit flips, a stale index -- must end with exit code 0 or 1 and without a sanitizer report."""
+    import random
+    import struct
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+
+    def run_a(*args):
+        p = subprocess.run([cli_asan, *args], capture_output=True, timeout=120, env=env)
+        assert p.returncode in (0, 1), (args, p.returncode, p.stderr[-600:])
+        assert b"Sanitizer" not in p.stderr and b"runtime error" not in p.stderr, p.stderr[-600:]
+        return p
+
+    good = os.path.join(GOLDEN, "sp1_dna.blow5")
+    for extra in ([], ["--split"], ["--map"]):
+        assert run_a("_dump", *extra, good).returncode == 0
+    for lf in (1 << 63, 1 << 32, (1 << 63) + 8, 0x7fffffff):
+        path = _crafted(tmp_path, "evil.blow5", lf, b"\x01\x00" * 8, 0)
+        for extra in ([], ["--split"], ["--map"]):
+            assert run_a("_dump", *extra, path).returncode == 1
+    blob = struct.pack("<I", 0x7fffffff) + b"\x00"
+    path = _crafted(tmp_path, "evil_svb.blow5", len(blob), blob, 1)
+    for extra in ([], ["--split"], ["--map"]):
+        assert run_a("_dump", *extra, path).returncode == 1
+    data = open(good, "rb").read()
+    rnd = random.Random(11)
+    path = str(tmp_path / "fz.blow5")
+    for it in range(24):
+        d = bytearray(data)
+        if it % 3 == 0:
+            for _ in range(rnd.randint(1, 5)):
+                d[rnd.randrange(len(d))] ^= 1 << rnd.randrange(8)
+        elif it % 3 == 1:
+            d = d[: rnd.randrange(70, len(d))]
+        else:
+            i = rnd.randrange(60, len(d) - 8)
+            d[i:i + 8] = bytes(rnd.getrandbits(8) for _ in range(8))
+        open(path, "wb").write(bytes(d))
+        for extra in ([], ["--split"], ["--map"]):
+            run_a("_dump", *extra, path)
+    # read-id mode through a corrupted index
+    import shutil
+    a = str(tmp_path / "a.blow5")
+    shutil.copy(good, a)
+    assert run_a("_dump", "--id", sp1.reads[5].read_id, a).returncode == 0
+    idx = bytearray(open(a + ".idx", "rb").read())
+    for it in range(12):
+        b = bytearray(idx)
+        for _ in range(3):
+            b[rnd.randrange(64, len(b))] ^= 1 << rnd.randrange(8)
+        open(a + ".idx", "wb").write(bytes(b))
+        run_a("_dump", "--id", sp1.reads[rnd.randrange(100)].read_id, a)
+    assert run_a("_fmtcheck", "99991").returncode == 0

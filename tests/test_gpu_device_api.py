@@ -220,3 +220,72 @@ def test_many_short_reads_next_to_one_very_long_read(gpu):
     for r in (0, 12345, 70000):
         o = int(b.offsets_host[r]); n = int(b.lengths_host[r])
         assert np.array_equal(q_all[o:o + n], (raw_all[o:o + n] >> 3) << 3), "qts, read %d" % r
+
+
+def test_baseline_config4_and_5_at_their_shard_size(gpu, oracle):
+    """BASELINE configs 4 and 5 at their per-GPU size (125 000 DNA reads x 100 000 samples: 25 GB of samples, 50 GB
+    of pA, 67 GB of event slots): properties that hold for every read, idempotence, and the oracle bit for bit on a
+    sample of reads -- fused stat + pA (config 4), then event on the same resident pool (config 5)."""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 170 * (1 << 30):
+        pytest.skip("needs 170 GB of free HBM (this device has %.0f GB free)" % (free / (1 << 30)))
+    R, N = 125000, 100000
+    b = device.synth_reads(R, N, seed=3, kind=0, device=dev)
+    pa = torch.empty(b.n_samples, dtype=torch.float32, device=dev)
+    rec, _ = device.stat_pa(b, pa)
+    torch.cuda.synchronize()
+    got = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:R]
+    # every read: the record carries its length, the statistics are finite, the pA median is the pA of the raw median
+    assert bool((got["n"] == N).all())
+    for name in ("raw_mean", "pa_mean", "raw_std", "pa_std", "pa_median"):
+        assert bool(np.isfinite(got[name]).all()), name
+    unit = (np.float32(1402.882324) / np.float32(8192.0)).astype(np.float32)
+    offs = b.off.cpu().numpy().astype(np.float32)
+    exp_med = ((got["raw_median"].astype(np.float32) + offs[:R]) * unit).astype(np.float32)
+    assert np.array_equal(exp_med.view(np.uint32), got["pa_median"].view(np.uint32))
+    # idempotence: a second pass gives identical records and identical pA (checksum of the whole 50 GB)
+    cks = lambda t: (int(t.view(torch.int32).to(torch.int64).sum().item()), int(t.view(torch.int32)[::4097].to(torch.int64).sum().item()))
+    c1 = cks(pa)
+    rec2, _ = device.stat_pa(b, pa)
+    torch.cuda.synchronize()
+    assert rec2.cpu().numpy().tobytes() == rec.cpu().numpy().tobytes() and cks(pa) == c1
+    # the oracle on a sample
+    for r in (0, 1, 62499, 124998, 124999):
+        o = int(b.offsets_host[r])
+        raw = b.samples[o:o + N].cpu().numpy()
+        d, of, rg = float(b.dig[r]), float(b.off[r]), float(b.rng[r])
+        e = oracle.stat(raw, d, of, rg)
+        g = got[r]
+        assert int(g["raw_median"]) == e[4]
+        for name, ev in (("raw_mean", e[0]), ("pa_mean", e[1]), ("raw_std", e[2]), ("pa_std", e[3]), ("pa_median", e[5])):
+            assert np.float32(g[name]).view(np.uint32) == np.float32(ev).view(np.uint32), (r, name)
+        assert np.array_equal(pa[o:o + N].cpu().numpy().view(np.uint32), oracle.pa(raw, d, of, rg).view(np.uint32))
+    # ---- config 5: event over the same pool
+    del pa
+    torch.cuda.empty_cache()
+    arena = device.EventArena(b)
+    device.event(b, arena, 0)
+    torch.cuda.synchronize()
+    st = arena.status()
+    nev = arena.n_events[:R].to(torch.int64)
+    assert st.n_capacity_overflow == 0 and int(nev.sum().item()) == st.n_events_total
+    slots = torch.from_numpy(arena.slots_host[:-1]).to(dev)
+    assert bool((arena.start[slots] == 0).all())
+    last = slots + nev - 1
+    assert bool(((arena.start[last].to(torch.int64) + arena.length[last].to(torch.int64)) == N).all())
+    snap_n = nev.clone()
+    first_ev = arena.events[slots].clone()
+    device.event(b, arena, 0)
+    torch.cuda.synchronize()
+    assert bool((arena.n_events[:R].to(torch.int64) == snap_n).all()) and bool((arena.events[slots] == first_ev).all())
+    for r in (0, 77777, 124999):
+        o = int(b.offsets_host[r])
+        raw = b.samples[o:o + N].cpu().numpy()
+        exp = oracle.event_raw(raw, float(b.dig[r]), float(b.off[r]), float(b.rng[r]), 0)
+        g = arena.read_events(r)
+        assert g.start.size == exp.start.size and np.array_equal(g.start.astype(np.uint64), exp.start)
+        assert np.array_equal(g.mean.view(np.uint32), exp.mean.view(np.uint32))
+        assert np.array_equal(g.stdv.view(np.uint32), exp.stdv.view(np.uint32))

@@ -19,6 +19,14 @@ def _n_gpus(gpu):
     return gpu.device_count()
 
 
+def _free_port():
+    """a rendezvous port nobody holds right now (a fixed number collides on a shared box)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 @pytest.mark.parametrize("tool", ["event", "stat", "prefix"])
 def test_cli_two_gpus_equals_one(gpu, tool):
     """sigtk-amd --gpus 2 with small batches (so both devices get work, jobs created lazily on the reader thread,
@@ -26,8 +34,8 @@ def test_cli_two_gpus_equals_one(gpu, tool):
     if _n_gpus(gpu) < 2:
         pytest.skip("needs 2 GPUs (this box has %d)" % _n_gpus(gpu))
     args = [tool, "-c", SP1] if tool == "event" else [tool, SP1]
-    one = subprocess.run([build.CLI, *args, "--gpus", "1", "--batch-samples", "40000"], capture_output=True)
-    two = subprocess.run([build.CLI, *args, "--gpus", "2", "--batch-samples", "40000"], capture_output=True)
+    one = subprocess.run([build.CLI, *args, "--gpus", "1", "--batch-samples", "40000"], capture_output=True, timeout=600)
+    two = subprocess.run([build.CLI, *args, "--gpus", "2", "--batch-samples", "40000"], capture_output=True, timeout=600)
     assert one.returncode == 0 and two.returncode == 0, two.stderr.decode()[-1000:]
     assert one.stdout == two.stdout and len(one.stdout) > 1000
 
@@ -39,7 +47,7 @@ def test_bench_two_ranks_rccl(gpu):
         pytest.skip("needs 2 GPUs (this box has %d)" % _n_gpus(gpu))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "2000", "--cpu-reads", "0"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -55,7 +63,7 @@ def test_bench_two_ranks_share_one_gpu_gloo(gpu):
     """The same launch with the gloo backend (both ranks on device 0): exercises the N > 1 code of bench.py --
     barrier, MAX over the step time, SUM of the units, strong-scaling partition -- on a 1-GPU box."""
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29542", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1000", "--cpu-reads", "0",
                         "--backend", "gloo", "--scaling", "strong", "--ragged", "0.8"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)

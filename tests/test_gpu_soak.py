@@ -13,11 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_short_soak(gpu):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_parity.py"), "--minutes", "0.4", "--seed", "3"],
-                       capture_output=True, text=True)
+    # a fixed number of batches: the same coverage on every box (a time box would not give that)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_parity.py"), "--batches", "120", "--seed", "3"],
+                       capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     stats = json.loads(p.stdout.strip().splitlines()[-1])
-    assert stats["mismatches"] == [] and stats["reads"] > 100 and stats["fallback_reads"] > 0
+    assert stats["mismatches"] == [] and stats["batches"] == 120 and stats["reads"] > 100 and stats["fallback_reads"] > 0
 
 
 def test_soak_regression_stale_samples_before_a_read():
@@ -65,8 +66,8 @@ def test_soak_regression_lane_local_rounding_in_the_flagged_pass(gpu, oracle):
 def test_short_wave_vs_lane_soak(gpu):
     """a short run of tests/soak_wave_vs_lane.py: stat / jnn / prefix of the wave-per-read kernels against the
     lane-per-read kernels on batches of 1 000 - 6 000 ragged reads (longer runs are recorded under profiles/)"""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_wave_vs_lane.py"), "--minutes", "0.3", "--seed", "9"],
-                       capture_output=True, text=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_wave_vs_lane.py"), "--batches", "40", "--seed", "9"],
+                       capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     stats = json.loads(p.stdout.strip().splitlines()[-1])
-    assert stats["mismatches"] == [] and stats["reads"] > 5000
+    assert stats["mismatches"] == [] and stats["batches"] == 40 and stats["reads"] > 5000

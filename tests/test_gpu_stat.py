@@ -298,3 +298,43 @@ def test_jnn_wave_regression_sync_sample_at_block_end(gpu, oracle):
         dig, off, rng = np.array([float(z["dig"])]), np.array([float(z["off"])]), np.array([float(z["rng"])])
         for rna in (0, 1):
             _check_jnn(oracle, [x], rna, gpu.jnn([x], dig, off, rng, rna))
+
+
+def test_stat_negative_raw_sum_is_exact_and_not_slow(gpu, oracle):
+    """reads whose running RAW sum is negative (signed ADC codes) used to fail the fast walk's sign test
+    on every tile (term-by-term fallback: exact, 10-50x slower, and with longest-first dispatch one such read sets the
+    kernel time).  The raw chain is oriented like the pA chain now: same bits as the oracle, and a batch of such reads
+    costs what its mirror image costs."""
+    import torch
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(21)
+    n, R = 150000, 96
+    pos = [(600 + rs.randint(-60, 61, size=n)).astype(np.int16) for _ in range(R)]
+    neg = [(-x).astype(np.int16) for x in pos]
+    dig = np.full(R, 8192.0); off = np.full(R, 5.0); rng = np.full(R, 1402.882324)
+    # (a chain whose TERMS change sign while the accumulator stays on one side -- first half +600s, second half -600s --
+    # is outside the monotone fast walk by construction and is added term by term: exact, checked below, not timed)
+    mixed = np.concatenate([pos[1][:n // 2], (-pos[1][n // 2:]).astype(np.int16)])
+    zeros = neg[2].copy(); zeros[::2] = 0       # raw chain: +0 terms on the negated chain; pA chain: mixed signs
+    hard = [mixed, zeros]
+    bm = device.upload_reads(hard, np.full(2, 8192.0), np.full(2, 5.0), np.full(2, 1402.882324), dev)
+    recm = device.stat(bm)
+    torch.cuda.synchronize()
+    _check_stat(oracle, hard, np.full(2, 8192.0), np.full(2, 5.0), np.full(2, 1402.882324),
+                np.frombuffer(recm.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:2])
+    times = {}
+    for name, reads in (("pos", pos), ("neg", neg)):
+        b = device.upload_reads(reads, dig, off, rng, dev)
+        rec = device.stat(b)
+        torch.cuda.synchronize()
+        got = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:R]
+        _check_stat(oracle, reads[:6] + reads[-2:], dig, off, rng, np.concatenate([got[:6], got[-2:]]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            device.stat(b)
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) / 5
+    assert times["neg"] < 1.5 * times["pos"] + 0.05, times
