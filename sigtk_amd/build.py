@@ -97,7 +97,7 @@ def build_cli_asan(force: bool = False, verbose: bool = False) -> str:
 def build_tools(force: bool = False, verbose: bool = False) -> None:
     """the stand-alone HIP programs of tools/ (issue-rate microbenchmark, hardware accuracy check of v_rsq_f32)"""
     tdir = os.path.join(ROOT, "tools")
-    for name in ("rsq_check", "valu_rate"):
+    for name in ("rsq_check", "valu_rate", "fetch_calib"):
         src = os.path.join(tdir, name + ".hip")
         exe = os.path.join(tdir, name)
         deps = [src] + ([os.path.join(tdir, "valu_rate_tests.inc")] if name == "valu_rate" else [])

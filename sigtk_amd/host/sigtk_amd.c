@@ -57,6 +57,32 @@ static double realtime(void) {
     gettimeofday(&tp, NULL);
     return tp.tv_sec + tp.tv_usec * 1e-6;
 }
+/* SGK_CLI_TIMING: where the wall time of a run goes that the pipeline's stage sums do not show (process start,
+ * HIP initialisation, first launch = code object load, buffer set-up, teardown).  Seconds since the process was
+ * started (execve), from /proc: starttime of /proc/self/stat against /proc/uptime. */
+static double since_exec(void) {
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return -1.0;
+    char buf[1024];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')');   /* the command name may hold spaces */
+    if (!p) return -1.0;
+    unsigned long long start = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++)
+        if (*p == ' ') field++;
+    if (sscanf(p, "%llu", &start) != 1) return -1.0;
+    double up = 0.0;
+    f = fopen("/proc/uptime", "r");
+    if (!f) return -1.0;
+    if (fscanf(f, "%lf", &up) != 1) up = -1.0;
+    fclose(f);
+    return up < 0 ? -1.0 : up - (double)start / (double)sysconf(_SC_CLK_TCK);
+}
+static double g_t_main = 0.0, g_exec_to_main = -1.0, g_t_first_submit = 0.0, g_t_pipeline_end = 0.0, g_t_destroyed = 0.0;
+
 static double cputime(void) {
     struct rusage r;
     getrusage(RUSAGE_SELF, &r);
@@ -442,6 +468,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
         rc = sgk_job_submit(b->job, tool, P->opt.rna, P->opt.pore, flags);
     if (rc != SGK_OK) gpu_fail("sgk_job_submit", rc);
     P->t_stage += realtime() - t1;
+    if (g_t_first_submit == 0.0) g_t_first_submit = realtime();
     q_push(&P->ready_q, b);
 }
 
@@ -863,18 +890,25 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
     q_push(&P->ready_q, &pool[nbatch]);
     pthread_join(wth, NULL);
     pool_destroy(P->load_pool);
+    g_t_pipeline_end = realtime();
     if (getenv("SGK_CLI_TIMING"))
         fprintf(stderr,
                 "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
                 "stage+submit %.3f s | wait-for-GPU %.3f s, format %.3f s, write %.3f s | HIP init %.3f s, job create %.3f s\n",
                 (unsigned long)P->n_reads, (unsigned long)P->n_samples, P->nthreads, n_gpus, P->t_read, P->t_parse,
                 P->t_stage, P->t_wait, P->t_format, P->t_write, t_init, t_jobs);
-    for (int i = 0; i < P->n_created; i++) {
-        sgk_job_destroy(pool[i].job);
-        for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
-        free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+    /* The process is about to leave through _exit (main): the jobs' pinned and device buffers go with it.  Releasing
+     * them one hipHostFree / hipFree at a time costs more than a small input's whole pipeline (SGK_CLI_TIMING shows
+     * it), so they are only released when asked to (leak checkers: SGK_CLI_FREE=1). */
+    if (getenv("SGK_CLI_FREE")) {
+        for (int i = 0; i < P->n_created; i++) {
+            sgk_job_destroy(pool[i].job);
+            for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
+            free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+        }
+        free(pool);
     }
-    free(pool);
+    g_t_destroyed = realtime();
 }
 
 /* ------------------------------------------------------------------ cmain (src/cmain.c:40-156) */
@@ -1275,6 +1309,8 @@ static void print_usage(FILE *fp) {
 
 int main(int argc, char *argv[]) {
     const double realtime0 = realtime();
+    g_t_main = realtime0;
+    if (getenv("SGK_CLI_TIMING")) g_exec_to_main = since_exec();
     int ret = 1;
     if (argc < 2) {
         print_usage(stderr);
@@ -1301,6 +1337,14 @@ int main(int argc, char *argv[]) {
     for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
     fprintf(stderr, "\n[%s] Real time: %.3f sec; CPU time: %.3f sec; Peak RAM: %.3f GB\n\n", __func__,
             realtime() - realtime0, cputime(), peakrss() / 1024.0 / 1024.0 / 1024.0);
+    if (getenv("SGK_CLI_TIMING") && g_t_pipeline_end > 0.0)
+        fprintf(stderr,
+                "[sigtk-amd] timeline: exec -> main %.3f s (loader, library constructors) | main -> first batch submitted "
+                "%.3f s (HIP init, job buffers, first launches = code object load) | -> pipeline drained %.3f s | teardown "
+                "%.3f s | total since exec %.3f s\n",
+                g_exec_to_main, g_t_first_submit > 0.0 ? g_t_first_submit - g_t_main : -1.0,
+                g_t_pipeline_end - (g_t_first_submit > 0.0 ? g_t_first_submit : g_t_main), g_t_destroyed - g_t_pipeline_end,
+                g_exec_to_main + (realtime() - g_t_main));
     /* everything is written; leave without running the HIP runtime's exit handlers (they take longer than a
      * small input does) */
     if (fflush(stdout) != 0 || ferror(stdout)) {

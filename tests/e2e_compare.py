@@ -47,6 +47,8 @@ def main():
             env = dict(os.environ, SGK_CLI_TIMING="1")
             t0 = time.perf_counter(); g = subprocess.run([build.CLI, *tool, *a.cli_args.split(), f], capture_output=True, env=env); tg = time.perf_counter() - t0
             stages = [ln for ln in g.stderr.decode(errors="replace").splitlines() if ln.startswith("[sigtk-amd]")]
+            for ln in stages[1:]:
+                print(name, ln, file=sys.stderr)
             if a.no_ref:
                 out[name] = {"rc": g.returncode, "sigtk_amd_s": round(tg, 3), "stdout_mb": round(len(g.stdout) / 1e6, 1),
                              "samples_per_s": round(out["samples"] / tg, 1), "stages": stages[0] if stages else None}

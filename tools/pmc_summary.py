@@ -55,11 +55,11 @@ def main():
            for k in fetch if k != "k_event_fallback"}
     rd_raw = sum(v["FETCH_SIZE_KiB"] for v in raw.values()) * 1024
     wr = sum(v["WRITE_SIZE_KiB"] for v in raw.values()) * 1024
-    # what the path must move at least, given its structure: samples read by the detector and again by the builder,
-    # the bitmap written and read back, the events written
-    known_rd = 2 * (2 * S) + S // 8
-    known_wr = 16 * E + S // 8
-    rd = min(max(rd_raw, known_rd), 2 * rd_raw)
+    # FETCH_SIZE tallies every 128-byte fabric request at 64 bytes, whatever the shape of the access
+    # (tools/fetch_calib.hip, profiles/r03_fetch_calibration.json: coalesced 16 / 32 / 64 bytes per lane, and 32 bytes
+    # per lane with every lane on its own stream as in the detector -- the request count changes with the shape, the
+    # bytes per request do not): the bytes that crossed the fabric are 2 x the counter.  Nothing is priced.
+    rd = 2 * rd_raw
     busy = {k: v["SQ_ACTIVE_INST_VALU"] * 4 / v["SQ_BUSY_CYCLES"] * 32 / 1024 for k, v in sq.items() if "SQ_BUSY_CYCLES" in v}
     try:
         commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(__file__)).decode().strip()
@@ -68,15 +68,14 @@ def main():
     doc = {
         "_comment": "HBM bytes per bench step (config 2: 1e9 samples) from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                     "collected in separate passes (tools/refresh_profiles.sh + tools/pmc_summary.py; mean over the "
-                    "dispatches of the run).  Counter unit is KiB.  Per MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies "
-                    "128-byte requests at 64 bytes, so a wide coalesced read stream is reported at exactly half and other "
-                    "access widths are uncalibrated: the read volume is therefore bracketed by [raw, 2 x raw] and priced at "
-                    "the known minimum of the path's structure when that lies inside the bracket (samples read by the "
-                    "detector and again by the builder, bitmap read back).  WRITE_SIZE is exact for wide stores.",
+                    "dispatches of the run).  Counter unit is KiB.  FETCH_SIZE tallies 128-byte requests at 64 bytes "
+                    "(MI355X_MICROARCH.md, HBM); calibrated for this kernel's access shapes by tools/fetch_calib.hip "
+                    "(profiles/r03_fetch_calibration.json): the factor is 2 for all of them, so read bytes = 2 x the "
+                    "counter -- measured, not priced.  WRITE_SIZE is exact for wide stores.",
         "recorded_for": {"commit": commit, "source": tag, "kernel": main_k},
         "raw": raw,
-        "read_bytes": {"raw": rd_raw, "bracket_high": 2 * rd_raw, "structural_minimum": known_rd, "priced": rd},
-        "write_bytes": {"counted": wr, "structural_minimum": known_wr},
+        "read_bytes": {"counter": rd_raw, "calibration_factor": 2.0, "measured": rd},
+        "write_bytes": {"counted": wr},
         "hbm_bytes_per_step": rd + wr,
         "algorithmic_bytes_per_step": alg,
         "traffic_over_algorithmic": round((rd + wr) / alg, 3),
