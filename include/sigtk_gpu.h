@@ -142,7 +142,19 @@ typedef struct sgk_event_status {
     uint32_t n_long_replays;     /* lanes (chunks) in which a run of the lazily evaluated long detector could not be
                                   * proven silent and was re-played exactly (diagnostic)  */
     uint64_t n_events_total;
+    uint32_t n_split_reads;      /* reads long enough to be taken by several wavefronts (segments of 131 072
+                                  * samples, reads of at least 262 144)                     */
+    uint32_t n_segments;         /* their segments                                         */
+    uint32_t n_seam_reruns;      /* segments whose speculative start was wrong and that were run again */
+    uint32_t reserved;
 } sgk_event_status_t;
+/* Tuning (process-wide; call it before sizing workspaces, not while an sgk_event call is being issued): a read of at
+ * least `long_min` samples is cut into segments of `seg_len` samples (multiple of 1024), one wavefront each; `lead` is
+ * the speculative warm-up in samples (multiple of 16, <= 512).  0 selects the default of a value (131 072 / 262 144 /
+ * the preset's own warm-up); the environment variables SGK_EVENT_SEG, SGK_EVENT_LONG_MIN, SGK_EVENT_LEAD give the
+ * values a process starts with.  Results do not depend on any of them. */
+int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead);
+
 /* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.
  * Returns SGK_ERR_CAPACITY if any read overflowed its slots. */
 int sgk_event_status(const void *workspace, sgk_event_status_t *out, void *stream);

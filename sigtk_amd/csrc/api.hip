@@ -54,6 +54,54 @@ ProfScope::~ProfScope() {
 }
 
 // ---------------------------------------------------------------- workspace layout (event)
+static std::mutex g_seg_mu;
+static EvSegConfig g_seg_cfg;
+static bool g_seg_cfg_set = false;
+static EvSegConfig seg_config_checked(long long seg, long long lmin, long lead) {
+    EvSegConfig c;
+    c.seg_len = 131072;    // one wavefront's share of a long read: ~0.6 ms of detector + builder
+    c.long_min = 262144;   // reads at least this long are cut into segments
+    c.lead_override = 0;
+    if (seg >= 1024 && seg <= (1ll << 30)) c.seg_len = (uint32_t)(seg / 1024 * 1024);
+    if (lmin >= 1) c.long_min = lmin > 0xffffffffll ? 0xffffffffu : (uint32_t)lmin;
+    if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
+    if (lead >= 16 && lead <= 512) c.lead_override = (int)(lead / 16 * 16);
+    return c;
+}
+EvSegConfig event_seg_config() {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    if (!g_seg_cfg_set) {
+        // development / tests: short segments put seams into ordinary reads, a short warm-up makes speculation fail
+        const char *e1 = getenv("SGK_EVENT_SEG"), *e2 = getenv("SGK_EVENT_LONG_MIN"), *e3 = getenv("SGK_EVENT_LEAD");
+        g_seg_cfg = seg_config_checked(e1 ? atoll(e1) : 0, e2 ? atoll(e2) : 0, e3 ? atol(e3) : 0);
+        g_seg_cfg_set = true;
+    }
+    return g_seg_cfg;
+}
+void event_seg_configure(long long seg, long long lmin, long lead) {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    g_seg_cfg = seg_config_checked(seg, lmin, lead);
+    g_seg_cfg_set = true;
+}
+
+void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
+                        uint32_t &max_long) {
+    const EvSegConfig c = event_seg_config();
+    max_segs = 0;
+    max_long = 0;
+    if (max_read_len < c.long_min) return;
+    uint64_t nl = n_samples / c.long_min;
+    if (nl > n_reads) nl = n_reads;
+    if (nl < 1) nl = 1;
+    const uint64_t ns = n_samples / c.seg_len + nl;  // sum of ceil(n_r / seg_len) over at most nl reads
+    max_segs = ns > 0x7fffffffull ? 0x7fffffffu : (uint32_t)ns;
+    // every long read has at least two segments; k_seg_plan admits long reads while their segments fit
+    uint64_t ml = max_segs / 2;
+    if (ml < nl) ml = nl;
+    if (ml > n_reads) ml = n_reads;
+    max_long = (uint32_t)ml;
+}
+
 EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, size_t available) {
     EvWorkspace w;
     const uint64_t nr = n_reads ? n_reads : 1;
@@ -63,6 +111,10 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.off_list = o;    o += round_up(nr * 4, 64);
     w.off_order = o;   o += round_up(nr * 4 + 128 * 4, 64);
     w.off_bitmap = o;  o += round_up((n_samples / 64 + nr + 2) * 8, 64);
+    event_seg_capacity(n_reads, n_samples, max_read_len, w.max_segs, w.max_long);
+    w.off_segs = o;       o += round_up((size_t)w.max_segs * sizeof(SegDesc), 64);
+    w.off_seg_state = o;  o += round_up((size_t)w.max_segs * sizeof(SegState), 64);
+    w.off_longs = o;      o += round_up((size_t)w.max_long * sizeof(LongRead), 64);
     w.off_scratch = o;
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
     const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
@@ -129,6 +181,15 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.bitmap = reinterpret_cast<unsigned long long *>(base + w.off_bitmap);
     a.scratch = reinterpret_cast<double *>(base + w.off_scratch);
     a.scratch_stride = w.scratch_stride;
+    const EvSegConfig sc = event_seg_config();
+    a.max_segs = w.max_segs;
+    a.max_long = w.max_long;
+    a.seg_len = sc.seg_len;
+    a.long_min = sc.long_min;
+    a.lead_override = sc.lead_override;
+    a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
+    a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
+    a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -256,7 +317,16 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     out->n_capacity_overflow = h.n_overflow;
     out->n_long_replays = h.n_hot_runs;
     out->n_events_total = h.n_events_total;
+    out->n_split_reads = h.n_long;   // (reads k_seg_plan could not place count here and under n_fallback_reads)
+    out->n_segments = h.n_segs;
+    out->n_seam_reruns = h.n_seam_rerun;
+    out->reserved = 0;
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
+}
+
+int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead) {
+    sgk::event_seg_configure(seg_len, long_min, lead);
+    return SGK_OK;
 }
 
 // diagnostics (not part of the stable ABI): t-statistic evaluations redone by the exact path

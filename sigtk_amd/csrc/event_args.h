@@ -11,9 +11,56 @@ struct EvHeader {
     uint32_t fb_next;     // work counter of the persistent fallback kernel
     unsigned long long n_events_total;
     uint32_t n_hot_runs;  // lanes that replayed long-detector runs exactly (lazy long detector)
-    uint32_t pad[9];
+    uint32_t n_long;      // reads taken by several wavefronts (segments), see SegDesc
+    uint32_t n_segs;      // their segments
+    uint32_t n_seam_rerun;  // segments whose speculative start was wrong and that were run again from the true state
+    uint32_t pad[6];
 };
 static_assert(sizeof(EvHeader) == 64, "header is one 64-byte block");
+
+// ---- reads longer than one wavefront should take (round 3) ----------------------------------------------------
+// A read of at least `long_min` samples is cut into segments of `seg_len` samples (a multiple of 1024), one wavefront
+// each: the same speculative scheme that lets the 64 lanes of a wave start in the middle of a read lets a wave do
+// so.  Segment g > 0 starts its first lane `lead` samples early from the fresh state; the state it reaches at the
+// segment's first index must equal the state segment g-1 ended with (k_event_seam checks, and runs a segment whose
+// speculation failed again from the true state).  The builder then runs per segment as well, from the last boundary
+// in front of the segment, at the event rank the segments in front of it determine.
+struct LzSnapState {  // detector state at an index, absolute (read-relative) positions: what chunks and segments hand over
+    int sp;         // short peak_pos, -1 when not in a peak
+    float sv;       // short peak_value
+    int lm;         // long masked_to (= short peak_pos at the last reset + W1), LZ_NONE when it no longer masks
+    int r0;         // index of the last reset of the long detector (pass start of a speculative pass)
+    uint32_t bits;  // 1: in a peak, 2: valid, 4: strong, 8: hot (long run since r0 needs the exact replay)
+};
+struct LzRun {
+    int a, b;  // exact replay of the long detector over [a, b) from the fresh state
+};
+constexpr int SEG_CROSS_MAX = 31;
+constexpr uint32_t SEG_NONE = 0xffffffffu;
+struct SegDesc {
+    uint32_t read;   // read index in the batch (SEG_NONE: an entry nobody owns, see k_seg_plan)
+    uint32_t g;      // segment index within the read
+    uint32_t lread;  // index into the long-read list
+    uint32_t pad;
+};
+struct SegState {           // 320 bytes per segment
+    LzSnapState init0;      // state the speculative first lane reached at the segment's first index (g > 0)
+    LzSnapState end;        // state at the segment's end
+    int status;             // detect_span's return code (non-zero: the read goes to the exact fallback)
+    uint32_t n_cross;       // hot long-detector runs that begin in front of the segment: replayed by k_event_seam
+    LzRun cross[SEG_CROSS_MAX];
+    // k_event_seg_count: the segment's boundary bits
+    uint32_t cnt;           // how many
+    int last;               // the last one (-1: none)
+    // builder outputs
+    uint32_t ext_lo, ext_hi;  // extremes of the samples walked: raw int16 (as int) or float bit patterns
+    uint32_t bflags;          // 1: a tile with more boundaries than the builder records, 2: event slots overflowed
+    uint32_t pad;
+};
+static_assert(sizeof(SegState) == 320, "SegState layout");
+struct LongRead {
+    uint32_t read, seg0, nseg, pad;
+};
 
 struct EvArgs {
     const void *samples;            // int16 or float, packed
@@ -33,11 +80,28 @@ struct EvArgs {
     double *scratch;                // fallback: per block scratch_stride doubles
     uint64_t scratch_stride;        // 2 * (max_read_len + 1), rounded up to even
     uint32_t *order;                // n_reads + 128: workgroup i of k_event takes read order[i] (longest first)
+    // long reads (max_segs == 0: none in this batch, nothing below is used)
+    uint32_t max_segs, max_long;    // capacities, from the batch's totals (event_seg_capacity)
+    uint32_t seg_len, long_min;
+    int lead_override;              // > 0: speculative warm-up in samples (tests: a short one makes speculation fail)
+    SegDesc *segs;
+    SegState *seg_state;
+    LongRead *longs;
 };
+
+struct EvSegConfig {
+    uint32_t seg_len, long_min;
+    int lead_override;
+};
+EvSegConfig event_seg_config();  // defaults, or SGK_EVENT_SEG / SGK_EVENT_LONG_MIN / SGK_EVENT_LEAD from the environment
+void event_seg_configure(long long seg, long long lmin, long lead);
+void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
+                        uint32_t &max_long);
 
 // workspace carving shared by sgk_event_workspace_bytes and sgk_event
 struct EvWorkspace {
-    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_scratch, total;
+    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_segs, off_seg_state, off_longs, off_scratch, total;
+    uint32_t max_segs, max_long;
     uint64_t scratch_stride;
     uint32_t n_fb_blocks;
 };

@@ -328,14 +328,7 @@ constexpr int LZ_NONE = -(1 << 29);   // "no mask" / far in the past (block-rela
 constexpr int LZ_NREC = 8;            // hot long-detector runs a lane can record per pass (more: read -> exact fallback)
 constexpr int LZ_RING_WORDS = 16;     // per-lane bitmap ring: 512 positions
 
-// detector state at a block boundary, absolute (read-relative) positions: what chunks hand over / compare
-struct LzSnapState {
-    int sp;         // short peak_pos, -1 when not in a peak
-    float sv;       // short peak_value
-    int lm;         // long masked_to (= short peak_pos at the last reset + W1), LZ_NONE when it no longer masks
-    int r0;         // index of the last reset of the long detector (pass start of a speculative pass)
-    uint32_t bits;  // 1: in a peak, 2: valid, 4: strong, 8: hot (long run since r0 needs the exact replay)
-};
+// detector state at a block boundary: LzSnapState (event_args.h), what chunks hand over / compare
 struct LzSnap {
     LzSnapState init[64];  // state a chunk's accepted run started from (at its chunk start)
     LzSnapState at_e[64];  // state at the chunk end
@@ -345,9 +338,6 @@ __device__ inline bool lz_equal(const LzSnapState &a, const LzSnapState &b) {
     return a.sp == b.sp && __float_as_int(a.sv) == __float_as_int(b.sv) && a.lm == b.lm && a.r0 == b.r0 &&
            a.bits == b.bits;
 }
-struct LzRun {
-    int a, b;  // exact replay of the long detector over [a, b) from the fresh state
-};
 struct LzLds {
     uint32_t ring[64][LZ_RING_WORDS];
     LzSnap snap;
@@ -840,14 +830,15 @@ __device__ __forceinline__ void lz_flush(uint32_t *ring, unsigned long long *bm,
 }
 
 // One pass of the lazy detector over the wave's chunks.
-//   first  : the first pass (every lane starts from the fresh state: true for lane 0, speculative for the others);
-//            otherwise a re-run of the lanes whose speculation failed, from snap.st0
-//   lead   : this lane's warm-up before its chunk start s (0 for lane 0 and in re-runs)
+//   given  : (per lane) this lane starts from snap.st0 -- the true state at its first index: a re-run of a lane whose
+//            speculation failed, or the first lane of a segment that is run from a known state; the other lanes
+//            start from the fresh state (true for the first lane of a read, speculative elsewhere)
+//   lead   : this lane's warm-up before its chunk start s (0 for a lane that starts from a true state)
 //   steps  : indices every lane runs (wave-uniform: warm-up + chunk length)
 //   active : whether this lane runs in this pass
 // Writes the lane's bitmap words, its hot-run records and (speculative pass) snap.init / snap.at_e.
 template <int W1, typename T, bool FLAGGED>
-__device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool first, int lead, int steps, bool active, int s,
+__device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int lead, int steps, bool active, int s,
                                           int e, LzLds *L, const RepairCtx *rep) {
     using LP = LazyPass<W1, T, FLAGGED>;
     constexpr int W2 = LP::W2, R = LP::R;
@@ -905,8 +896,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool first, int 
     f.bw = 0u;
     f.lm = LZ_NONE;
     f.r0 = 0;  // the (pseudo) reset a speculative pass starts from; index 0 for lane 0
-    if (!first) {
-        const LzSnapState st = L->snap.st0[l];
+    if (__any(given)) {
+        LzSnapState st = L->snap.st0[l];
+        if (!given) { st.sp = -1; st.sv = FLT_MAX; st.lm = LZ_NONE; st.r0 = i_begin; st.bits = 0u; }  // fresh
         f.sv = st.sv;
         f.inpk = __ballot((st.bits & 1u) != 0u);
         f.val = __ballot((st.bits & 2u) != 0u);
@@ -998,82 +990,111 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool first, int 
     if (active) L->nrec[l] = f.nrec;
 }
 
-// Exact replay of the long detector (events.c:383-440, k = 1) over the recorded hot runs: from the fresh state a
-// reset leaves, over the indices of the run (inside a run masked_to does not change and every index is processed).
+// Exact replay of the long detector (events.c:383-440, k = 1) over one hot run per lane: from the fresh state a
+// reset leaves, over the indices [i, b) of the run (inside a run masked_to does not change and every index is
+// processed).  Peaks are ORed into the read's bitmap if they lie in [bits_lo, bits_hi).
 template <int W1, typename T, bool FLAGGED>
-__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active) {
+__device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has, int i, int b, int bits_lo,
+                           int bits_hi) {
     constexpr int W2 = 2 * W1;
     constexpr float ph = DetParam<W1>::ph, thr2 = DetParam<W1>::thr2;
-    const int l = lane_id();
     const int n = (int)rc.n;
     const unsigned cnt2 = (n - 2 * W2 + 1) > 0 ? (unsigned)(n - 2 * W2 + 1) : 0u;
-    const int nrec = active ? L->nrec[l] : 0;
     uint32_t *bm32 = reinterpret_cast<uint32_t *>(rc.bm);
-    for (int k = 0; k < LZ_NREC; ++k) {
-        const bool has = k < nrec;
-        if (!__any(has)) break;
-        int i = has ? L->runs[l][k].a : 0;
-        const int b = has ? L->runs[l][k].b : 0;
-        int lp = -1;
-        float lv = FLT_MAX;
-        bool lvalid = false;
-        while (__any(has && i < b)) {
-            if (has && i < b) {
-                float v2 = 0.0f;
-                if ((unsigned)(i - W2) < cnt2) {
-                    if constexpr (FLAGGED) v2 = tstat_prefix_at(rep->P, rep->P2, i, W2);
-                    else v2 = tstat_exact_at<T>(rc.base, rc.sc, i, W2);
-                }
-                if (lp < 0) {
-                    if (v2 < lv) {
-                        lv = v2;
-                    } else if (v2 - lv > ph) {
-                        lv = v2;
-                        lp = i;
-                    }
-                } else {
-                    if (v2 > lv) {
-                        lv = v2;
-                        lp = i;
-                    }
-                    if (lv - v2 > ph && lv > thr2) lvalid = true;
-                    if (lvalid && (i - lp) > W2 / 2) {
-                        if (lp > 0 && lp < n) atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
-                        lp = -1;
-                        lv = v2;
-                        lvalid = false;
-                    }
-                }
-                ++i;
+    int lp = -1;
+    float lv = FLT_MAX;
+    bool lvalid = false;
+    while (__any(has && i < b)) {
+        if (has && i < b) {
+            float v2 = 0.0f;
+            if ((unsigned)(i - W2) < cnt2) {
+                if constexpr (FLAGGED) v2 = tstat_prefix_at(rep->P, rep->P2, i, W2);
+                else v2 = tstat_exact_at<T>(rc.base, rc.sc, i, W2);
             }
+            if (lp < 0) {
+                if (v2 < lv) {
+                    lv = v2;
+                } else if (v2 - lv > ph) {
+                    lv = v2;
+                    lp = i;
+                }
+            } else {
+                if (v2 > lv) {
+                    lv = v2;
+                    lp = i;
+                }
+                if (lv - v2 > ph && lv > thr2) lvalid = true;
+                if (lvalid && (i - lp) > W2 / 2) {
+                    if (lp > 0 && lp < n && lp >= bits_lo && lp < bits_hi) atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
+                    lp = -1;
+                    lv = v2;
+                    lvalid = false;
+                }
+            }
+            ++i;
         }
     }
 }
-
-// speculative pass + verification / re-run loop + replay of the hot long-detector runs.
-// Returns 0 when the read is done, 1 when the fast pass cannot take it (alignment / room around the read), 2 when
-// a lane met more hot runs than it can record (pathological signal: constant stretches, tiny variances).
+// ... over the recorded hot runs of the wave's lanes.  bits_lo: first index of the span this wave owns (a run that
+// began in front of it leaves its peaks in front of the span to whoever replays the span's cross runs)
 template <int W1, typename T, bool FLAGGED>
-__device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep) {
+__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active, int bits_lo) {
+    const int l = lane_id();
+    const int nrec = active ? L->nrec[l] : 0;
+    for (int k = 0; k < LZ_NREC; ++k) {
+        const bool has = k < nrec;
+        if (!__any(has)) break;
+        const int i = has ? L->runs[l][k].a : 0;
+        const int b = has ? L->runs[l][k].b : 0;
+        replay_run<W1, T, FLAGGED>(rc, rep, has, i, b, bits_lo, 0x7fffffff);
+    }
+}
+
+// speculative pass + verification / re-run loop + replay of the hot long-detector runs over the span [a, b) of a read
+// (a multiple of 16; the whole read: a = 0, b = n).
+//   mode 0: the state at a is the fresh one (a = 0: the read's start)
+//   mode 1: unknown: the first lane warms up in front of a like every other lane; the state it reached at a is
+//           left in seg->init0 for the owner of the span in front to compare (k_event_seam)
+//   mode 2: the state at a is L->snap.st0[0], put there by the caller
+// seg (spans of a read that several waves share; null otherwise) receives the state at b and the hot runs that began
+// in front of a.
+// Returns 0 when the span is done, 1 when the fast pass cannot take the read (alignment / room around the read), 2
+// when a lane met more hot runs than it can record (pathological signal: constant stretches, tiny variances).
+template <int W1, typename T, bool FLAGGED>
+__device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep,
+                                           const int a, const int b, const int mode, const int lead_override,
+                                           SegState *seg) {
     const int n = (int)rc.n;
-    if (n <= 0) return 0;
+    if (b <= a) return 0;
     // speculative warm-up before every chunk.  RNA events are ~5x longer, so the automata converge later: with 64
     // samples ~1.4 % of the chunk boundaries need a re-run, with 256 about 0.002 %.  A re-run costs the wave one
     // more pass over a chunk (K samples), the warm-up costs `lead` samples per lane: short reads (small K) are
     // better off with a short warm-up and the occasional re-run, long reads with a long one.
     // (DNA, long reads: 32 samples were tried: 6 re-runs per 640 000 chunk boundaries of the benchmark, no gain.)
-    int lead = n < 32768 ? SGK_LEAD_DNA_SHORT : SGK_LEAD_DNA;
-    if (W1 == 7) lead = n <= 32768 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_RNA;
+    const int len = b - a;
+    int lead = len < 32768 ? SGK_LEAD_DNA_SHORT : SGK_LEAD_DNA;
+    if (W1 == 7) lead = len <= 32768 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_RNA;
+    if (lead_override > 0) lead = lead_override;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 16 readable samples behind the
     // read; other reads take the exact fallback
     if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.hi < (int64_t)n + 16) return 1;
-    const int K = chunk_len_fast(n, lead);
     const int c = lane_id();
+    int K, s, e0, lead_c;
+    if (mode == 1) {
+        // every lane warms up: lane c owns [a + cK, a + (c+1)K)
+        K = 16 * ((len + 1023) / 1024);
+        s = a + c * K;
+        e0 = s + K;
+        lead_c = lead;
+    } else {
+        K = chunk_len_fast(len, lead);
+        s = c == 0 ? a : a + c * K + lead;
+        e0 = c == 0 ? a + lead + K : s + K;
+        lead_c = c > 0 ? lead : 0;
+    }
     const int TT = lead + K;
-    const int s = c == 0 ? 0 : c * K + lead;
-    const int e0 = c == 0 ? TT : s + K;
-    const int e = e0 < n ? e0 : n;
-    const bool active = s < n;
+    const int e = e0 < b ? e0 : b;
+    const bool active = s < b;
     {
         LzSnapState z;
         z.sp = -1; z.sv = FLT_MAX; z.lm = LZ_NONE; z.r0 = 0; z.bits = 0u;
@@ -1084,7 +1105,8 @@ __device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, c
     bool run = active;
     bool first = true;
     for (int iter = 0; iter < 66; ++iter) {
-        pass_lazy<W1, T, FLAGGED>(rc, first, (first && c > 0) ? lead : 0, first ? TT : K, run, s, e, L, rep);
+        pass_lazy<W1, T, FLAGGED>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : K, run, s, e,
+                                  L, rep);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
         const LzSnapState pe = L->snap.at_e[c > 0 ? c - 1 : 0];
@@ -1103,16 +1125,45 @@ __device__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, c
         __syncthreads();
     }
     if (__any(active && L->nrec[c] > LZ_NREC)) return 2;
+    int rcode = 0;
+    if (seg) {
+        // what the neighbours need: the states at both ends, the runs that began in front of the span
+        const int last = __popcll(__ballot(active)) - 1;
+        if (c == 0) {
+            seg->init0 = L->snap.init[0];
+            seg->end = L->snap.at_e[last];
+        }
+        const int nrec = active ? L->nrec[c] : 0;
+        int ncross = 0;
+        for (int k = 0; k < nrec; ++k) ncross += (L->runs[c][k].a < a) ? 1 : 0;
+        const int incl = wave_incl_scan_i(ncross);
+        const int total = wave_last_i(incl);
+        if (total > SEG_CROSS_MAX) rcode = 2;
+        else {
+            int at = incl - ncross;
+            for (int k = 0; k < nrec; ++k) {
+                if (L->runs[c][k].a < a) seg->cross[at++] = L->runs[c][k];
+            }
+        }
+        if (c == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
+    }
     const unsigned long long hotm = __ballot(active && L->nrec[c] > 0);
     if (hotm != 0ull) {
         if (c == 0) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
         __threadfence_block();
         __syncthreads();  // every lane's bitmap words are in memory before the replay ORs into them
 #ifndef SGK_EXP_NO_REPLAY
-        replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active);
+        replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active, a);
 #endif
     }
-    return 0;
+    return rcode;
+}
+// one wave, one read
+template <int W1, typename T, bool FLAGGED>
+__device__ __forceinline__ int detect_read_lazy(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep) {
+    const int n = (int)rc.n;
+    if (n <= 0) return 0;
+    return detect_span<W1, T, FLAGGED>(rc, hdr, L, rep, 0, n, 0, 0, nullptr);
 }
 
 __device__ inline bool guard_ok(float mn, float mx, int64_t n) {
@@ -1265,8 +1316,14 @@ __device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, in
     }
 }
 
-template <typename T>
-__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined) {
+// SEG: the wave builds the events of one segment [seg_a, seg_b) of a long read (several waves share the read): the
+// events that END at a boundary inside the segment, and the read's last event if the segment is the read's last.
+// It walks from the last boundary in front of the segment (prev_p; none: from the read's start), at the event rank the
+// boundaries in front give (cnt_before); extremes and flags go to st, the read's verdict is k_event_long_finish's.
+template <typename T, bool SEG = false>
+__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined,
+                           int64_t seg_a = 0, int64_t seg_b = 0, SegState *st = nullptr, uint32_t cnt_before = 0,
+                           int prev_p = -1) {
     const int64_t n = rc.n;
     const int l = lane_id();
     const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
@@ -1280,6 +1337,19 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     eo.cap = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
+    // SEG: bits in [bit_lo, bit_hi) count; the first of them (the boundary in front of the segment) ends no event of
+    // this segment: its record only starts the next one
+    int64_t bit_lo = 0, bit_hi = n, walk0 = 0;
+    uint32_t skip_rank = 0xffffffffu;
+    if constexpr (SEG) {
+        bit_hi = seg_b;
+        if (prev_p >= 0) {
+            bit_lo = prev_p;
+            walk0 = bit_lo & ~(int64_t)31;
+            rank = cnt_before - 1u;
+            skip_rank = rank;
+        }
+    }
     double Gprev = 0.0, G2prev = 0.0;  // prefix sums at the previous boundary, relative to the current tile start
     // exactness guard inputs: int16 reads track the extremes of the RAW samples (packed 16-bit min / max, two samples
     // per instruction); pA reads the extremes of the float bit patterns
@@ -1294,6 +1364,11 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         const int64_t rem = n - pos0;
         nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
         if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
+        if constexpr (SEG) {
+            const int64_t dl = bit_lo - pos0, dh = bit_hi - pos0;
+            if (dl > 0) bits = dl >= BT ? 0u : (bits & ~((1u << (int)dl) - 1u));
+            if (dh < BT) bits = dh <= 0 ? 0u : (bits & ((1u << (int)dh) - 1u));
+        }
         if (pos0 >= n) {
             // lanes behind the read's end (every read's last tile has some): nothing to load
 #pragma unroll
@@ -1312,14 +1387,14 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     T nbuf[BT];
     uint32_t nbits;
     int nnvalid;
-    load_tile(0, nbuf, nbits, nnvalid);
-    for (int64_t tb = 0; tb < n; tb += 64 * BT) {
+    load_tile(walk0, nbuf, nbits, nnvalid);
+    for (int64_t tb = walk0; tb < bit_hi; tb += 64 * BT) {
         T buf[BT];
 #pragma unroll
         for (int k = 0; k < BT; ++k) buf[k] = nbuf[k];
         const uint32_t bits = nbits;
         const int nvalid = nnvalid;
-        if (tb + 64 * BT < n) load_tile(tb + 64 * BT, nbuf, nbits, nnvalid);
+        if (tb + 64 * BT < bit_hi) load_tile(tb + 64 * BT, nbuf, nbits, nnvalid);
         const int cnt = __popc(bits);
         const int incl = wave_incl_scan_i(cnt);
         const int excl = incl - cnt;
@@ -1369,7 +1444,8 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             const double G2 = L->pt2[ln] + rcd.S2;
             const uint32_t pp = (uint32_t)wave_shr1_i((int)p, (int)prevp);
             const double Gp = wave_shr1_d(G, Gprev), G2p = wave_shr1_d(G2, G2prev);
-            if (act) store_event_fast(eo, rank + (uint32_t)k, pp, p, G - Gp, G2 - G2p, overflow);
+            if (act && (!SEG || rank + (uint32_t)k != skip_rank))
+                store_event_fast(eo, rank + (uint32_t)k, pp, p, G - Gp, G2 - G2p, overflow);
             const int last = (tot - k0) < 64 ? (tot - k0 - 1) : 63;  // wave-uniform
             prevp = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
             Gprev = readlane_d(G, last);
@@ -1392,7 +1468,8 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             rmn = o1 < rmn ? o1 : rmn;
             rmxv = o2 > rmxv ? o2 : rmxv;
         }
-        known = raw_extremes_to_pa(rmn, rmxv, rc.sc, mn, mx);
+        if constexpr (SEG) { mnb = (uint32_t)rmn; mxb = (uint32_t)rmxv; }
+        else known = raw_extremes_to_pa(rmn, rmxv, rc.sc, mn, mx);
     } else {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -1403,6 +1480,17 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
         mx = __uint_as_float(mxb);
         known = mxb < 0x7f800000u;
+    }
+    if constexpr (SEG) {
+        // the read's last segment closes the read's last event; the verdict on the read is k_event_long_finish's
+        if (l == 0 && seg_b == n) store_event_fast(eo, rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
+        const bool ovf = __any(overflow);
+        if (l == 0) {
+            st->ext_lo = mnb;
+            st->ext_hi = mxb;
+            st->bflags = (dense ? 1u : 0u) | (ovf ? 2u : 0u);
+        }
+        return;
     }
     const bool flagged = dense || !known || !guard_ok(mn, mx, n) || declined;
     if (l == 0) {
@@ -1584,14 +1672,78 @@ union EventLds {
     LzLds lz;
     BuildLds b;
 };
+// span of segment g of a read of n samples
+__device__ __forceinline__ void seg_span(const EvArgs &a, uint32_t g, int64_t n, int &sa, int &sb) {
+    const int64_t lo = (int64_t)g * a.seg_len, hi = lo + a.seg_len;
+    sa = (int)lo;
+    sb = (int)(hi < n ? hi : n);
+}
+
+// Long reads: the list of their segments (one thread per read; the order of the list does not matter).
+__global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const uint32_t n = a.lengths[r];
+    if (n < a.long_min) return;
+    const uint32_t G = (uint32_t)(((uint64_t)n + a.seg_len - 1) / a.seg_len);
+    const uint32_t s0 = atomicAdd(&a.hdr->n_segs, G), li = atomicAdd(&a.hdr->n_long, 1u);
+    // The capacities cover every batch of non-overlapping reads with these totals (event_seg_capacity).  A read that
+    // does not fit all the same (overlapping reads) is left to the exact fallback; what it took of the lists is marked
+    // as nobody's.
+    if ((uint64_t)s0 + G > a.max_segs || li >= a.max_long) {
+        for (uint64_t k = s0; k < (uint64_t)s0 + G && k < a.max_segs; ++k) a.segs[k].read = SEG_NONE;
+        if (li < a.max_long) {
+            LongRead none;
+            none.read = r; none.seg0 = 0; none.nseg = 0; none.pad = 0;
+            a.longs[li] = none;
+        }
+        a.flags[r] = 1;
+        a.flag_list[atomicAdd(&a.hdr->n_flagged, 1u)] = r;
+        return;
+    }
+    LongRead lr;
+    lr.read = r; lr.seg0 = s0; lr.nseg = G; lr.pad = 0;
+    a.longs[li] = lr;
+    for (uint32_t g = 0; g < G; ++g) {
+        SegDesc d;
+        d.read = r; d.g = g; d.lread = li; d.pad = 0;
+        a.segs[s0 + g] = d;
+    }
+}
+
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
     __shared__ EventLds L;
-    // reads are taken longest first (launch_order): a kernel cannot end before its longest read has, so that one
-    // should start first, not wherever it sits in the batch
-    const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    // The first max_segs workgroups take the segments of the long reads (detector only: k_event_seam checks the seams,
+    // k_event_build_seg builds; the segment list is usually much shorter than its capacity), the others one read each,
+    // longest first (launch_order): a kernel cannot end before its longest read has, so that one should start first,
+    // not wherever it sits in the batch.
+    const bool is_seg = blockIdx.x < a.max_segs;
+    uint32_t r, g = 0;
+    if (is_seg) {
+        if (blockIdx.x >= a.hdr->n_segs) return;
+        const SegDesc d = a.segs[blockIdx.x];
+        if (d.read == SEG_NONE) return;
+        r = d.read;
+        g = d.g;
+    } else {
+        const uint32_t bi = blockIdx.x - a.max_segs;
+        r = a.order ? a.order[bi] : bi;
+    }
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L.lz, nullptr);
+    int sa = 0, sb = (int)rc.n;
+    SegState *st = nullptr;
+    if (is_seg) {
+        seg_span(a, g, rc.n, sa, sb);
+        st = a.seg_state + blockIdx.x;
+    } else {
+        if (a.max_segs && rc.n >= (int64_t)a.long_min) return;  // taken by its segments
+    }
+    const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, sa, sb, g == 0 ? 0 : 1, a.lead_override, st);
+    if (is_seg) {
+        if (lane_id() == 0) st->status = rcode;
+        return;
+    }
     // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
     // them back.  Workgroup scope: the wave's own CU only -- an agent-scope release / acquire pair here writes back and
     // invalidates L2 once per read, which made 5 000-sample reads 1.7x slower than with two kernels.
@@ -1599,6 +1751,188 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     build_read<T>(a, rc, r, &L.b, rcode != 0);
+}
+
+// Long reads, after every segment's detector pass: one wave per long read
+//  1. walks the seams: segment g was right iff its speculative first lane reached, at the segment's first index, the
+//     state segment g-1 ended with; a segment that was not is run again from that state (and may change its own end);
+//  2. replays the hot long-detector runs that cross a seam for the part in front of the seam (the segment itself
+//     replayed the part behind it).
+template <int W1, typename T>
+__global__ __launch_bounds__(64) void k_event_seam(EvArgs a) {
+    __shared__ LzLds L;
+    const uint32_t nl = a.hdr->n_long;
+    if (blockIdx.x >= (nl < a.max_long ? nl : a.max_long)) return;
+    const LongRead lr = a.longs[blockIdx.x];
+    if (lr.nseg == 0) return;
+    const ReadCtx<T> rc = make_ctx<T>(a, lr.read);
+    SegState *st = a.seg_state + lr.seg0;
+    const int l = lane_id();
+    bool declined = false;
+    for (uint32_t g = l; g < lr.nseg; g += 64) declined = declined || st[g].status != 0;
+    declined = __any(declined);
+    for (uint32_t g = 1; g < lr.nseg && !declined; ++g) {
+        const LzSnapState pe = st[g - 1].end, mine = st[g].init0;
+        if (lz_equal(pe, mine)) continue;
+        int sa, sb;
+        seg_span(a, g, rc.n, sa, sb);
+        __syncthreads();
+        if (l == 0) {
+            L.snap.st0[0] = pe;
+            atomicAdd(&a.hdr->n_seam_rerun, 1u);
+        }
+        __syncthreads();
+        const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L, nullptr, sa, sb, 2, a.lead_override, st + g);
+        if (l == 0) {
+            st[g].status = rcode;
+            st[g].init0 = pe;
+        }
+        declined = rcode != 0;
+        __threadfence();
+        __syncthreads();
+    }
+    if (declined) {
+        if (l == 0) st[0].status = st[0].status ? st[0].status : 2;  // the whole read goes to the exact fallback
+        return;
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t g = 1; g < lr.nseg; ++g) {
+        const int nc = (int)st[g].n_cross;
+        if (nc == 0) continue;
+        int sa, sb;
+        seg_span(a, g, rc.n, sa, sb);
+        const bool has = l < nc;
+        const LzRun run = has ? st[g].cross[l] : LzRun{0, 0};
+        replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa);
+    }
+}
+
+// Long reads: the boundary bits of every segment (how many, and the last one), one wave per segment.  A segment starts
+// on a multiple of 1024: whole 64-bit bitmap words.
+template <typename T>
+__global__ __launch_bounds__(64) void k_event_seg_count(EvArgs a) {
+    if (blockIdx.x >= a.hdr->n_segs) return;
+    const SegDesc d = a.segs[blockIdx.x];
+    if (d.read == SEG_NONE) return;
+    const ReadCtx<T> rc = make_ctx<T>(a, d.read);
+    int sa, sb;
+    seg_span(a, d.g, rc.n, sa, sb);
+    const int l = lane_id();
+    const int w0 = sa >> 6, w1 = (sb + 63) >> 6;
+    int cnt = 0, last = -1;
+    for (int wb = w0; wb < w1; wb += 256) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = wb + 64 * k + l;
+            v[k] = w < w1 ? rc.bm[w] : 0ull;
+            const int rem = sb - (w << 6);
+            if (rem < 64) v[k] = rem <= 0 ? 0ull : (v[k] & ((1ull << rem) - 1ull));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (v[k]) {
+                cnt += __popcll(v[k]);
+                last = ((wb + 64 * k + l) << 6) + 63 - __clzll(v[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        cnt += __shfl_xor(cnt, dd, 64);
+        const int o = __shfl_xor(last, dd, 64);
+        last = o > last ? o : last;
+    }
+    if (l == 0) {
+        a.seg_state[blockIdx.x].cnt = (uint32_t)cnt;
+        a.seg_state[blockIdx.x].last = last;
+    }
+}
+
+// Long reads: the builder, one wave per segment.
+template <typename T>
+__global__ __launch_bounds__(64, 3) void k_event_build_seg(EvArgs a) {
+    __shared__ BuildLds L;
+    if (blockIdx.x >= a.hdr->n_segs) return;
+    const SegDesc d = a.segs[blockIdx.x];
+    if (d.read == SEG_NONE) return;
+    const LongRead lr = a.longs[d.lread];
+    const SegState *st0 = a.seg_state + lr.seg0;
+    if (st0[0].status != 0) return;  // declined: the fallback builds the read
+    const ReadCtx<T> rc = make_ctx<T>(a, d.read);
+    int sa, sb;
+    seg_span(a, d.g, rc.n, sa, sb);
+    // boundary bits in front of the segment: their number is the rank of the segment's first event, the last of them
+    // is where that event starts
+    uint32_t before = 0;
+    int prev = -1;
+    for (uint32_t g = lane_id(); g < d.g; g += 64) {
+        before += st0[g].cnt;
+        const int q = st0[g].last;
+        prev = q > prev ? q : prev;
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        before += (uint32_t)__shfl_xor((int)before, dd, 64);
+        const int o = __shfl_xor(prev, dd, 64);
+        prev = o > prev ? o : prev;
+    }
+    build_read<T, true>(a, rc, d.read, &L, false, sa, sb, a.seg_state + blockIdx.x, before, prev);
+}
+
+// Long reads: the read-level verdict (exactness guard over the whole read, counters), one thread per long read.
+template <typename T>
+__global__ __launch_bounds__(64) void k_event_long_finish(EvArgs a) {
+    const uint32_t li = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t nl = a.hdr->n_long;
+    if (li >= (nl < a.max_long ? nl : a.max_long)) return;
+    const LongRead lr = a.longs[li];
+    if (lr.nseg == 0) return;  // k_seg_plan sent the read to the fallback
+    const SegState *st = a.seg_state + lr.seg0;
+    const uint32_t r = lr.read;
+    const int64_t n = (int64_t)a.lengths[r];
+    bool flagged = st[0].status != 0, overflow = false;
+    if (!flagged) {
+        float mn, mx;
+        bool known;
+        uint32_t bf = 0, nev = 1;
+        if constexpr (std::is_same<T, int16_t>::value) {
+            int rmn = 32767, rmx = -32768;
+            for (uint32_t g = 0; g < lr.nseg; ++g) {
+                const int lo = (int)st[g].ext_lo, hi = (int)st[g].ext_hi;
+                rmn = lo < rmn ? lo : rmn;
+                rmx = hi > rmx ? hi : rmx;
+                bf |= st[g].bflags;
+                nev += st[g].cnt;
+            }
+            const Scale sc = make_scale(a.dig[r], a.off[r], a.rng[r]);
+            known = raw_extremes_to_pa(rmn, rmx, sc, mn, mx);
+        } else {
+            uint32_t mnb = 0xffffffffu, mxb = 0u;
+            for (uint32_t g = 0; g < lr.nseg; ++g) {
+                mnb = st[g].ext_lo < mnb ? st[g].ext_lo : mnb;
+                mxb = st[g].ext_hi > mxb ? st[g].ext_hi : mxb;
+                bf |= st[g].bflags;
+                nev += st[g].cnt;
+            }
+            mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
+            mx = __uint_as_float(mxb);
+            known = mxb < 0x7f800000u;
+        }
+        flagged = (bf & 1u) || !known || !guard_ok(mn, mx, n);
+        overflow = (bf & 2u) != 0u;
+        if (!flagged) {
+            a.n_events[r] = nev;
+            atomicAdd(&a.hdr->n_events_total, (unsigned long long)nev);
+            if (overflow) atomicAdd(&a.hdr->n_overflow, 1u);
+        }
+    }
+    a.flags[r] = flagged ? 1 : 0;
+    if (flagged) {
+        const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
+        a.flag_list[k] = r;
+    }
 }
 
 template <int W1, typename T>
@@ -1659,12 +1993,27 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         const int rc = launch_order(a.lengths, a.n_reads, a.order, a.order + a.n_reads, st);
         if (rc != SGK_OK) return rc;
     } else ao.order = nullptr;
+    if (ao.max_segs) hipLaunchKernelGGL(k_seg_plan, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, ao);
     {
         ProfScope ps("k_event", st);
-        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
-        else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
+    if (ao.max_segs) {
+        {
+            ProfScope ps("k_event_seam", st);
+            if (rna) hipLaunchKernelGGL((k_event_seam<7, T>), dim3(ao.max_long), dim3(64), 0, st, ao);
+            else hipLaunchKernelGGL((k_event_seam<3, T>), dim3(ao.max_long), dim3(64), 0, st, ao);
+            hipLaunchKernelGGL((k_event_seg_count<T>), dim3(ao.max_segs), dim3(64), 0, st, ao);
+        }
+        {
+            ProfScope ps("k_event_build_seg", st);
+            hipLaunchKernelGGL((k_event_build_seg<T>), dim3(ao.max_segs), dim3(64), 0, st, ao);
+            hipLaunchKernelGGL((k_event_long_finish<T>), dim3((ao.max_long + 63) / 64), dim3(64), 0, st, ao);
+        }
+        SGK_HIP_TRY(hipGetLastError());
+    }
 #else
     {
         ProfScope ps("k_event_detect", st);

@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--batches", type=int, default=0,
                     help="run exactly this many batches (the same work on every box) instead of a time box")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--segments", type=float, default=0.5,
+                    help="share of the batches whose event pass runs with short segments (reads shared by several "
+                         "wavefronts: sgk_event_configure) and, for a third of those, a warm-up short enough for "
+                         "speculation to fail at seams")
     a = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -28,9 +32,12 @@ def main():
     api.load_library()
     orc = Oracle()
     rs = np.random.RandomState(a.seed)
+    rs_cfg = np.random.RandomState(a.seed ^ 0x5E6)
     job = api.Job(0)
     t_end = time.time() + a.minutes * 60
-    stats = {"batches": 0, "reads": 0, "samples": 0, "fallback_reads": 0, "rerun_chunks": 0, "mismatches": []}
+    stats = {"batches": 0, "reads": 0, "samples": 0, "fallback_reads": 0, "rerun_chunks": 0, "split_reads": 0,
+             "segments": 0, "seam_reruns": 0, "mismatches": []}
+    L = api.load_library()
 
     def fail(msg):
         stats["mismatches"].append(msg)
@@ -67,11 +74,20 @@ def main():
         counts = [x.size for x in reads] if svb else None
         rna = kind if rs.rand() < 0.8 else 1 - kind
         pore = int(rs.choice([0, 2]))
-        tag = "batch %d (seed %d kind %d rna %d svb %d)" % (stats["batches"], seed, kind, rna, svb)
+        cfg = (0, 0, 0)   # (drawn from a stream of its own: tests/soak_replay.py regenerates the main one)
+        if rs_cfg.rand() < a.segments:
+            seg = int(rs_cfg.choice([1024, 2048, 3072, 8192, 32768]))
+            cfg = (seg, int(seg + 1 + rs_cfg.randint(0, 3 * seg)), int(rs_cfg.choice([0, 0, 16, 32])))
+        tag = "batch %d (seed %d kind %d rna %d svb %d segments %s)" % (stats["batches"], seed, kind, rna, svb, cfg)
 
         job.stage(sig, dig, off, rng, counts)
+        L.sgk_event_configure(*cfg)
         job.launch(api.TOOL_EVENT, rna=rna)
         res = job.wait()
+        L.sgk_event_configure(0, 0, 0)
+        stats["split_reads"] += int(res["status"].n_split_reads)
+        stats["segments"] += int(res["status"].n_segments)
+        stats["seam_reruns"] += int(res["status"].n_seam_reruns)
         stats["fallback_reads"] += int(res["status"].n_fallback_reads)
         stats["rerun_chunks"] += int(res["status"].n_rerun_passes)
         for r, raw in enumerate(reads):

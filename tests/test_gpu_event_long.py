@@ -1,0 +1,118 @@
+"""GPU parity: reads that several wavefronts share (segments), against the oracle (bit-exact).
+
+A read of at least `long_min` samples is cut into segments of `seg_len` samples; each segment's detector starts
+speculatively in front of the segment, k_event_seam compares the states at the seams (and runs a segment again when
+its speculation failed), replays the long-detector runs that cross a seam, and k_event_build_seg builds the events
+per segment.  sgk_event_configure() shrinks the segments so that ordinary test reads have hundreds of seams, and
+shortens the speculative warm-up so that speculation does fail.  Results must not depend on any of it.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_event import _check_events
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def configure(gpu):
+    L = gpu.load_library()
+
+    def f(seg, lmin, lead=0):
+        assert L.sgk_event_configure(seg, lmin, lead) == 0
+    yield f
+    L.sgk_event_configure(0, 0, 0)
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_long_reads_default_segments(gpu, oracle, rna):
+    lens = [700000, 300000, 262144, 262143, 100000, 50, 3000001]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=21 + rna, kind=rna)
+    got, st = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+    assert st.n_split_reads == 4 and st.n_segments == 6 + 3 + 2 + 23
+    assert st.n_capacity_overflow == 0 and st.n_fallback_reads == 0
+    assert st.n_events_total == sum(g.start.size for g in got)
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+@pytest.mark.parametrize("seg,lmin", [(1024, 1025), (4096, 10000), (2048, 2049)])
+def test_small_segments_on_the_fixture(gpu, oracle, sp1, configure, rna, seg, lmin):
+    recs = sp1.reads[:60]
+    reads = [r.raw for r in recs]
+    dig = np.array([r.digitisation for r in recs]); off = np.array([r.offset for r in recs])
+    rng = np.array([r.range for r in recs])
+    configure(seg, lmin)
+    got, st = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+    nlong = sum(1 for r in reads if r.size >= lmin)
+    assert st.n_split_reads == nlong and st.n_segments == sum(-(-r.size // seg) for r in reads if r.size >= lmin)
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_failed_speculation_at_seams_is_rerun(gpu, oracle, configure, rna):
+    """a 16-sample warm-up is too short for the automaton to converge: many seams (and chunk boundaries) disagree and
+    their segments are run again from the true state, some of them in a chain"""
+    lens = [40000, 33333, 2049, 2048, 4097, 100000, 12345, 20480]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=5 + rna, kind=rna)
+    configure(2048, 2049, 16)
+    got, st = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+    assert st.n_seam_reruns > 0 and st.n_rerun_passes > 0
+    configure(1024, 1025, 32)
+    got, st = gpu.event(reads, dig, off, rng, rna)
+    _check_events(oracle, reads, dig, off, rng, rna, got)
+
+
+def test_edge_signals_in_segments(gpu, oracle, configure):
+    """constant stretches (hot long-detector runs that cross seams, events longer than a segment), dense boundaries,
+    a read that fails the exactness guard in one segment only, full-range noise"""
+    rs = np.random.RandomState(3)
+    n = 30000
+    const = np.full(n, 500, dtype=np.int16)
+    steps = np.repeat(rs.randint(300, 700, size=n // 10), 10).astype(np.int16)
+    noise = rs.randint(-32768, 32767, size=n).astype(np.int16)
+    tiny = (rs.randint(400, 600, size=n)).astype(np.int16)
+    tiny[20001] = -9
+    zeros = np.zeros(n, dtype=np.int16)
+    dense = (np.repeat(np.tile([420, 610], n // 6 + 1), 3)[:n] + rs.randint(-2, 3, size=n)).astype(np.int16)
+    # long flat stretches between bursts: events that span several segments
+    flat = np.full(n, 480, dtype=np.int16)
+    for p in (100, 9000, 9003, 25000):
+        flat[p:p + 40] = rs.randint(300, 700, size=40)
+    ramp = (400 + (np.arange(n) // 1500) * 7 + rs.randint(-3, 4, size=n)).astype(np.int16)
+    reads = [const, steps, noise, tiny, zeros, dense, flat, ramp]
+    R = len(reads)
+    dig = np.full(R, 8192.0); off = np.array([10.0, 3.0, 0.0, 11.0, 0.0, 5.0, 6.0, 2.0]); rng = np.full(R, 1402.882324)
+    for seg, lmin, lead in ((1024, 1025, 0), (3072, 3073, 0), (2048, 2049, 16)):
+        configure(seg, lmin, lead)
+        for rna in (0, 1):
+            got, st = gpu.event(reads, dig, off, rng, rna)
+            _check_events(oracle, reads, dig, off, rng, rna, got)
+            assert st.n_fallback_reads >= 1
+
+
+def test_segments_device_api_layouts_and_capacity(gpu, oracle, configure):
+    """odd alignment (no fast path: the read's segments decline and the read takes the exact fallback), too few slots"""
+    from test_gpu_device_api import _run_layout
+    configure(2048, 2049)
+    reads, _, _, _ = gpu.synth_reads_host(3, [30000, 20000, 25000], seed=31, kind=0)
+    offsets = [0, 30001, 50008]
+    b, arena = _run_layout(gpu, oracle, reads, offsets, 75016, 0)
+    st = arena.status()
+    assert st.n_split_reads == 3 and st.n_fallback_reads >= 1 and st.n_capacity_overflow == 0
+    for r, raw in enumerate(reads):
+        exp = oracle.event_raw(raw, 8192.0, 7.0, 1402.882324, 0)
+        got = arena.read_events(r)
+        assert got.start.size == exp.start.size, "read %d" % r
+        assert np.array_equal(got.start.astype(np.uint64), exp.start)
+        assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+        assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+    b, arena = _run_layout(gpu, oracle, reads[:2], [256, 256 + 30016], 256 + 30016 + 20000 + 320, 0,
+                           slots_for=lambda n: 100)
+    st = arena.status()
+    assert st.n_capacity_overflow == 2
+    exp = oracle.event_raw(reads[0], 8192.0, 7.0, 1402.882324, 0)
+    assert int(arena.n_events[0].item()) == exp.start.size
+    got = arena.read_events(0)
+    assert np.array_equal(got.start[:100].astype(np.uint64), exp.start[:100])
