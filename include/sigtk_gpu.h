@@ -147,6 +147,7 @@ typedef struct sgk_event_status {
     uint32_t n_segments;         /* their segments                                         */
     uint32_t n_seam_reruns;      /* segments whose speculative start was wrong and that were run again */
     uint32_t reserved;
+    uint64_t n_replay_indices;   /* indices the exact replay of the long detector walked (diagnostic: one lane each) */
 } sgk_event_status_t;
 /* Tuning (process-wide; call it before sizing workspaces, not while an sgk_event call is being issued): a read of at
  * least `long_min` samples is cut into segments of `seg_len` samples (multiple of 1024), one wavefront each; `lead` is

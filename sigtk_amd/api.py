@@ -43,7 +43,7 @@ class EventStatus(C.Structure):
     _fields_ = [("n_fallback_reads", C.c_uint32), ("n_rerun_passes", C.c_uint32),
                 ("n_capacity_overflow", C.c_uint32), ("n_long_replays", C.c_uint32),
                 ("n_events_total", C.c_uint64), ("n_split_reads", C.c_uint32), ("n_segments", C.c_uint32),
-                ("n_seam_reruns", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_seam_reruns", C.c_uint32), ("reserved", C.c_uint32), ("n_replay_indices", C.c_uint64)]
 
 
 class EventsHost(C.Structure):

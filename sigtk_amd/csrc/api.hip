@@ -321,6 +321,7 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     out->n_segments = h.n_segs;
     out->n_seam_reruns = h.n_seam_rerun;
     out->reserved = 0;
+    out->n_replay_indices = h.n_replay_idx;
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
 }
 

@@ -14,7 +14,8 @@ struct EvHeader {
     uint32_t n_long;      // reads taken by several wavefronts (segments), see SegDesc
     uint32_t n_segs;      // their segments
     uint32_t n_seam_rerun;  // segments whose speculative start was wrong and that were run again from the true state
-    uint32_t pad[6];
+    unsigned long long n_replay_idx;  // indices the exact replay of the long detector walked (one lane each)
+    uint32_t pad[4];
 };
 static_assert(sizeof(EvHeader) == 64, "header is one 64-byte block");
 
@@ -29,13 +30,15 @@ struct LzSnapState {  // detector state at an index, absolute (read-relative) po
     int sp;         // short peak_pos, -1 when not in a peak
     float sv;       // short peak_value
     int lm;         // long masked_to (= short peak_pos at the last reset + W1), LZ_NONE when it no longer masks
-    int r0;         // index of the last reset of the long detector (pass start of a speculative pass)
+    int r0;         // first index of the long detector's current run: behind its last reset and behind the mask that
+                    // reset set (pass start of a speculative pass)
     uint32_t bits;  // 1: in a peak, 2: valid, 4: strong, 8: hot (long run since r0 needs the exact replay)
 };
 struct LzRun {
     int a, b;  // exact replay of the long detector over [a, b) from the fresh state
 };
-constexpr int SEG_CROSS_MAX = 31;
+constexpr int SEG_CROSS_MAX = 23;
+constexpr int SEG_PRE_MAX = 15;
 constexpr uint32_t SEG_NONE = 0xffffffffu;
 struct SegDesc {
     uint32_t read;   // read index in the batch (SEG_NONE: an entry nobody owns, see k_seg_plan)
@@ -49,6 +52,8 @@ struct SegState {           // 320 bytes per segment
     int status;             // detect_span's return code (non-zero: the read goes to the exact fallback)
     uint32_t n_cross;       // hot long-detector runs that begin in front of the segment: replayed by k_event_seam
     LzRun cross[SEG_CROSS_MAX];
+    uint32_t n_pre;         // peaks in front of the segment that were pending at its first index and emitted inside it
+    int pre[SEG_PRE_MAX];   // (their positions): k_event_seam sets the bits once the seam is verified
     // k_event_seg_count: the segment's boundary bits
     uint32_t cnt;           // how many
     int last;               // the last one (-1: none)

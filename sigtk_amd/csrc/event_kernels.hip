@@ -339,7 +339,7 @@ __device__ inline bool lz_equal(const LzSnapState &a, const LzSnapState &b) {
            a.bits == b.bits;
 }
 struct LzLds {
-    uint32_t ring[64][LZ_RING_WORDS];
+    uint32_t ring[64][LZ_RING_WORDS + 1];  // + one word: the lane's inherited emission (LZ_PRE, below)
     LzSnap snap;
     LzRun runs[64][LZ_NREC];
     int nrec[64];
@@ -457,10 +457,23 @@ __device__ __forceinline__ void repair_mark(const RepairCtx &rep, int &next_t, i
     next_t = nt;
 }
 
-// out of line (rare): a peak whose bitmap word may have left the lane's ring, or that lies before the pass
+// out of line (rare): a peak whose bitmap word may have left the lane's ring, or that lies in front of the lane's own
+// range [s, e).  A lane stops at e even if a peak is still pending there: the lane behind starts (verified) from the
+// same state and emits it -- a peak that lies in front of its own range.  If that happens inside its range (cur >=
+// own_lo), the lane INHERITED the peak with its start state and leaves the position in its ring's extra word (LZ_PRE):
+// detect_span sets the bit once the lane's start state is known to be the true one.  (At most one per pass: after the
+// emission every peak position lies inside the range.)  If it happens during the warm-up, the owner has emitted it.
+// (Round 2 let the OWNER run on until its pending peak was emitted; on a flat signal that is never, and every pass of
+// every lane walked to the end of the read: 5 s for a constant read of 75 000 samples.)
+constexpr int LZ_PRE = LZ_RING_WORDS;
 __device__ __attribute__((noinline)) void lz_emit_slow(uint32_t *ring, unsigned long long *bm, int flushed,
-                                                       int i_begin, int s, int e, int p) {
-    if (p >= flushed && p >= 0) {
+                                                       int i_begin, int s, int e, int p, int cur) {
+    const int own_lo = s - i_begin;
+    if (p < own_lo) {
+        if (cur >= own_lo) ring[LZ_PRE] = (uint32_t)(i_begin + p);
+        return;
+    }
+    if (p >= flushed) {
         atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
     } else {
         const int pa = i_begin + p;
@@ -657,7 +670,7 @@ struct LazyPass {
         if (SLOW && oldpeak) {
             // some lane holds a peak older than the bitmap ring reaches (or one from before the pass)
             if (lane_of(em)) {
-                lz_emit_slow(ring, bm, flushed, i_begin, s, e, jb + sp);
+                lz_emit_slow(ring, bm, flushed, i_begin, s, e, jb + sp, jb + u);
                 lm = sp;
                 r0 = u;
             }
@@ -861,6 +874,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
     f.i_begin = i_begin;
 #pragma unroll
     for (int k = 0; k < LZ_RING_WORDS; ++k) f.ring[k] = 0u;
+    if (active) f.ring[LZ_PRE] = 0xffffffffu;  // no inherited emission in this pass yet
 #pragma unroll
     for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.nk[k] = 0ull; f.hc[k] = 0ull; }
     {
@@ -936,7 +950,11 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         st.sv = f.sv;
         st.sp = ip ? ib + f.sp : -1;
         st.lm = (f.lm + W1 < 0) ? LZ_NONE : ib + f.lm + W1;  // normalised when it no longer masks
-        st.r0 = ib + f.r0;
+        // what the long detector's current run STARTS with: the first index behind the last reset that is not masked.
+        // (The reset index alone is not enough once the mask is normalised away: a lane that takes this state over
+        // would replay a hot run from the reset, through indices the mask hid from the reference's long detector --
+        // found by the soak with a 16-sample warm-up, tests/golden/soak_seed41_*.npz.)
+        st.r0 = ib + max(f.r0, f.lm + W1 + 1);
         st.bits = (ip ? 1u : 0u) | ((ip && lane_of(f.val)) ? 2u : 0u) | ((ip && lane_of(f.strong)) ? 4u : 0u) |
                   (lane_of(f.hot) ? 8u : 0u);
         return st;
@@ -951,8 +969,10 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         }
         // blocks that touch the read's last W1 indices (the statistic is defined as 0 there) or its end take the
         // predicated forms of the steps; so does a block in which some lane holds a peak older than the bitmap ring
+        // or one from in front of its own range
         const bool lane_edge = ib + R - 1 > n - W1;
-        const bool old_peak = f.sp < -(256 - 2 * R) || f.sp + jb < 0;
+        // (a peak in front of the lane's own range, in a block that reaches into the range: it may be emitted there)
+        const bool old_peak = f.sp < -(256 - 2 * R) || (f.sp + jb < own_lo && jb + R > own_lo);
         f.oldpeak = (__ballot(old_peak) & f.inpk & ~f.done) != 0ull;
         f.slow = f.oldpeak || (__ballot(lane_edge) & ~f.done) != 0ull;
         f.ib = ib;
@@ -973,9 +993,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             const int nb = i_begin + jb;  // first index of the next block
             if (active && lead > 0 && jb == lead) L->snap.init[l] = snapshot(nb);
             if (active && nb == e) L->snap.at_e[l] = snapshot(nb);
-            const bool pend = lane_of(f.inpk) && (nb + f.sp) < e;
-            // the reference's loop ends at n-1: peaks still pending there are dropped
-            f.done |= __ballot(nb >= e && (!pend || nb >= n));
+            // a lane stops at the end of its range; a peak still pending there is emitted by the lane behind
+            // (lz_emit_slow), and dropped at the read's end as in the reference, whose loop ends at n-1
+            f.done |= __ballot(nb >= e);
         }
         if (jb >= main_steps && f.done == ~0ull) break;
     }
@@ -995,7 +1015,8 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
 // processed).  Peaks are ORed into the read's bitmap if they lie in [bits_lo, bits_hi).
 template <int W1, typename T, bool FLAGGED>
 __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has, int i, int b, int bits_lo,
-                           int bits_hi) {
+                           int bits_hi, EvHeader *hdr) {
+    if (has && b > i) atomicAdd(&hdr->n_replay_idx, (unsigned long long)(b - i));
     constexpr int W2 = 2 * W1;
     constexpr float ph = DetParam<W1>::ph, thr2 = DetParam<W1>::thr2;
     const int n = (int)rc.n;
@@ -1038,7 +1059,8 @@ __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has,
 // ... over the recorded hot runs of the wave's lanes.  bits_lo: first index of the span this wave owns (a run that
 // began in front of it leaves its peaks in front of the span to whoever replays the span's cross runs)
 template <int W1, typename T, bool FLAGGED>
-__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active, int bits_lo) {
+__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active, int bits_lo,
+                                 EvHeader *hdr) {
     const int l = lane_id();
     const int nrec = active ? L->nrec[l] : 0;
     for (int k = 0; k < LZ_NREC; ++k) {
@@ -1046,7 +1068,7 @@ __device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx
         if (!__any(has)) break;
         const int i = has ? L->runs[l][k].a : 0;
         const int b = has ? L->runs[l][k].b : 0;
-        replay_run<W1, T, FLAGGED>(rc, rep, has, i, b, bits_lo, 0x7fffffff);
+        replay_run<W1, T, FLAGGED>(rc, rep, has, i, b, bits_lo, 0x7fffffff, hdr);
     }
 }
 
@@ -1101,6 +1123,7 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         L->snap.init[c] = z;
         L->snap.at_e[c] = z;
         L->nrec[c] = 0;
+        L->ring[c][LZ_PRE] = 0xffffffffu;
     }
     bool run = active;
     bool first = true;
@@ -1147,13 +1170,30 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         }
         if (c == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
     }
+    // inherited emissions (lz_emit_slow) of the lanes' accepted runs.  Inside the span the bit is set here; in front of
+    // it (another wave's words) only when nobody else is writing any more and the span's start state is the true one
+    // (mode 2: k_event_seam, one span at a time) -- a speculative span leaves them to k_event_seam (seg->pre).
+    const int pre = active ? (int)L->ring[c][LZ_PRE] : -1;
+    const bool pre_out = pre >= 0 && pre < a;
+    if (seg) {
+        const int npre = (mode == 1 && pre_out) ? 1 : 0;
+        const int incl = wave_incl_scan_i(npre);
+        const int total = wave_last_i(incl);
+        if (total > SEG_PRE_MAX) rcode = 2;
+        else if (npre) seg->pre[incl - 1] = pre;
+        if (c == 0) seg->n_pre = total > SEG_PRE_MAX ? 0u : (uint32_t)total;
+    }
     const unsigned long long hotm = __ballot(active && L->nrec[c] > 0);
-    if (hotm != 0ull) {
-        if (c == 0) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
+    const bool anypre = __any(pre >= 0);
+    if (hotm != 0ull || anypre) {
+        if (c == 0 && hotm != 0ull) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
         __threadfence_block();
-        __syncthreads();  // every lane's bitmap words are in memory before the replay ORs into them
+        __syncthreads();  // every lane's bitmap words are in memory before anything is ORed into them
+        if (pre >= 0 && (!pre_out || mode == 2)) {
+            atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
+        }
 #ifndef SGK_EXP_NO_REPLAY
-        replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active, a);
+        if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active, a, hdr);
 #endif
     }
     return rcode;
@@ -1804,7 +1844,15 @@ __global__ __launch_bounds__(64) void k_event_seam(EvArgs a) {
         seg_span(a, g, rc.n, sa, sb);
         const bool has = l < nc;
         const LzRun run = has ? st[g].cross[l] : LzRun{0, 0};
-        replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa);
+        replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr);
+    }
+    // peaks that were pending at a seam and emitted behind it
+    for (uint32_t g = 1; g < lr.nseg; ++g) {
+        const int np = (int)st[g].n_pre;
+        if (l < np) {
+            const int p = st[g].pre[l];
+            atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (p >> 5), 1u << (p & 31));
+        }
     }
 }
 

@@ -44,6 +44,8 @@ def main():
         print("MISMATCH", msg, flush=True)
 
     while (stats["batches"] < a.batches if a.batches else time.time() < t_end) and len(stats["mismatches"]) < 5:
+        if stats["batches"] % 500 == 0:
+            print("progress", json.dumps({k: v for k, v in stats.items() if k != "mismatches"}), flush=True)
         kind = int(rs.randint(0, 2))
         if rs.rand() < 0.1:   # many tiny reads: slot / offset arithmetic, reads shorter than every window
             nr = int(rs.randint(200, 2000))
@@ -80,10 +82,12 @@ def main():
             cfg = (seg, int(seg + 1 + rs_cfg.randint(0, 3 * seg)), int(rs_cfg.choice([0, 0, 16, 32])))
         tag = "batch %d (seed %d kind %d rna %d svb %d segments %s)" % (stats["batches"], seed, kind, rna, svb, cfg)
 
+        t_batch = time.time()
         job.stage(sig, dig, off, rng, counts)
         L.sgk_event_configure(*cfg)
         job.launch(api.TOOL_EVENT, rna=rna)
         res = job.wait()
+        t_event = time.time() - t_batch
         L.sgk_event_configure(0, 0, 0)
         stats["split_reads"] += int(res["status"].n_split_reads)
         stats["segments"] += int(res["status"].n_segments)
@@ -156,6 +160,9 @@ def main():
             good = (q["blobs"][r] == blow5.svb_zd_encode(e)) if svb_out else np.array_equal(q["samples"][r], e)
             if not good:
                 fail("%s qts read %d bits %d method %d svb_out %d" % (tag, r, bits, method, svb_out))
+        if time.time() - t_batch > 20.0:   # (mostly the oracle on a batch of long reads; the GPU part is printed beside it)
+            print("SLOW %s: %.1f s (event job %.2f s), %d reads, %d samples" % (tag, time.time() - t_batch, t_event, nr,
+                                                                               int(sum(lens))), flush=True)
         stats["batches"] += 1
         stats["reads"] += nr
         stats["samples"] += int(sum(lens))

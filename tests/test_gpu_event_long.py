@@ -116,3 +116,24 @@ def test_segments_device_api_layouts_and_capacity(gpu, oracle, configure):
     assert int(arena.n_events[0].item()) == exp.start.size
     got = arena.read_events(0)
     assert np.array_equal(got.start[:100].astype(np.uint64), exp.start[:100])
+
+
+@pytest.mark.parametrize("name,seg,lmin", [("soak_seed41_b3403_r1243.npz", 0, 0), ("soak_seed41_b4551_r8.npz", 2048, 7101),
+                                            ("soak_seed41_b4551_r8.npz", 0, 0)])
+def test_soak_regression_run_start_behind_the_mask(gpu, oracle, configure, name, seg, lmin):
+    """seed 41, batches 3403 (read 1243, 200 samples) and 4551 (read 8, 16 557 samples) of tests/soak_parity.py with a
+    16-sample warm-up, RNA parameters: a lane whose speculation failed takes its start state from the lane in front.
+    The state carried the index of the long detector's last reset but (normalised) not the mask that reset had set, so
+    a hot run that was open at the hand-over was replayed from the reset -- through indices the reference's long
+    detector never saw (a statistic of 9.47 two indices before the mask ended became a boundary).  The state now
+    carries the first index of the run.  With the presets' warm-ups a lane is re-run about once per 10^5 chunk
+    boundaries, which is why 11 million soak reads had not met it."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    raw = z["samples"].astype(np.int16)
+    dig, off, rng = z["dig"], z["off"], z["rng"]
+    configure(seg, lmin, 16)
+    for rna in (1, 0):
+        got, st = gpu.event([raw], dig, off, rng, rna)
+        _check_events(oracle, [raw], dig, off, rng, rna, got)
+        assert st.n_rerun_passes > 0 or rna == 0
