@@ -137,3 +137,25 @@ def test_soak_regression_run_start_behind_the_mask(gpu, oracle, configure, name,
         got, st = gpu.event([raw], dig, off, rng, rna)
         _check_events(oracle, [raw], dig, off, rng, rna, got)
         assert st.n_rerun_passes > 0 or rna == 0
+
+
+def test_flat_signal_costs_no_more_than_its_length(gpu, oracle, configure):
+    """seed 41, batch 1310, read 21 of tests/soak_parity.py: a constant read (raw 254, offset 0) of 75 651 samples with
+    RNA parameters.  The short detector enters a peak near the read's start that nothing ever emits; while the owner
+    of a pending peak had to run on until it was emitted, every pass of every lane walked to the end of the read: 5 s in
+    one wavefront, 150 s as 37 segments (every segment of a flat read is re-run: its long detector's run started at
+    the read's first index, which no speculative start can know)."""
+    import time
+    flat = np.full(75651, 254, dtype=np.int16)
+    other = np.full(33932, 174, dtype=np.int16)
+    reads = [flat, other]
+    dig = np.full(2, 8192.0); off = np.array([0.0, 13.0]); rng = np.array([1402.882324, -1402.882324])
+    gpu.event([flat[:4000]], dig[:1], off[:1], rng[:1], 1)   # (first call of the process: module load)
+    for seg, lmin in ((0, 0), (2048, 3287)):
+        configure(seg, lmin)
+        for rna in (1, 0):
+            t0 = time.time()
+            got, st = gpu.event(reads, dig, off, rng, rna)
+            dt = time.time() - t0
+            _check_events(oracle, reads, dig, off, rng, rna, got)
+            assert dt < 2.0, "flat reads took %.1f s (segments %d / %d, rna %d)" % (dt, seg, lmin, rna)
