@@ -234,6 +234,8 @@ def main():
                        "fallback_reads": int(st.n_fallback_reads) if st is not None else None,
                        "rerun_chunks": int(st.n_rerun_passes) if st is not None else None,
                        "long_detector_replays": int(st.n_long_replays) if st is not None else None,
+                       "long_detector_replay_indices": int(st.n_replay_indices) if st is not None else None,
+                       "split_reads": int(st.n_split_reads) if st is not None else None,
                        "parallelism": "reads sharded across ranks, no collective"},
             "parity_spot_check": parity,
             "roofline": roofline,

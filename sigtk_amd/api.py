@@ -93,7 +93,7 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_configure",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_configure", "sgk_event_configure_short",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
     "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
     "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
@@ -147,6 +147,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     L.sgk_event_configure.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
     L.sgk_event_configure.restype = C.c_int
+    if hasattr(L, "sgk_event_configure_short"):   # (absent from older builds selected with SIGTK_AMD_LIB for A/B runs)
+        L.sgk_event_configure_short.argtypes = [C.c_int]
+        L.sgk_event_configure_short.restype = C.c_int
     L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sgk_stat_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

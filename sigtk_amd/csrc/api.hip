@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "event_args.h"
+#include "stat_args.h"
 #include "host_util.h"
 #include "sgk_common.h"
 #include "synth.h"
@@ -66,7 +67,14 @@ static EvSegConfig seg_config_checked(long long seg, long long lmin, long lead) 
     if (lmin >= 1) c.long_min = lmin > 0xffffffffll ? 0xffffffffu : (uint32_t)lmin;
     if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
     if (lead >= 16 && lead <= 512) c.lead_override = (int)(lead / 16 * 16);
+    c.multi = 0;
     return c;
+}
+static int multi_checked(long v) {
+    if (v < 0) return -1;
+    int p = 1;
+    while (p * 2 <= v && p < 32) p *= 2;
+    return v == 0 ? 0 : p;
 }
 EvSegConfig event_seg_config() {
     std::lock_guard<std::mutex> lk(g_seg_mu);
@@ -74,14 +82,22 @@ EvSegConfig event_seg_config() {
         // development / tests: short segments put seams into ordinary reads, a short warm-up makes speculation fail
         const char *e1 = getenv("SGK_EVENT_SEG"), *e2 = getenv("SGK_EVENT_LONG_MIN"), *e3 = getenv("SGK_EVENT_LEAD");
         g_seg_cfg = seg_config_checked(e1 ? atoll(e1) : 0, e2 ? atoll(e2) : 0, e3 ? atol(e3) : 0);
+        if (const char *e4 = getenv("SGK_EVENT_MULTI")) g_seg_cfg.multi = multi_checked(atol(e4));
         g_seg_cfg_set = true;
     }
     return g_seg_cfg;
 }
 void event_seg_configure(long long seg, long long lmin, long lead) {
+    (void)event_seg_config();  // (the environment first)
     std::lock_guard<std::mutex> lk(g_seg_mu);
+    const int multi = g_seg_cfg.multi;
     g_seg_cfg = seg_config_checked(seg, lmin, lead);
-    g_seg_cfg_set = true;
+    g_seg_cfg.multi = multi;
+}
+void event_multi_configure(int lanes) {
+    (void)event_seg_config();
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    g_seg_cfg.multi = multi_checked(lanes);
 }
 
 void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
@@ -190,6 +206,23 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
     a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
     a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
+    // Short reads.  On all 64 lanes a 5 000-sample read spends more steps on warm-ups (lead per lane) than on its
+    // samples; k_event_multi gives a read fewer lanes and a wave several reads.  Worth it when the batch has enough
+    // reads to fill the GPU that way (>= 4 rounds of waves) -- a small batch wants every lane it can get.
+    a.multi_lanes = 0;
+    a.multi_max = 16384;
+    {
+        const uint64_t mean = n_samples / n_reads;
+        const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;
+        if (sc.multi >= 0 && mean < a.multi_max && (sorted || max_read_len < a.multi_max)) {
+            const uint32_t lead = sc.lead_override > 0 ? (uint32_t)sc.lead_override : (rna ? 128u : 32u);
+            uint32_t lanes = 1;
+            while (lanes < 64 && (uint64_t)lanes * 2 * 8 * lead <= mean) lanes *= 2;       // chunks of >= 8 warm-ups
+            while (lanes < 64 && (uint64_t)n_reads * lanes < 64ull * 4 * 3072) lanes *= 2;  // >= 4 rounds of waves
+            if (sc.multi > 0) lanes = (uint32_t)sc.multi;
+            if (lanes < 64) a.multi_lanes = lanes;
+        }
+    }
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -327,6 +360,10 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
 
 int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead) {
     sgk::event_seg_configure(seg_len, long_min, lead);
+    return SGK_OK;
+}
+int sgk_event_configure_short(int lanes_per_read) {
+    sgk::event_multi_configure(lanes_per_read);
     return SGK_OK;
 }
 

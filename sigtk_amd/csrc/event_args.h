@@ -92,14 +92,19 @@ struct EvArgs {
     SegDesc *segs;
     SegState *seg_state;
     LongRead *longs;
+    // short reads (multi_lanes == 0: every read has a wavefront of its own)
+    uint32_t multi_lanes;           // lanes per short read (a power of two below 64): k_event_multi packs 64 / lanes reads
+    uint32_t multi_max;             // reads shorter than this (a power of two) are short
 };
 
 struct EvSegConfig {
     uint32_t seg_len, long_min;
     int lead_override;
+    int multi;  // lanes per short read: 0 = chosen per batch, -1 = off (64 lanes per read), 1 .. 32 = forced
 };
 EvSegConfig event_seg_config();  // defaults, or SGK_EVENT_SEG / SGK_EVENT_LONG_MIN / SGK_EVENT_LEAD from the environment
 void event_seg_configure(long long seg, long long lmin, long lead);
+void event_multi_configure(int lanes);
 void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
                         uint32_t &max_long);
 

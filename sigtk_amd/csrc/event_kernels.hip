@@ -70,6 +70,12 @@ __device__ inline int chunk_len_fast(int n, int lead) {
     const int k = (m + 1023) / 1024;
     return 16 * (k < 1 ? 1 : k);
 }
+// ... when `lanes` lanes (a power of two) share the read instead of 64
+__device__ inline int chunk_len_lanes(int n, int lead, int lanes) {
+    const int m = n > lead ? n - lead : 1;
+    const int k = (m + 16 * lanes - 1) / (16 * lanes);
+    return 16 * (k < 1 ? 1 : k);
+}
 
 // ---------------------------------------------------------------- detector state
 struct DetState {
@@ -684,8 +690,9 @@ struct LazyPass {
             if (erare != 0ull) {
                 if (lane_of(erare)) {  // an older peak: undo the bit, set the right one (its word is in the ring)
                     bw &= ~bit;
-                    const int p = jb + sp;
-                    atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+                    const int p = jb + sp, own = s - i_begin;
+                    if (p >= own) atomicOr(&ring[(p >> 5) & (LZ_RING_WORDS - 1)], 1u << (p & 31));
+                    else if (jb >= own) ring[LZ_PRE] = (uint32_t)(i_begin + p);  // inherited, see lz_emit_slow
                 }
             }
         }
@@ -737,12 +744,16 @@ struct LazyPass {
         dstep_core<true>(U, t1[U & 3], hc[U & 3], live);
     }
     // the statistic is defined as 0 at the read's first / last W1 indices (events.c:332-338)
+    // ... and so is the long window's at the last W2: it cannot exceed thr2 there.  (Its window sums reach behind the
+    // read there -- whatever lies behind it made the long detector "hot" at the end of most short RNA reads, and each
+    // of them paid for an exact replay of its last run.)
     __device__ __forceinline__ void slow_fix(const int u0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool in1 = (unsigned)(ib + u0 + k - W1) < cnt1;
             t1[k] = in1 ? t1[k] : 0.0f;
             nk[k] &= __ballot(in1);
+            hc[k] &= __ballot((unsigned)(ib + u0 + k - W2) < cnt2);
         }
     }
 
@@ -954,7 +965,11 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         // (The reset index alone is not enough once the mask is normalised away: a lane that takes this state over
         // would replay a hot run from the reset, through indices the mask hid from the reference's long detector --
         // found by the soak with a 16-sample warm-up, tests/golden/soak_seed41_*.npz.)
+#ifdef SGK_EXP_OLD_R0
+        st.r0 = ib + f.r0;
+#else
         st.r0 = ib + max(f.r0, f.lm + W1 + 1);
+#endif
         st.bits = (ip ? 1u : 0u) | ((ip && lane_of(f.val)) ? 2u : 0u) | ((ip && lane_of(f.strong)) ? 4u : 0u) |
                   (lane_of(f.hot) ? 8u : 0u);
         return st;
@@ -967,12 +982,14 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             lz_flush(f.ring, f.bm, i_begin, jb - 512, own_lo, own_hi);
             f.flushed = jb - 256;
         }
-        // blocks that touch the read's last W1 indices (the statistic is defined as 0 there) or its end take the
+        // blocks that touch the read's last W2 indices (the statistics are defined as 0 there) or its end take the
         // predicated forms of the steps; so does a block in which some lane holds a peak older than the bitmap ring
         // or one from in front of its own range
-        const bool lane_edge = ib + R - 1 > n - W1;
-        // (a peak in front of the lane's own range, in a block that reaches into the range: it may be emitted there)
-        const bool old_peak = f.sp < -(256 - 2 * R) || (f.sp + jb < own_lo && jb + R > own_lo);
+        const bool lane_edge = ib + R - 1 > n - W2;
+        // (... or a peak in front of the lane's own range in the range's first block: it may be emitted there within
+        // w/2 indices, as a "usual" peak whose bit the fast steps would put into the bitmap word; in later blocks it is
+        // an "older peak", which the fast steps hand to the ring or, in front of the range, to LZ_PRE)
+        const bool old_peak = f.sp < -(256 - 2 * R) || (f.sp + jb < own_lo && jb == own_lo);
         f.oldpeak = (__ballot(old_peak) & f.inpk & ~f.done) != 0ull;
         f.slow = f.oldpeak || (__ballot(lane_edge) & ~f.done) != 0ull;
         f.ib = ib;
@@ -995,12 +1012,22 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             if (active && nb == e) L->snap.at_e[l] = snapshot(nb);
             // a lane stops at the end of its range; a peak still pending there is emitted by the lane behind
             // (lz_emit_slow), and dropped at the read's end as in the reference, whose loop ends at n-1
-            f.done |= __ballot(nb >= e);
+            const lmask_t reach = __ballot(nb >= e) & ~f.done;
+            // the run still open at the end of the read is replayed by the lane that holds the read's last index --
+            // recorded HERE: the lane may step on (other lanes of the wave have more to do, and in k_event_multi their
+            // reads are longer) through whatever lies behind the read, and its run bookkeeping with it
+            if ((reach & f.hot) != 0ull) {
+                if (lane_of(reach & f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, nb + max(f.r0, f.lm + W1 + 1), n, s, e, n);
+            }
+            f.done |= reach;
+            // ... and it steps on without the exact redo of uncertified statistics: whatever it decides from here on
+            // must not land in its own range.  Out of its peak, every position it can emit lies behind the range.
+            f.inpk &= ~reach;
+            f.val &= ~reach;
+            f.strong &= ~reach;
         }
         if (jb >= main_steps && f.done == ~0ull) break;
     }
-    // the run still open at the end of the read is replayed by the lane that holds the read's last index
-    if (active && lane_of(f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, i_begin + jb + max(f.r0, f.lm + W1 + 1), n, s, e, n);
     // remaining ring words (the current bitmap word first)
     {
         const int p = jb - LP::H1 - 2 < 0 ? 0 : jb - LP::H1 - 2;  // a position inside the word bw stands for
@@ -1082,12 +1109,17 @@ __device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx
 // in front of a.
 // Returns 0 when the span is done, 1 when the fast pass cannot take the read (alignment / room around the read), 2
 // when a lane met more hot runs than it can record (pathological signal: constant stretches, tiny variances).
-template <int W1, typename T, bool FLAGGED>
+//
+// MULTI (k_event_multi): the wave holds 64 / lanes reads, `lanes` consecutive lanes each (rc, b and the return code are
+// per lane; a = 0, mode 0, no seg): a short read on all 64 lanes spends more steps on warm-ups than on its samples.
+template <int W1, typename T, bool FLAGGED, bool MULTI = false>
 __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep,
                                            const int a, const int b, const int mode, const int lead_override,
-                                           SegState *seg) {
+                                           SegState *seg, const int lanes = 64) {
     const int n = (int)rc.n;
-    if (b <= a) return 0;
+    if constexpr (!MULTI) {
+        if (b <= a) return 0;
+    }
     // speculative warm-up before every chunk.  RNA events are ~5x longer, so the automata converge later: with 64
     // samples ~1.4 % of the chunk boundaries need a re-run, with 256 about 0.002 %.  A re-run costs the wave one
     // more pass over a chunk (K samples), the warm-up costs `lead` samples per lane: short reads (small K) are
@@ -1096,11 +1128,15 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
     const int len = b - a;
     int lead = len < 32768 ? SGK_LEAD_DNA_SHORT : SGK_LEAD_DNA;
     if (W1 == 7) lead = len <= 32768 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_RNA;
+    if constexpr (MULTI) lead = W1 == 7 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_DNA_SHORT;  // (every read of the wave is short)
     if (lead_override > 0) lead = lead_override;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 16 readable samples behind the
     // read; other reads take the exact fallback
-    if ((reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.hi < (int64_t)n + 16) return 1;
-    const int c = lane_id();
+    const bool no_fast = (reinterpret_cast<uintptr_t>(rc.base) & 3u) != 0 || rc.hi < (int64_t)n + 16;
+    if constexpr (!MULTI) {
+        if (no_fast) return 1;
+    }
+    const int c = MULTI ? (lane_id() & (lanes - 1)) : lane_id();  // lane within its read
     int K, s, e0, lead_c;
     if (mode == 1) {
         // every lane warms up: lane c owns [a + cK, a + (c+1)K)
@@ -1109,71 +1145,90 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         e0 = s + K;
         lead_c = lead;
     } else {
-        K = chunk_len_fast(len, lead);
+        K = MULTI ? chunk_len_lanes(len, lead, lanes) : chunk_len_fast(len, lead);
         s = c == 0 ? a : a + c * K + lead;
         e0 = c == 0 ? a + lead + K : s + K;
         lead_c = c > 0 ? lead : 0;
     }
-    const int TT = lead + K;
+    int TT = lead + K;
+    int Kmax = K;
+    if constexpr (MULTI) {  // the passes' step counts are the wave's: the longest of its reads
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(Kmax, d, 64);
+            Kmax = o > Kmax ? o : Kmax;
+        }
+        TT = lead + Kmax;
+    }
     const int e = e0 < b ? e0 : b;
-    const bool active = s < b;
+    const bool active = s < b && !(MULTI && no_fast);
     {
         LzSnapState z;
         z.sp = -1; z.sv = FLT_MAX; z.lm = LZ_NONE; z.r0 = 0; z.bits = 0u;
-        L->snap.init[c] = z;
-        L->snap.at_e[c] = z;
-        L->nrec[c] = 0;
-        L->ring[c][LZ_PRE] = 0xffffffffu;
+        L->snap.init[lane_id()] = z;
+        L->snap.at_e[lane_id()] = z;
+        L->nrec[lane_id()] = 0;
+        L->ring[lane_id()][LZ_PRE] = 0xffffffffu;
     }
     bool run = active;
     bool first = true;
+    const int l = lane_id();
     for (int iter = 0; iter < 66; ++iter) {
-        pass_lazy<W1, T, FLAGGED>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : K, run, s, e,
+        pass_lazy<W1, T, FLAGGED>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : Kmax, run, s, e,
                                   L, rep);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
-        const LzSnapState pe = L->snap.at_e[c > 0 ? c - 1 : 0];
-        const LzSnapState mine = L->snap.init[c];
+        const LzSnapState pe = L->snap.at_e[c > 0 ? l - 1 : l];
+        const LzSnapState mine = L->snap.init[l];
         const bool bad = active && c > 0 && !lz_equal(pe, mine);
         const unsigned long long badmask = __ballot(bad);
         if (badmask == 0ull) break;
         __syncthreads();
         if (bad) {
-            L->snap.init[c] = pe;
-            L->snap.st0[c] = pe;
+            L->snap.init[l] = pe;
+            L->snap.st0[l] = pe;
         }
         run = bad;
         first = false;
-        if (c == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
+        if (l == 0) atomicAdd(&hdr->n_rerun, (uint32_t)__popcll(badmask));
         __syncthreads();
     }
-    if (__any(active && L->nrec[c] > LZ_NREC)) return 2;
     int rcode = 0;
+    if constexpr (MULTI) {
+        // per read: the lanes of a read that cannot be taken here, or whose lanes met too many hot runs, stand aside
+        const unsigned long long over = __ballot(active && L->nrec[l] > LZ_NREC);
+        const unsigned long long grp = (lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull)) << (l & ~(lanes - 1));
+        if (no_fast) rcode = 1;
+        else if (over & grp) rcode = 2;
+    } else {
+        if (__any(active && L->nrec[l] > LZ_NREC)) return 2;
+    }
+    const bool mine_ok = active && rcode == 0;
     if (seg) {
         // what the neighbours need: the states at both ends, the runs that began in front of the span
         const int last = __popcll(__ballot(active)) - 1;
-        if (c == 0) {
+        if (l == 0) {
             seg->init0 = L->snap.init[0];
             seg->end = L->snap.at_e[last];
         }
-        const int nrec = active ? L->nrec[c] : 0;
+        const int nrec = active ? L->nrec[l] : 0;
         int ncross = 0;
-        for (int k = 0; k < nrec; ++k) ncross += (L->runs[c][k].a < a) ? 1 : 0;
+        for (int k = 0; k < nrec; ++k) ncross += (L->runs[l][k].a < a) ? 1 : 0;
         const int incl = wave_incl_scan_i(ncross);
         const int total = wave_last_i(incl);
         if (total > SEG_CROSS_MAX) rcode = 2;
         else {
             int at = incl - ncross;
             for (int k = 0; k < nrec; ++k) {
-                if (L->runs[c][k].a < a) seg->cross[at++] = L->runs[c][k];
+                if (L->runs[l][k].a < a) seg->cross[at++] = L->runs[l][k];
             }
         }
-        if (c == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
+        if (l == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
     }
     // inherited emissions (lz_emit_slow) of the lanes' accepted runs.  Inside the span the bit is set here; in front of
     // it (another wave's words) only when nobody else is writing any more and the span's start state is the true one
     // (mode 2: k_event_seam, one span at a time) -- a speculative span leaves them to k_event_seam (seg->pre).
-    const int pre = active ? (int)L->ring[c][LZ_PRE] : -1;
+    const int pre = mine_ok ? (int)L->ring[l][LZ_PRE] : -1;
     const bool pre_out = pre >= 0 && pre < a;
     if (seg) {
         const int npre = (mode == 1 && pre_out) ? 1 : 0;
@@ -1181,19 +1236,19 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         const int total = wave_last_i(incl);
         if (total > SEG_PRE_MAX) rcode = 2;
         else if (npre) seg->pre[incl - 1] = pre;
-        if (c == 0) seg->n_pre = total > SEG_PRE_MAX ? 0u : (uint32_t)total;
+        if (l == 0) seg->n_pre = total > SEG_PRE_MAX ? 0u : (uint32_t)total;
     }
-    const unsigned long long hotm = __ballot(active && L->nrec[c] > 0);
+    const unsigned long long hotm = __ballot(mine_ok && L->nrec[l] > 0);
     const bool anypre = __any(pre >= 0);
     if (hotm != 0ull || anypre) {
-        if (c == 0 && hotm != 0ull) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
+        if (l == 0 && hotm != 0ull) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
         __threadfence_block();
         __syncthreads();  // every lane's bitmap words are in memory before anything is ORed into them
         if (pre >= 0 && (!pre_out || mode == 2)) {
             atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
         }
 #ifndef SGK_EXP_NO_REPLAY
-        if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, active, a, hdr);
+        if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, mine_ok, a, hdr);
 #endif
     }
     return rcode;
@@ -1778,6 +1833,7 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
         st = a.seg_state + blockIdx.x;
     } else {
         if (a.max_segs && rc.n >= (int64_t)a.long_min) return;  // taken by its segments
+        if (a.multi_lanes && rc.n < (int64_t)a.multi_max) return;  // taken by k_event_multi
     }
     const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, sa, sb, g == 0 ? 0 : 1, a.lead_override, st);
     if (is_seg) {
@@ -1983,6 +2039,39 @@ __global__ __launch_bounds__(64) void k_event_long_finish(EvArgs a) {
     }
 }
 
+// Short reads, several per wavefront: `lanes` consecutive lanes share a read (detector: detect_span<MULTI>), then the
+// wave builds its reads one after the other.  The short reads are the tail of the dispatch order (launch_order sorts by
+// length class, longest first; multi_max is a class boundary) or, in a batch without an order, all reads.
+template <int W1, typename T>
+__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_multi(EvArgs a) {
+    __shared__ EventLds L;
+    const int lanes = (int)a.multi_lanes, G = 64 / lanes;
+    const int l = lane_id();
+    const uint32_t first = a.order ? a.order[a.n_reads + len_bucket(a.multi_max)] : 0u;  // reads that are not short
+    const uint32_t nshort = a.n_reads - first;
+    const uint32_t w0 = blockIdx.x * (uint32_t)G;
+    if (w0 >= nshort) return;
+    const uint32_t gi = (uint32_t)l / (uint32_t)lanes;
+    const bool has = w0 + gi < nshort;
+    const uint32_t idx = first + (has ? w0 + gi : w0);
+    const uint32_t r = a.order ? a.order[idx] : idx;
+    ReadCtx<T> rc = make_ctx<T>(a, r);
+    if (!has) rc.n = 0;
+    const int rcode = detect_span<W1, T, false, true>(rc, a.hdr, &L.lz, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr,
+                                                      lanes);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int g = 0; g < G; ++g) {
+        if (w0 + (uint32_t)g >= nshort) break;
+        const uint32_t rg = (uint32_t)__builtin_amdgcn_readlane((int)r, g * lanes);
+        const int code = __builtin_amdgcn_readlane(rcode, g * lanes);
+        const ReadCtx<T> rcg = make_ctx<T>(a, rg);
+        build_read<T>(a, rcg, rg, &L.b, code != 0);
+        __syncthreads();
+    }
+}
+
 template <int W1, typename T>
 __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
     __shared__ PrefixLds L;
@@ -2042,12 +2131,21 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         if (rc != SGK_OK) return rc;
     } else ao.order = nullptr;
     if (ao.max_segs) hipLaunchKernelGGL(k_seg_plan, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, ao);
-    {
+    const bool all_short = ao.multi_lanes && !ao.order;  // k_event would have nothing to do
+    if (!all_short) {
         ProfScope ps("k_event", st);
         if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
         else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
+    if (ao.multi_lanes) {
+        ProfScope ps("k_event_multi", st);
+        const uint32_t per_wave = 64u / ao.multi_lanes;
+        const uint32_t grid = (a.n_reads + per_wave - 1) / per_wave;
+        if (rna) hipLaunchKernelGGL((k_event_multi<7, T>), dim3(grid), dim3(64), 0, st, ao);
+        else hipLaunchKernelGGL((k_event_multi<3, T>), dim3(grid), dim3(64), 0, st, ao);
+        SGK_HIP_TRY(hipGetLastError());
+    }
     if (ao.max_segs) {
         {
             ProfScope ps("k_event_seam", st);

@@ -116,6 +116,13 @@ __device__ inline float wave_max_f(float v) {
     return v;
 }
 
+// length class of a read for the dispatch order (launch_order: counting sort into 128 classes, 4 per octave)
+__device__ inline uint32_t len_bucket(uint32_t n) {
+    if (n < 4u) return n;
+    const uint32_t e = 31u - (uint32_t)__clz((int)n);
+    return 4u * e + ((n >> (e - 2u)) & 3u);  // <= 127
+}
+
 // pA conversion, src/misc.c:26-28: (float)raw + offset, then * unit; never contracted
 // (the library is compiled with -ffp-contract=off).
 struct Scale {

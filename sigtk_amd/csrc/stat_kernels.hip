@@ -1910,11 +1910,6 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
 // ---------------------------------------------------------------- dispatch order of the wave-per-read kernels
 // A wave-per-read kernel cannot finish before its longest read has: reads are handed to the waves longest first
 // (workgroups start in index order), by a counting sort of the read lengths into 128 buckets (4 per octave).
-__device__ inline uint32_t len_bucket(uint32_t n) {
-    if (n < 4u) return n;
-    const uint32_t e = 31u - (uint32_t)__clz((int)n);
-    return 4u * e + ((n >> (e - 2u)) & 3u);  // <= 127
-}
 // (per-workgroup LDS histograms first: a batch of equal-length reads would otherwise send every atomic to one word)
 __global__ __launch_bounds__(256) void k_order_count(const uint32_t *lengths, uint32_t n, uint32_t *hist) {
     __shared__ uint32_t h[128];

@@ -85,10 +85,12 @@ def main():
         t_batch = time.time()
         job.stage(sig, dig, off, rng, counts)
         L.sgk_event_configure(*cfg)
+        L.sgk_event_configure_short(int(rs_cfg.choice([0, 0, -1, 1, 2, 4, 8, 16, 32])))   # lanes per short read
         job.launch(api.TOOL_EVENT, rna=rna)
         res = job.wait()
         t_event = time.time() - t_batch
         L.sgk_event_configure(0, 0, 0)
+        L.sgk_event_configure_short(0)
         stats["split_reads"] += int(res["status"].n_split_reads)
         stats["segments"] += int(res["status"].n_segments)
         stats["seam_reruns"] += int(res["status"].n_seam_reruns)
