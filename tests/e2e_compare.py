@@ -57,6 +57,22 @@ def main():
             out[name] = {"identical": g.stdout == r.stdout and g.returncode == 0, "sigtk_amd_s": round(tg, 3),
                          "reference_s": round(tr, 3), "stdout_mb": round(len(r.stdout) / 1e6, 1),
                          "stages": stages[0] if stages else None}
+            if r.returncode != 0:
+                # the reference died (it does on some inputs, e.g. ragged batches of very short RNA-like reads): compare
+                # the rows it completed
+                done = r.stdout[:r.stdout.rfind(b"\n") + 1]
+                out[name]["reference_rc"] = r.returncode
+                out[name]["reference_rows_completed"] = done.count(b"\n")
+                out[name]["identical_on_completed_rows"] = g.stdout.startswith(done)
+            if g.stdout != r.stdout:   # where: the first rows that differ
+                gl, rl = g.stdout.split(b"\n"), r.stdout.split(b"\n")
+                diff = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
+                out[name]["rc"] = g.returncode
+                out[name]["rows"] = [len(gl), len(rl)]
+                out[name]["differing_rows"] = len(diff)
+                out[name]["first_differences"] = [[i, gl[i][:200].decode(errors="replace"), rl[i][:200].decode(errors="replace")]
+                                                  for i in diff[:3]]
+                out[name]["stderr_tail"] = g.stderr.decode(errors="replace")[-400:]
         if not a.no_ref:
             # qts writes a file: compare what a reader sees in the two outputs
             og, orf = os.path.join(tmp, "g.blow5"), os.path.join(tmp, "r.blow5")
