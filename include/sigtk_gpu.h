@@ -155,7 +155,7 @@ typedef struct sgk_event_status {
  * the preset's own warm-up); the environment variables SGK_EVENT_SEG, SGK_EVENT_LONG_MIN, SGK_EVENT_LEAD give the
  * values a process starts with.  Results do not depend on any of them. */
 int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead);
-/* Short reads (< 16 384 samples) in large batches: a wavefront takes 64 / lanes_per_read reads, lanes_per_read lanes
+/* Short reads (< 16 384 samples; < 65 536 with RNA parameters) in large batches: a wavefront takes 64 / lanes_per_read reads, lanes_per_read lanes
  * each (a power of two, 1 .. 32).  0: chosen per batch (the default), -1: off, every read has a wavefront of its own.
  * Environment: SGK_EVENT_MULTI.  Results do not depend on it. */
 int sgk_event_configure_short(int lanes_per_read);

@@ -68,6 +68,7 @@ static EvSegConfig seg_config_checked(long long seg, long long lmin, long lead) 
     if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
     if (lead >= 16 && lead <= 512) c.lead_override = (int)(lead / 16 * 16);
     c.multi = 0;
+    c.multi_max = 0;
     return c;
 }
 static int multi_checked(long v) {
@@ -83,6 +84,12 @@ EvSegConfig event_seg_config() {
         const char *e1 = getenv("SGK_EVENT_SEG"), *e2 = getenv("SGK_EVENT_LONG_MIN"), *e3 = getenv("SGK_EVENT_LEAD");
         g_seg_cfg = seg_config_checked(e1 ? atoll(e1) : 0, e2 ? atoll(e2) : 0, e3 ? atol(e3) : 0);
         if (const char *e4 = getenv("SGK_EVENT_MULTI")) g_seg_cfg.multi = multi_checked(atol(e4));
+        if (const char *e5 = getenv("SGK_EVENT_MULTI_MAX")) {   // development: the length below which a read is short
+            const long v = atol(e5);
+            uint32_t p2 = 1024;
+            while (p2 < (1u << 30) && (long)p2 * 2 <= v) p2 *= 2;
+            if (v >= 1024) g_seg_cfg.multi_max = p2;
+        }
         g_seg_cfg_set = true;
     }
     return g_seg_cfg;
@@ -91,8 +98,10 @@ void event_seg_configure(long long seg, long long lmin, long lead) {
     (void)event_seg_config();  // (the environment first)
     std::lock_guard<std::mutex> lk(g_seg_mu);
     const int multi = g_seg_cfg.multi;
+    const uint32_t multi_max = g_seg_cfg.multi_max;
     g_seg_cfg = seg_config_checked(seg, lmin, lead);
     g_seg_cfg.multi = multi;
+    g_seg_cfg.multi_max = multi_max;
 }
 void event_multi_configure(int lanes) {
     (void)event_seg_config();
@@ -210,7 +219,11 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     // samples; k_event_multi gives a read fewer lanes and a wave several reads.  Worth it when the batch has enough
     // reads to fill the GPU that way (>= 4 rounds of waves) -- a small batch wants every lane it can get.
     a.multi_lanes = 0;
-    a.multi_max = 16384;
+    // (RNA parameters: warm-ups of 128 / 256 samples make the 64-lane layout 1.3 x its samples' worth up to ~64 k
+    // samples: 33 333 x 30 000 samples 6.15 -> 5.13 ms; DNA parameters: 32 / 64, 20 000-sample reads already cost what
+    // 100 000-sample reads cost.  Above that the packed kernel's per-lane read parameters cost more than they save:
+    // two 100 000-sample reads per wave are 6-9 % slower than one.)
+    a.multi_max = sc.multi_max ? sc.multi_max : (rna ? 65536u : 16384u);
     {
         const uint64_t mean = n_samples / n_reads;
         const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;

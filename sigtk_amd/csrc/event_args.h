@@ -101,6 +101,7 @@ struct EvSegConfig {
     uint32_t seg_len, long_min;
     int lead_override;
     int multi;  // lanes per short read: 0 = chosen per batch, -1 = off (64 lanes per read), 1 .. 32 = forced
+    uint32_t multi_max;  // 0 = default; reads shorter than this (a power of two) count as short
 };
 EvSegConfig event_seg_config();  // defaults, or SGK_EVENT_SEG / SGK_EVENT_LONG_MIN / SGK_EVENT_LEAD from the environment
 void event_seg_configure(long long seg, long long lmin, long lead);

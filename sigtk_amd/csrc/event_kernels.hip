@@ -31,6 +31,7 @@
 // for x and for the float squares, and that every non-zero |x| lies in [2^-20, 2^20] (the range in which the
 // certified fast arithmetic of tstat_math.h has no subnormal intermediate); reads failing the check take the
 // fallback kernel.
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1128,7 +1129,12 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
     const int len = b - a;
     int lead = len < 32768 ? SGK_LEAD_DNA_SHORT : SGK_LEAD_DNA;
     if (W1 == 7) lead = len <= 32768 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_RNA;
-    if constexpr (MULTI) lead = W1 == 7 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_DNA_SHORT;  // (every read of the wave is short)
+    if constexpr (MULTI) {
+        // the same rule for the same chunk length: what 64 lanes would see of a read 64 / lanes times as long
+        const long long len64 = (long long)len * (64 / lanes);
+        lead = len64 < 32768 ? SGK_LEAD_DNA_SHORT : SGK_LEAD_DNA;
+        if (W1 == 7) lead = len64 <= 32768 ? SGK_LEAD_RNA_SHORT : SGK_LEAD_RNA;
+    }
     if (lead_override > 0) lead = lead_override;
     // the fast pass uses unguarded 4-byte-aligned 32-byte vector loads: it needs 16 readable samples behind the
     // read; other reads take the exact fallback
@@ -1155,10 +1161,10 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
     if constexpr (MULTI) {  // the passes' step counts are the wave's: the longest of its reads
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            const int o = __shfl_xor(Kmax, d, 64);
+            const int o = __shfl_xor(Kmax, d, 64), t = __shfl_xor(TT, d, 64);
             Kmax = o > Kmax ? o : Kmax;
+            TT = t > TT ? t : TT;
         }
-        TT = lead + Kmax;
     }
     const int e = e0 < b ? e0 : b;
     const bool active = s < b && !(MULTI && no_fast);
@@ -2116,6 +2122,37 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 #ifndef SGK_EVENT_FUSED
 #define SGK_EVENT_FUSED 1
 #endif
+// A batch with short AND longer reads runs two detector kernels: k_event (a wavefront per read, and the segments of the
+// long reads) and k_event_multi (several short reads per wavefront).  In one stream the second would wait for the last
+// wave of the first -- two tails instead of one, which costs what the packing gains (50 000 RNA-like reads, log-normal
+// around 20 000 samples: 6.36 ms against 6.29 ms with a wavefront per read).  k_event_multi therefore goes to a side
+// stream of the library's own (one per device), forked off the caller's stream behind the dispatch order and joined
+// in front of the fallback kernel; the long reads' seam / builder kernels overlap with it as well.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static std::mutex g_side_mu;      // held from the fork to the join of one launch: the events are shared
+static SideStream g_side[64];
+static SideStream *side_stream_locked() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideStream &x = g_side[dev];
+    if (!x.s) {
+        hipStream_t s = nullptr;
+        hipEvent_t f = nullptr, j = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
+            if (f) (void)hipEventDestroy(f);
+            (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        x.s = s; x.fork = f; x.join = j;
+    }
+    return &x;
+}
+
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
     if (a.n_reads == 0) return SGK_OK;
@@ -2132,20 +2169,33 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     } else ao.order = nullptr;
     if (ao.max_segs) hipLaunchKernelGGL(k_seg_plan, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, ao);
     const bool all_short = ao.multi_lanes && !ao.order;  // k_event would have nothing to do
+    std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
+    SideStream *side = nullptr;
+    hipStream_t st_multi = st;
+    if (ao.multi_lanes && !all_short) {
+        side_lock.lock();
+        side = side_stream_locked();
+        if (side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess)
+            st_multi = side->s;
+        else {
+            side = nullptr;   // (no side stream: one stream does, slower)
+            side_lock.unlock();
+        }
+    }
+    if (ao.multi_lanes) {
+        ProfScope ps("k_event_multi", st_multi);
+        const uint32_t per_wave = 64u / ao.multi_lanes;
+        const uint32_t grid = (a.n_reads + per_wave - 1) / per_wave;
+        if (rna) hipLaunchKernelGGL((k_event_multi<7, T>), dim3(grid), dim3(64), 0, st_multi, ao);
+        else hipLaunchKernelGGL((k_event_multi<3, T>), dim3(grid), dim3(64), 0, st_multi, ao);
+        SGK_HIP_TRY(hipGetLastError());
+    }
     if (!all_short) {
         ProfScope ps("k_event", st);
         if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
         else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
-    if (ao.multi_lanes) {
-        ProfScope ps("k_event_multi", st);
-        const uint32_t per_wave = 64u / ao.multi_lanes;
-        const uint32_t grid = (a.n_reads + per_wave - 1) / per_wave;
-        if (rna) hipLaunchKernelGGL((k_event_multi<7, T>), dim3(grid), dim3(64), 0, st, ao);
-        else hipLaunchKernelGGL((k_event_multi<3, T>), dim3(grid), dim3(64), 0, st, ao);
-        SGK_HIP_TRY(hipGetLastError());
-    }
     if (ao.max_segs) {
         {
             ProfScope ps("k_event_seam", st);
@@ -2159,6 +2209,12 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
             hipLaunchKernelGGL((k_event_long_finish<T>), dim3((ao.max_long + 63) / 64), dim3(64), 0, st, ao);
         }
         SGK_HIP_TRY(hipGetLastError());
+    }
+    if (side) {
+        // join: the fallback kernel (and whatever the caller enqueues next) waits for the packed reads as well
+        const bool ok = hipEventRecord(side->join, side->s) == hipSuccess && hipStreamWaitEvent(st, side->join, 0) == hipSuccess;
+        side_lock.unlock();
+        if (!ok) SGK_HIP_TRY(hipStreamSynchronize(side->s));
     }
 #else
     {

@@ -1,6 +1,7 @@
 """GPU parity: several short reads per wavefront (k_event_multi), against the oracle (bit-exact).
 
-Reads shorter than 16 384 samples in a large batch get `lanes` lanes each instead of a wavefront of their own
+Reads shorter than 16 384 samples (65 536 with RNA parameters) in a large batch get `lanes` lanes each instead of a
+wavefront of their own
 (sgk_event_configure_short forces the number here; by default it is chosen per batch and small batches keep 64).
 """
 import numpy as np
@@ -60,12 +61,13 @@ def test_sorted_batch_short_tail_and_long_head(gpu, oracle, lanes_cfg, rna):
     rs = np.random.RandomState(5)
     lens = np.exp(rs.uniform(np.log(1), np.log(40000), size=1100)).astype(np.int64)
     lens[7] = 300000; lens[100] = 16384; lens[101] = 16383; lens[500] = 0
+    lens[102] = 65536; lens[103] = 65535; lens[104] = 50000   # (RNA parameters: reads under 65 536 samples are short)
     reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens.tolist(), seed=23, kind=rna)
     for lanes in (0, 4, 32):   # 0: the library's own choice for this batch
         lanes_cfg(lanes)
         got, st = gpu.event(reads, dig, off, rng, rna)
         assert st.n_split_reads == 1 and st.n_capacity_overflow == 0
-        pick = list(range(0, 1100, 37)) + [7, 100, 101, 500]
+        pick = list(range(0, 1100, 37)) + [7, 100, 101, 102, 103, 104, 500]
         _check_events(oracle, [reads[i] for i in pick], dig[pick], off[pick], rng[pick], rna, [got[i] for i in pick])
         assert st.n_events_total == sum(g.start.size for g in got)
 
