@@ -160,6 +160,19 @@ int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead);
  * Environment: SGK_EVENT_MULTI.  Results do not depend on it. */
 int sgk_event_configure_short(int lanes_per_read);
 
+/* How sgk_event would take a batch with these totals under the current configuration (host only, no GPU work): the
+ * segment geometry and list capacities of the long reads, the threshold and the lanes per read of the short ones
+ * (0: every read has a wavefront of its own). */
+typedef struct sgk_event_plan {
+    uint32_t segment_len, long_min;         /* long reads: >= long_min samples, cut into segments of segment_len */
+    uint32_t max_segments, max_long_reads;  /* capacities reserved in the workspace (0: no read is long enough) */
+    uint32_t short_max;                     /* reads under this many samples are short ...                      */
+    uint32_t lanes_per_short_read;          /* ... and get this many lanes each (0: packing is off for the batch) */
+    uint32_t warmup_override;               /* 0: the presets' warm-ups                                          */
+    uint32_t reserved;
+} sgk_event_plan_t;
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, sgk_event_plan_t *out);
+
 /* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.
  * Returns SGK_ERR_CAPACITY if any read overflowed its slots. */
 int sgk_event_status(const void *workspace, sgk_event_status_t *out, void *stream);

@@ -46,6 +46,12 @@ class EventStatus(C.Structure):
                 ("n_seam_reruns", C.c_uint32), ("reserved", C.c_uint32), ("n_replay_indices", C.c_uint64)]
 
 
+class EventPlan(C.Structure):   # sgk_event_plan_t
+    _fields_ = [("segment_len", C.c_uint32), ("long_min", C.c_uint32), ("max_segments", C.c_uint32),
+                ("max_long_reads", C.c_uint32), ("short_max", C.c_uint32), ("lanes_per_short_read", C.c_uint32),
+                ("warmup_override", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class EventsHost(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("ev_offsets", C.POINTER(C.c_uint64)),
                 ("start", C.POINTER(C.c_uint32)), ("length", C.POINTER(C.c_uint32)),
@@ -93,7 +99,7 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_configure", "sgk_event_configure_short",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_configure", "sgk_event_configure_short", "sgk_event_plan",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
     "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
     "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
@@ -147,6 +153,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     L.sgk_event_configure.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
     L.sgk_event_configure.restype = C.c_int
+    if hasattr(L, "sgk_event_plan"):
+        L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(EventPlan)]
+        L.sgk_event_plan.restype = C.c_int
     if hasattr(L, "sgk_event_configure_short"):   # (absent from older builds selected with SIGTK_AMD_LIB for A/B runs)
         L.sgk_event_configure_short.argtypes = [C.c_int]
         L.sgk_event_configure_short.restype = C.c_int

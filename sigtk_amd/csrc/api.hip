@@ -174,6 +174,31 @@ int check_batch(const sgk_batch_t *b) {
     return SGK_OK;
 }
 
+// Short reads.  On all 64 lanes a 5 000-sample read spends more steps on warm-ups (lead per lane) than on its samples;
+// k_event_multi gives a read fewer lanes and a wave several reads.  Worth it when the batch has enough reads to fill
+// the GPU that way (>= 4 rounds of waves) -- a small batch wants every lane it can get.  `sorted`: the batch gets a
+// dispatch order (its short reads are the order's tail); without one the batch must be short as a whole.
+void event_multi_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, bool sorted,
+                      uint32_t &multi_lanes, uint32_t &multi_max) {
+    const EvSegConfig sc = event_seg_config();
+    multi_lanes = 0;
+    // (RNA parameters: warm-ups of 128 / 256 samples make the 64-lane layout 1.3 x its samples' worth up to ~64 k
+    // samples: 33 333 x 30 000 samples 6.15 -> 5.13 ms; DNA parameters: 32 / 64, 20 000-sample reads already cost what
+    // 100 000-sample reads cost.  Above that the packed kernel's per-lane read parameters cost more than they save:
+    // two 100 000-sample reads per wave are 6-9 % slower than one.)
+    multi_max = sc.multi_max ? sc.multi_max : (rna ? 65536u : 16384u);
+    if (n_reads == 0) return;
+    const uint64_t mean = n_samples / n_reads;
+    if (sc.multi >= 0 && mean < multi_max && (sorted || max_read_len < multi_max)) {
+        const uint32_t lead = sc.lead_override > 0 ? (uint32_t)sc.lead_override : (rna ? 128u : 32u);
+        uint32_t lanes = 1;
+        while (lanes < 64 && (uint64_t)lanes * 2 * 8 * lead <= mean) lanes *= 2;       // chunks of >= 8 warm-ups
+        while (lanes < 64 && (uint64_t)n_reads * lanes < 64ull * 4 * 3072) lanes *= 2;  // >= 4 rounds of waves
+        if (sc.multi > 0) lanes = (uint32_t)sc.multi;
+        if (lanes < 64) multi_lanes = lanes;
+    }
+}
+
 static int run_event(const void *samples, bool float_input, const uint64_t *offsets, const uint32_t *lengths,
                      const double *dig, const double *off, const double *rng, uint32_t n_reads,
                      uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
@@ -215,27 +240,8 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
     a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
     a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
-    // Short reads.  On all 64 lanes a 5 000-sample read spends more steps on warm-ups (lead per lane) than on its
-    // samples; k_event_multi gives a read fewer lanes and a wave several reads.  Worth it when the batch has enough
-    // reads to fill the GPU that way (>= 4 rounds of waves) -- a small batch wants every lane it can get.
-    a.multi_lanes = 0;
-    // (RNA parameters: warm-ups of 128 / 256 samples make the 64-lane layout 1.3 x its samples' worth up to ~64 k
-    // samples: 33 333 x 30 000 samples 6.15 -> 5.13 ms; DNA parameters: 32 / 64, 20 000-sample reads already cost what
-    // 100 000-sample reads cost.  Above that the packed kernel's per-lane read parameters cost more than they save:
-    // two 100 000-sample reads per wave are 6-9 % slower than one.)
-    a.multi_max = sc.multi_max ? sc.multi_max : (rna ? 65536u : 16384u);
-    {
-        const uint64_t mean = n_samples / n_reads;
-        const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;
-        if (sc.multi >= 0 && mean < a.multi_max && (sorted || max_read_len < a.multi_max)) {
-            const uint32_t lead = sc.lead_override > 0 ? (uint32_t)sc.lead_override : (rna ? 128u : 32u);
-            uint32_t lanes = 1;
-            while (lanes < 64 && (uint64_t)lanes * 2 * 8 * lead <= mean) lanes *= 2;       // chunks of >= 8 warm-ups
-            while (lanes < 64 && (uint64_t)n_reads * lanes < 64ull * 4 * 3072) lanes *= 2;  // >= 4 rounds of waves
-            if (sc.multi > 0) lanes = (uint32_t)sc.multi;
-            if (lanes < 64) a.multi_lanes = lanes;
-        }
-    }
+    const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;
+    event_multi_plan(n_reads, n_samples, max_read_len, rna, sorted, a.multi_lanes, a.multi_max);
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -373,6 +379,23 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
 
 int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead) {
     sgk::event_seg_configure(seg_len, long_min, lead);
+    return SGK_OK;
+}
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, sgk_event_plan_t *out) {
+    if (!out) return SGK_ERR_ARG;
+    const sgk::EvSegConfig sc = sgk::event_seg_config();
+    uint32_t max_segs = 0, max_long = 0, lanes = 0, mmax = 0;
+    sgk::event_seg_capacity(n_reads, n_samples, max_read_len, max_segs, max_long);
+    const bool sorted = n_reads >= sgk::ORDER_MIN_READS && (uint64_t)max_read_len * n_reads > n_samples + n_samples / 4;
+    sgk::event_multi_plan(n_reads, n_samples, max_read_len, rna, sorted, lanes, mmax);
+    out->segment_len = sc.seg_len;
+    out->long_min = sc.long_min;
+    out->max_segments = max_segs;
+    out->max_long_reads = max_long;
+    out->short_max = mmax;
+    out->lanes_per_short_read = lanes;
+    out->warmup_override = (uint32_t)sc.lead_override;
+    out->reserved = 0;
     return SGK_OK;
 }
 int sgk_event_configure_short(int lanes_per_read) {

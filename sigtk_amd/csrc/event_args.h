@@ -106,6 +106,8 @@ struct EvSegConfig {
 EvSegConfig event_seg_config();  // defaults, or SGK_EVENT_SEG / SGK_EVENT_LONG_MIN / SGK_EVENT_LEAD from the environment
 void event_seg_configure(long long seg, long long lmin, long lead);
 void event_multi_configure(int lanes);
+void event_multi_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, bool sorted,
+                      uint32_t &multi_lanes, uint32_t &multi_max);
 void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
                         uint32_t &max_long);
 
