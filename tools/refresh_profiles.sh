@@ -12,6 +12,18 @@ timeout -s KILL 600 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>
 timeout -s KILL 600 python bench.py --ragged 0.8 --cpu-reads 0 > $O/bench_ragged.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_5k.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_5k_rna.json 2>> $O/bench.err
+# round 3: the shapes the one-wavefront-per-read layout served badly (long reads in segments, short reads packed), and
+# the same build with packing off
+timeout -s KILL 600 python bench.py --ragged 0.8 --rna 1 --cpu-reads 0 > $O/bench_ragged_rna.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --read-len 12000 --reads 83333 --rna 1 --cpu-reads 0 > $O/bench_12k_rna.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --read-len 30000 --reads 33333 --rna 1 --cpu-reads 0 > $O/bench_30k_rna.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 20000 --reads 50000 --rna 1 --cpu-reads 0 > $O/bench_ragged_20k_rna.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_ragged_5k.json 2>> $O/bench.err
+timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_ragged_5k_rna.json 2>> $O/bench.err
+SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_5k_one_read_per_wave.json 2>> $O/bench.err
+SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_5k_rna_one_read_per_wave.json 2>> $O/bench.err
+SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 20000 --reads 50000 --rna 1 --cpu-reads 0 > $O/bench_ragged_20k_rna_one_read_per_wave.json 2>> $O/bench.err
+SGK_EVENT_LONG_MIN=4000000000 timeout -s KILL 600 python bench.py --ragged 0.8 --cpu-reads 0 > $O/bench_ragged_one_wave_per_read.json 2>> $O/bench.err
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 > $O/prof.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
@@ -23,6 +35,7 @@ timeout -s KILL 900 python bench.py --config 4 --steps 5 > $O/bench_c4.json 2>> 
 timeout -s KILL 900 python bench.py --config 5 --steps 3 > $O/bench_c5.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 125000 --rna 0 > $O/subtools_c4.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 50000 --rna 1 > $O/subtools_c3.json 2>> $O/bench.err
+timeout -s KILL 600 python tools/bench_subtools.py --ragged 0.8 > $O/subtools_ragged.json 2>> $O/bench.err
 fi
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
