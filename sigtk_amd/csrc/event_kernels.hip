@@ -2062,7 +2062,9 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     const uint32_t idx = first + (has ? w0 + gi : w0);
     const uint32_t r = a.order ? a.order[idx] : idx;
     ReadCtx<T> rc = make_ctx<T>(a, r);
-    if (!has) rc.n = 0;
+    // (with segments shorter than multi_max -- tests -- a read can be short and long at once: the segments have it)
+    const bool mine = has && !(a.max_segs && rc.n >= (int64_t)a.long_min);
+    if (!mine) rc.n = 0;
     const int rcode = detect_span<W1, T, false, true>(rc, a.hdr, &L.lz, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr,
                                                       lanes);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2072,6 +2074,7 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
         if (w0 + (uint32_t)g >= nshort) break;
         const uint32_t rg = (uint32_t)__builtin_amdgcn_readlane((int)r, g * lanes);
         const int code = __builtin_amdgcn_readlane(rcode, g * lanes);
+        if (!__builtin_amdgcn_readlane((int)mine, g * lanes)) continue;
         const ReadCtx<T> rcg = make_ctx<T>(a, rg);
         build_read<T>(a, rcg, rg, &L.b, code != 0);
         __syncthreads();
@@ -2168,7 +2171,9 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         if (rc != SGK_OK) return rc;
     } else ao.order = nullptr;
     if (ao.max_segs) hipLaunchKernelGGL(k_seg_plan, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, ao);
-    const bool all_short = ao.multi_lanes && !ao.order;  // k_event would have nothing to do
+    // (no dispatch order and packing on: every read is under multi_max.  k_event would have nothing to do -- unless
+    // the segments are test-sized and some of those reads are long: their segments are k_event's)
+    const bool all_short = ao.multi_lanes && !ao.order && !ao.max_segs;
     std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
     SideStream *side = nullptr;
     hipStream_t st_multi = st;

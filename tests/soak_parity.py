@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--batches", type=int, default=0,
                     help="run exactly this many batches (the same work on every box) instead of a time box")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--trace", default="", help="file that receives every batch's tag BEFORE its event launch (flushed): "
+                    "after a GPU fault the last line names the batch")
     ap.add_argument("--segments", type=float, default=0.5,
                     help="share of the batches whose event pass runs with short segments (reads shared by several "
                          "wavefronts: sgk_event_configure) and, for a third of those, a warm-up short enough for "
@@ -80,12 +82,17 @@ def main():
         if rs_cfg.rand() < a.segments:
             seg = int(rs_cfg.choice([1024, 2048, 3072, 8192, 32768]))
             cfg = (seg, int(seg + 1 + rs_cfg.randint(0, 3 * seg)), int(rs_cfg.choice([0, 0, 16, 32])))
-        tag = "batch %d (seed %d kind %d rna %d svb %d segments %s)" % (stats["batches"], seed, kind, rna, svb, cfg)
+        lanes_cfg = int(rs_cfg.choice([0, 0, -1, 1, 2, 4, 8, 16, 32]))   # lanes per short read
+        tag = "batch %d (seed %d kind %d rna %d svb %d segments %s lanes %d)" % (stats["batches"], seed, kind, rna, svb, cfg,
+                                                                             lanes_cfg)
 
         t_batch = time.time()
+        if a.trace:
+            with open(a.trace, "a") as tf:
+                tf.write(tag + " lens " + ",".join(str(x) for x in lens[:64]) + "\n")
         job.stage(sig, dig, off, rng, counts)
         L.sgk_event_configure(*cfg)
-        L.sgk_event_configure_short(int(rs_cfg.choice([0, 0, -1, 1, 2, 4, 8, 16, 32])))   # lanes per short read
+        L.sgk_event_configure_short(lanes_cfg)
         job.launch(api.TOOL_EVENT, rna=rna)
         res = job.wait()
         t_event = time.time() - t_batch

@@ -111,3 +111,19 @@ def test_packed_reads_on_odd_addresses_decline_one_by_one(gpu, oracle, lanes_cfg
         assert np.array_equal(got.start.astype(np.uint64), exp.start)
         assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
         assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_a_read_that_is_short_and_long_belongs_to_its_segments(gpu, oracle, lanes_cfg, rna):
+    """with test-sized segments a read can be under the short threshold and over the long one: the packed kernel must
+    leave it to its segments (the two run side by side on different streams)"""
+    L = gpu.load_library()
+    lens = [5000, 3000, 900, 1500, 12000, 700, 2048, 1025, 1024, 40000]
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=3 + rna, kind=rna)
+    for lanes in (4, 16):
+        lanes_cfg(lanes)
+        assert L.sgk_event_configure(1024, 1025, 0) == 0
+        for _ in range(3):
+            got, st = gpu.event(reads, dig, off, rng, rna)
+            _check_events(oracle, reads, dig, off, rng, rna, got)
+            assert st.n_split_reads == sum(1 for n in lens if n >= 1025)
