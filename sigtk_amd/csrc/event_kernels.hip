@@ -1,28 +1,36 @@
 // event_kernels.hip -- the `event` hot path (reference: src/events.c:293-573) for gfx950.
 //
-// One wavefront (64 lanes) per read.  Three kernels:
+// The unit of work is a SPAN of a read on one wavefront (64 lanes):
 //
-//   k_event_detect   window sums -> t-statistics -> short/long peak detector (LazyPass, below).
-//                    Lane c owns chunk c of the read (K samples, K a multiple of 64).  Each lane slides a
+//   detector         (detect_span, LazyPass)  window sums -> t-statistics -> short/long peak detector.
+//                    Lane c owns chunk c of the span (K samples, K a multiple of 16).  Each lane slides a
 //                    running double prefix sum through a register ring, evaluates the reference's mixed
 //                    float/double t-statistic expression tree (events.c:338-361) for the short window in
 //                    certified fast arithmetic, steps the short detector automaton (events.c:383-440) as
 //                    lane-mask algebra, and runs the long detector lazily (exact only where a rigorous bound
 //                    cannot exclude a peak).  The automaton is serial in the reference; here every chunk
-//                    starts SPECULATIVELY from the fresh state LEAD samples before its chunk, and the
+//                    starts SPECULATIVELY from the fresh state `lead` samples before its chunk, and the
 //                    speculation is verified: chunk c is accepted iff its state at its chunk start equals
 //                    chunk c-1's state at that position; mismatching chunks are re-run from the true state
 //                    until a fixed point (exact in the general case; re-runs are counted in the status
 //                    block).  Output: one bit per sample (peak positions) in a workspace bitmap.
 //
-//   k_event_build    bitmap + samples -> event table (events.c:457-504).  Lane-local double prefix sums,
-//                    wave scan across lanes, boundary records compacted in LDS, then one event per lane per
-//                    round with coalesced SoA stores of (start, length, mean, stdv).
+//   builder          (build_read)  bitmap + samples -> event table (events.c:457-504).  Lane-local double prefix
+//                    sums, wave scan across lanes, boundary records compacted in LDS, then one event per lane per
+//                    round with one 16-byte store of (start, length, mean, stdv).
 //
+// and the kernels differ in what a wave's span is:
+//
+//   k_event          a whole read: detector and builder back to back in the same wave (most reads);
+//                    its first workgroups run the detector over the SEGMENTS of reads too long for one wave
+//   k_event_seam / k_event_seg_count / k_event_build_seg / k_event_long_finish
+//                    the long reads: seams between segments verified (and re-run), builder per segment (round 3)
+//   k_event_multi    several short reads per wave, `lanes` lanes each, on a side stream beside k_event (round 3)
 //   k_event_fallback persistent kernel over the reads that fail the exactness guard: lane 0 reproduces
 //                    compute_sum_sumsq's sequential double prefix scan (events.c:293-303) into workspace
 //                    scratch, then the same detector and builder run with window/event sums taken as
 //                    differences of those arrays, exactly as the reference does.
+//   (k_event_detect / k_event_build: detector and builder as two kernels, SGK_EVENT_FUSED=0, development)
 //
 // Exactness guard: the reference accumulates double prefix sums sequentially and uses their differences; the
 // fast path forms window sums and event sums directly.  Both give the real-number sums (hence identical bits)
@@ -966,11 +974,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         // (The reset index alone is not enough once the mask is normalised away: a lane that takes this state over
         // would replay a hot run from the reset, through indices the mask hid from the reference's long detector --
         // found by the soak with a 16-sample warm-up, tests/golden/soak_seed41_*.npz.)
-#ifdef SGK_EXP_OLD_R0
-        st.r0 = ib + f.r0;
-#else
         st.r0 = ib + max(f.r0, f.lm + W1 + 1);
-#endif
         st.bits = (ip ? 1u : 0u) | ((ip && lane_of(f.val)) ? 2u : 0u) | ((ip && lane_of(f.strong)) ? 4u : 0u) |
                   (lane_of(f.hot) ? 8u : 0u);
         return st;
