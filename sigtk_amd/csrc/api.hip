@@ -140,6 +140,7 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.off_segs = o;       o += round_up((size_t)w.max_segs * sizeof(SegDesc), 64);
     w.off_seg_state = o;  o += round_up((size_t)w.max_segs * sizeof(SegState), 64);
     w.off_longs = o;      o += round_up((size_t)w.max_long * sizeof(LongRead), 64);
+    w.off_runs = o;       o += round_up((size_t)nr * 64u * 8u * sizeof(LzRun), 64);
     w.off_scratch = o;
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
     const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
@@ -240,8 +241,13 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
     a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
     a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
+    a.rec_runs = reinterpret_cast<LzRun *>(base + w.off_runs);
     const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;
     event_multi_plan(n_reads, n_samples, max_read_len, rna, sorted, a.multi_lanes, a.multi_max);
+    {
+        const char *e = getenv("SGK_EVENT_REC");   // development switch, removed with the old path
+        a.rec_on = e ? (uint32_t)atoi(e) : 1u;
+    }
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 

@@ -95,6 +95,8 @@ struct EvArgs {
     // short reads (multi_lanes == 0: every read has a wavefront of its own)
     uint32_t multi_lanes;           // lanes per short read (a power of two below 64): k_event_multi packs 64 / lanes reads
     uint32_t multi_max;             // reads shorter than this (a power of two) are short
+    uint32_t rec_on;                // events straight from the detector pass where k_event can (round 4)
+    LzRun *rec_runs;                // ... its lanes' hot-run records: n_reads x 64 x 8
 };
 
 struct EvSegConfig {
@@ -113,7 +115,7 @@ void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_
 
 // workspace carving shared by sgk_event_workspace_bytes and sgk_event
 struct EvWorkspace {
-    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_segs, off_seg_state, off_longs, off_scratch, total;
+    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_segs, off_seg_state, off_longs, off_runs, off_scratch, total;
     uint32_t max_segs, max_long;
     uint64_t scratch_stride;
     uint32_t n_fb_blocks;
