@@ -60,7 +60,10 @@
 extern "C" {
 #endif
 
-#define SGK_VERSION_STRING "0.1.0"
+/* 0.2.0: per-call options (sgk_event_options_t, sgk_stat_options_t) replace the process-wide sgk_event_configure* and
+ * the environment variables of 0.1.0; sgk_event_plan takes the options; sgk_event_plan_t / sgk_event_status_t as below.
+ * Bindings should compare sgk_version() with the header they were written against. */
+#define SGK_VERSION_STRING "0.2.0"
 
 /* ---- error codes --------------------------------------------------------------- */
 #define SGK_OK 0
@@ -142,36 +145,58 @@ typedef struct sgk_event_status {
     uint32_t n_long_replays;     /* lanes (chunks) in which a run of the lazily evaluated long detector could not be
                                   * proven silent and was re-played exactly (diagnostic)  */
     uint64_t n_events_total;
-    uint32_t n_split_reads;      /* reads long enough to be taken by several wavefronts (segments of 131 072
-                                  * samples, reads of at least 262 144)                     */
+    uint32_t n_split_reads;      /* reads taken by several wavefronts: long reads (segments of 131 072 samples, reads
+                                  * of at least 262 144) and the reads of the tail split    */
     uint32_t n_segments;         /* their segments                                         */
     uint32_t n_seam_reruns;      /* segments whose speculative start was wrong and that were run again */
     uint32_t reserved;
     uint64_t n_replay_indices;   /* indices the exact replay of the long detector walked (diagnostic: one lane each) */
 } sgk_event_status_t;
-/* Tuning (process-wide; call it before sizing workspaces, not while an sgk_event call is being issued): a read of at
- * least `long_min` samples is cut into segments of `seg_len` samples (multiple of 1024), one wavefront each; `lead` is
- * the speculative warm-up in samples (multiple of 16, <= 512).  0 selects the default of a value (131 072 / 262 144 /
- * the preset's own warm-up); the environment variables SGK_EVENT_SEG, SGK_EVENT_LONG_MIN, SGK_EVENT_LEAD give the
- * values a process starts with.  Results do not depend on any of them. */
-int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead);
-/* Short reads (< 16 384 samples; < 65 536 with RNA parameters) in large batches: a wavefront takes 64 / lanes_per_read reads, lanes_per_read lanes
- * each (a power of two, 1 .. 32).  0: chosen per batch (the default), -1: off, every read has a wavefront of its own.
- * Environment: SGK_EVENT_MULTI.  Results do not depend on it. */
-int sgk_event_configure_short(int lanes_per_read);
+/* Per-call options of the event path.  All zero (or a null pointer) = the defaults.  The library keeps no mutable
+ * process-wide configuration and reads no environment variable: two callers in one process may use different options
+ * at the same time; size a workspace with the options the call will use.  Results do not depend on any of them.
+ *   segment_len / long_min   a read of at least long_min samples is cut into segments of segment_len samples (a multiple
+ *                            of 1024), one wavefront each                         (0: 131 072 / 262 144)
+ *   warmup                   speculative warm-up in samples, a multiple of 16, <= 512  (0: the presets' own; tests use
+ *                            16 to make speculation fail at every few chunk boundaries)
+ *   lanes_per_short_read     short reads (< short_max samples) in large batches: a wavefront takes 64 / lanes reads,
+ *                            lanes lanes each (a power of two, 1 .. 32)           (0: chosen per batch, -1: off)
+ *   short_max                (0: 16 384, 65 536 with RNA parameters; a power of two >= 1024)
+ *   tail_split               a batch of fewer than 8 rounds of wavefronts: the reads of its last, partial round are cut
+ *                            into segments so that the GPU drains on small units  (0: chosen per batch, -1: off) */
+typedef struct sgk_event_options {
+    uint32_t segment_len, long_min;
+    int32_t warmup;
+    int32_t lanes_per_short_read;
+    uint32_t short_max;
+    int32_t tail_split;
+    uint32_t reserved[2];
+} sgk_event_options_t; /* 32 bytes */
+size_t sgk_event_workspace_bytes_opt(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len,
+                                     const sgk_event_options_t *opt);
+int sgk_event_opt(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events,
+                  uint32_t *n_events, void *workspace, size_t workspace_bytes, void *stream,
+                  const sgk_event_options_t *opt);
+int sgk_event_pa_opt(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                     uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
+                     sgk_event_rec_t *events, uint32_t *n_events, void *workspace, size_t workspace_bytes, void *stream,
+                     const sgk_event_options_t *opt);
 
-/* How sgk_event would take a batch with these totals under the current configuration (host only, no GPU work): the
- * segment geometry and list capacities of the long reads, the threshold and the lanes per read of the short ones
- * (0: every read has a wavefront of its own). */
+/* How sgk_event_opt would take a batch with these totals under `opt` (host only, no GPU work; the tail split assumes
+ * the current device's CU count, 256 without a device): the segment geometry and list capacities of the long reads, the
+ * threshold and the lanes per read of the short ones (0: every read has a wavefront of its own), the tail split. */
 typedef struct sgk_event_plan {
     uint32_t segment_len, long_min;         /* long reads: >= long_min samples, cut into segments of segment_len */
-    uint32_t max_segments, max_long_reads;  /* capacities reserved in the workspace (0: no read is long enough) */
+    uint32_t max_segments, max_long_reads;  /* capacities reserved in the workspace (0: no read is cut)           */
     uint32_t short_max;                     /* reads under this many samples are short ...                      */
     uint32_t lanes_per_short_read;          /* ... and get this many lanes each (0: packing is off for the batch) */
     uint32_t warmup_override;               /* 0: the presets' warm-ups                                          */
-    uint32_t reserved;
+    uint32_t tail_split_from;               /* tail split: reads at dispatch positions >= this (n_reads: none) ... */
+    uint32_t tail_segment_len;              /* ... are cut into segments of this many samples (0: none)           */
+    uint32_t reserved[3];
 } sgk_event_plan_t;
-int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, sgk_event_plan_t *out);
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
+                   sgk_event_plan_t *out);
 
 /* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.
  * Returns SGK_ERR_CAPACITY if any read overflowed its slots. */
@@ -216,6 +241,23 @@ typedef struct sgk_prefix_rec {
 size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
                size_t workspace_bytes, void *stream);
+
+/* Per-call options of stat / jnn / prefix (null = defaults).  The library has two implementations of these subtools:
+ * one read per wavefront (round 2; any batch) and one read per lane (round 1; wins on large batches of short reads of
+ * similar length: >= 65 536 reads of <= 16 384 samples, the longest <= 1.5 x the mean).  kernels: 0 chosen per batch,
+ * 1 one read per lane, 2 one read per wavefront.  Results do not depend on it (the tests compare the two bit for bit). */
+typedef struct sgk_stat_options {
+    int32_t kernels;
+    uint32_t reserved[3];
+} sgk_stat_options_t;
+int sgk_stat_opt(const sgk_batch_t *batch, sgk_stat_rec_t *out, void *workspace, size_t workspace_bytes, void *stream,
+                 const sgk_stat_options_t *opt);
+int sgk_stat_pa_opt(const sgk_batch_t *batch, sgk_stat_rec_t *out, float *pa_out, void *workspace,
+                    size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
+int sgk_jnn_opt(const sgk_batch_t *batch, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
+                uint32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
+int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
+                   size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
 
 /* ---- ent: the histograms behind `sigtk ent` (src/ent.c) ----------------- */
 /* The counting runs on the GPU, the sum of -p*log2(p) over the (few thousand) non-empty bins on the host
@@ -304,10 +346,12 @@ typedef struct sgk_events_host {
     sgk_event_status_t status;
 } sgk_events_host_t;
 int sgk_event_host(const sgk_host_batch_t *batch, int rna, sgk_events_host_t *out);
+int sgk_event_host_opt(const sgk_host_batch_t *batch, int rna, sgk_events_host_t *out, const sgk_event_options_t *opt);
 void sgk_events_host_free(sgk_events_host_t *ev);
 
 int sgk_pa_host(const sgk_host_batch_t *batch, float *pa_out /* host, n_samples */);
 int sgk_stat_host(const sgk_host_batch_t *batch, sgk_stat_rec_t *out /* host, n_reads */);
+int sgk_stat_host_opt(const sgk_host_batch_t *batch, sgk_stat_rec_t *out, const sgk_stat_options_t *opt);
 
 typedef struct sgk_segs_host {
     uint32_t n_reads;
@@ -315,9 +359,12 @@ typedef struct sgk_segs_host {
     int32_t *x, *y;
 } sgk_segs_host_t;
 int sgk_jnn_host(const sgk_host_batch_t *batch, int rna, sgk_segs_host_t *out);
+int sgk_jnn_host_opt(const sgk_host_batch_t *batch, int rna, sgk_segs_host_t *out, const sgk_stat_options_t *opt);
 void sgk_segs_host_free(sgk_segs_host_t *s);
 
 int sgk_prefix_host(const sgk_host_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out /* host, n_reads */);
+int sgk_prefix_host_opt(const sgk_host_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out,
+                        const sgk_stat_options_t *opt);
 
 /* ---- pipelined host jobs (the batched, overlapped replacement of the ------
  *      reference's one-record-at-a-time loop, src/cmain.c:118-120) ---------------------
@@ -380,6 +427,8 @@ typedef struct sgk_job_output {
 } sgk_job_output_t;
 
 int sgk_job_create(int device, sgk_job_t **out);
+/* the options the job's submits use from now on (copied; null = defaults) */
+int sgk_job_set_options(sgk_job_t *job, const sgk_event_options_t *event_opt, const sgk_stat_options_t *stat_opt);
 void sgk_job_destroy(sgk_job_t *job);
 int sgk_job_device(const sgk_job_t *job);
 /* lengths[r]: samples of read r; blob_bytes[r] (SGK_SIGNAL_SVBZD only): byte length of its blob */

@@ -49,7 +49,60 @@ class EventStatus(C.Structure):
 class EventPlan(C.Structure):   # sgk_event_plan_t
     _fields_ = [("segment_len", C.c_uint32), ("long_min", C.c_uint32), ("max_segments", C.c_uint32),
                 ("max_long_reads", C.c_uint32), ("short_max", C.c_uint32), ("lanes_per_short_read", C.c_uint32),
-                ("warmup_override", C.c_uint32), ("reserved", C.c_uint32)]
+                ("warmup_override", C.c_uint32), ("tail_split_from", C.c_uint32), ("tail_segment_len", C.c_uint32),
+                ("reserved", C.c_uint32 * 3)]
+
+
+class EventOptions(C.Structure):   # sgk_event_options_t (all zero = the defaults)
+    _fields_ = [("segment_len", C.c_uint32), ("long_min", C.c_uint32), ("warmup", C.c_int32),
+                ("lanes_per_short_read", C.c_int32), ("short_max", C.c_uint32), ("tail_split", C.c_int32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+class StatOptions(C.Structure):   # sgk_stat_options_t
+    _fields_ = [("kernels", C.c_int32), ("reserved", C.c_uint32 * 3)]
+
+
+def _env_int(name, default=0):
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+#: The options every wrapper of this module (and sigtk_amd.device) passes with its calls.  The library itself keeps no
+#: configuration and reads no environment variable; the development / A-B switches live here, in the bindings:
+#: SGK_EVENT_SEG, SGK_EVENT_LONG_MIN, SGK_EVENT_LEAD, SGK_EVENT_MULTI, SGK_EVENT_MULTI_MAX, SGK_EVENT_TAIL (0 = off),
+#: SGK_LANE_PER_READ (1 / 0 = one read per lane / per wavefront).  Tests set them with event_configure() & co.
+EVENT_OPTIONS = EventOptions(_env_int("SGK_EVENT_SEG"), _env_int("SGK_EVENT_LONG_MIN"), _env_int("SGK_EVENT_LEAD"),
+                             _env_int("SGK_EVENT_MULTI"), _env_int("SGK_EVENT_MULTI_MAX"),
+                             -1 if os.environ.get("SGK_EVENT_TAIL", "1") == "0" else 0)
+STAT_OPTIONS = StatOptions({"1": 1, "0": 2}.get(os.environ.get("SGK_LANE_PER_READ", ""), 0))
+
+
+def event_configure(segment_len: int = 0, long_min: int = 0, warmup: int = 0) -> None:
+    """segment geometry / warm-up of the calls that follow (0 = the library's defaults)"""
+    EVENT_OPTIONS.segment_len, EVENT_OPTIONS.long_min, EVENT_OPTIONS.warmup = int(segment_len), int(long_min), int(warmup)
+
+
+def event_configure_short(lanes_per_read: int = 0, short_max: int = 0) -> None:
+    EVENT_OPTIONS.lanes_per_short_read, EVENT_OPTIONS.short_max = int(lanes_per_read), int(short_max)
+
+
+def event_configure_tail(on: bool = True) -> None:
+    EVENT_OPTIONS.tail_split = 0 if on else -1
+
+
+def stat_configure(kernels: int = 0) -> None:
+    """0: chosen per batch, 1: one read per lane (round-1 kernels), 2: one read per wavefront"""
+    STAT_OPTIONS.kernels = int(kernels)
+
+
+def event_plan(n_reads: int, n_samples: int, max_read_len: int, rna: int, opt: "EventOptions" = None) -> EventPlan:
+    p = EventPlan()
+    check(load_library().sgk_event_plan(int(n_reads), int(n_samples), int(max_read_len), int(rna),
+                                        C.byref(opt if opt is not None else EVENT_OPTIONS), C.byref(p)), "sgk_event_plan")
+    return p
 
 
 class EventsHost(C.Structure):
@@ -99,9 +152,11 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_configure", "sgk_event_configure_short", "sgk_event_plan",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan",
+    "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
-    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
+    "sgk_stat_host_opt", "sgk_jnn_host_opt", "sgk_prefix_host_opt", "sgk_job_set_options", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
     "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
     "sgk_event_host", "sgk_events_host_free", "sgk_pa_host", "sgk_stat_host", "sgk_jnn_host",
@@ -151,19 +206,23 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_event_pa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int] + \
                               [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
-    L.sgk_event_configure.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
-    L.sgk_event_configure.restype = C.c_int
-    if hasattr(L, "sgk_event_plan"):
-        L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(EventPlan)]
-        L.sgk_event_plan.restype = C.c_int
-    if hasattr(L, "sgk_event_configure_short"):   # (absent from older builds selected with SIGTK_AMD_LIB for A/B runs)
-        L.sgk_event_configure_short.argtypes = [C.c_int]
-        L.sgk_event_configure_short.restype = C.c_int
+    ver = L.sgk_version().decode()
+    if tuple(int(x) for x in ver.split(".")[:2]) < (0, 2):
+        raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2" % (path, ver))
+    OE, OS = C.POINTER(EventOptions), C.POINTER(StatOptions)
+    L.sgk_event_workspace_bytes_opt.restype = C.c_size_t
+    L.sgk_event_workspace_bytes_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, OE]
+    L.sgk_event_opt.argtypes = L.sgk_event.argtypes + [OE]
+    L.sgk_event_pa_opt.argtypes = L.sgk_event_pa.argtypes + [OE]
+    L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, OE, C.POINTER(EventPlan)]
+    L.sgk_event_plan.restype = C.c_int
     L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sgk_stat_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sgk_jnn.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
     L.sgk_prefix.argtypes = [C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    for f in ("sgk_stat", "sgk_stat_pa", "sgk_jnn", "sgk_prefix"):
+        getattr(L, f + "_opt").argtypes = getattr(L, f).argtypes + [OS]
     L.sgk_svbzd_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
     L.sgk_synth_reads.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
@@ -187,7 +246,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_job_submit_qts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.sgk_job_wait.argtypes = [C.c_void_p]
     L.sgk_job_output.argtypes = [C.c_void_p, C.POINTER(JobOutput)]
+    L.sgk_job_set_options.argtypes = [C.c_void_p, OE, OS]
     L.sgk_event_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.POINTER(EventsHost)]
+    L.sgk_event_host_opt.argtypes = L.sgk_event_host.argtypes + [OE]
     L.sgk_events_host_free.argtypes = [C.POINTER(EventsHost)]
     L.sgk_events_host_free.restype = None
     L.sgk_pa_host.argtypes = [C.POINTER(HostBatch), C.c_void_p]
@@ -196,6 +257,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_segs_host_free.argtypes = [C.POINTER(SegsHost)]
     L.sgk_segs_host_free.restype = None
     L.sgk_prefix_host.argtypes = [C.POINTER(HostBatch), C.c_int, C.c_int, C.c_void_p]
+    L.sgk_stat_host_opt.argtypes = L.sgk_stat_host.argtypes + [OS]
+    L.sgk_jnn_host_opt.argtypes = L.sgk_jnn_host.argtypes + [OS]
+    L.sgk_prefix_host_opt.argtypes = L.sgk_prefix_host.argtypes + [OS]
     L.sgk_signal_in_picoamps.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double]
     L.sgk_signal_in_picoamps.restype = C.POINTER(C.c_float)
     _lib = L
@@ -256,7 +320,7 @@ def event(reads: Sequence[np.ndarray], dig, off, rng, rna: int):
     L = load_library()
     hb = _HB(reads, dig, off, rng)
     ev = EventsHost()
-    check(L.sgk_event_host(C.byref(hb.c), int(rna), C.byref(ev)), "sgk_event_host")
+    check(L.sgk_event_host_opt(C.byref(hb.c), int(rna), C.byref(ev), C.byref(EVENT_OPTIONS)), "sgk_event_host_opt")
     try:
         offs = _np_from(ev.ev_offsets, hb.n + 1, np.uint64)
         tot = int(offs[-1]) if hb.n else 0
@@ -279,7 +343,7 @@ def stat(reads: Sequence[np.ndarray], dig, off, rng) -> np.ndarray:
     L = load_library()
     hb = _HB(reads, dig, off, rng)
     out = np.zeros(max(hb.n, 1), dtype=STAT_DTYPE)
-    check(L.sgk_stat_host(C.byref(hb.c), out.ctypes.data), "sgk_stat_host")
+    check(L.sgk_stat_host_opt(C.byref(hb.c), out.ctypes.data, C.byref(STAT_OPTIONS)), "sgk_stat_host_opt")
     return out[:hb.n]
 
 
@@ -288,7 +352,7 @@ def jnn(reads: Sequence[np.ndarray], dig, off, rng, rna: int):
     L = load_library()
     hb = _HB(reads, dig, off, rng)
     sg = SegsHost()
-    check(L.sgk_jnn_host(C.byref(hb.c), int(rna), C.byref(sg)), "sgk_jnn_host")
+    check(L.sgk_jnn_host_opt(C.byref(hb.c), int(rna), C.byref(sg), C.byref(STAT_OPTIONS)), "sgk_jnn_host_opt")
     try:
         offs = _np_from(sg.seg_offsets, hb.n + 1, np.uint64)
         tot = int(offs[-1]) if hb.n else 0
@@ -304,7 +368,8 @@ def prefix(reads: Sequence[np.ndarray], dig, off, rng, rna: int, pore: int) -> n
     L = load_library()
     hb = _HB(reads, dig, off, rng)
     out = np.zeros(max(hb.n, 1), dtype=PREFIX_DTYPE)
-    check(L.sgk_prefix_host(C.byref(hb.c), int(rna), int(pore), out.ctypes.data), "sgk_prefix_host")
+    check(L.sgk_prefix_host_opt(C.byref(hb.c), int(rna), int(pore), out.ctypes.data, C.byref(STAT_OPTIONS)),
+          "sgk_prefix_host_opt")
     return out[:hb.n]
 
 
@@ -452,6 +517,13 @@ class Job:
         self.L = load_library()
         self.h = C.c_void_p()
         check(self.L.sgk_job_create(device, C.byref(self.h)), "sgk_job_create")
+        self.set_options()
+
+    def set_options(self, event_opt: "EventOptions" = None, stat_opt: "StatOptions" = None):
+        """the options the job's submits use from now on (default: this module's EVENT_OPTIONS / STAT_OPTIONS as they
+        are NOW: the job keeps a copy)"""
+        check(self.L.sgk_job_set_options(self.h, C.byref(event_opt if event_opt is not None else EVENT_OPTIONS),
+                                         C.byref(stat_opt if stat_opt is not None else STAT_OPTIONS)), "sgk_job_set_options")
 
     def close(self):
         if self.h:

@@ -54,80 +54,116 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(g_prof[slot].t1, stream);
 }
 
-// ---------------------------------------------------------------- workspace layout (event)
-static std::mutex g_seg_mu;
-static EvSegConfig g_seg_cfg;
-static bool g_seg_cfg_set = false;
-static EvSegConfig seg_config_checked(long long seg, long long lmin, long lead) {
+// ---------------------------------------------------------------- event options -> configuration
+// (no process-wide state: every entry point derives its configuration from the caller's options)
+EvSegConfig event_config(const sgk_event_options_t *o) {
     EvSegConfig c;
     c.seg_len = 131072;    // one wavefront's share of a long read: ~0.6 ms of detector + builder
     c.long_min = 262144;   // reads at least this long are cut into segments
     c.lead_override = 0;
-    if (seg >= 1024 && seg <= (1ll << 30)) c.seg_len = (uint32_t)(seg / 1024 * 1024);
-    if (lmin >= 1) c.long_min = lmin > 0xffffffffll ? 0xffffffffu : (uint32_t)lmin;
-    if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
-    if (lead >= 16 && lead <= 512) c.lead_override = (int)(lead / 16 * 16);
     c.multi = 0;
     c.multi_max = 0;
+    c.tail_split = 0;
+    if (!o) return c;
+    if (o->segment_len >= 1024 && o->segment_len <= (1u << 30)) c.seg_len = o->segment_len / 1024 * 1024;
+    if (o->long_min >= 1) c.long_min = o->long_min;
+    if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
+    if (o->warmup >= 16 && o->warmup <= 512) c.lead_override = o->warmup / 16 * 16;
+    if (o->lanes_per_short_read < 0) c.multi = -1;
+    else if (o->lanes_per_short_read > 0) {
+        int p = 1;
+        while (p * 2 <= o->lanes_per_short_read && p < 32) p *= 2;
+        c.multi = p;
+    }
+    if (o->short_max >= 1024) {
+        uint32_t p2 = 1024;
+        while (p2 < (1u << 30) && (uint64_t)p2 * 2 <= o->short_max) p2 *= 2;
+        c.multi_max = p2;
+    }
+    c.tail_split = o->tail_split < 0 ? -1 : 0;
     return c;
 }
-static int multi_checked(long v) {
-    if (v < 0) return -1;
-    int p = 1;
-    while (p * 2 <= v && p < 32) p *= 2;
-    return v == 0 ? 0 : p;
-}
-EvSegConfig event_seg_config() {
-    std::lock_guard<std::mutex> lk(g_seg_mu);
-    if (!g_seg_cfg_set) {
-        // development / tests: short segments put seams into ordinary reads, a short warm-up makes speculation fail
-        const char *e1 = getenv("SGK_EVENT_SEG"), *e2 = getenv("SGK_EVENT_LONG_MIN"), *e3 = getenv("SGK_EVENT_LEAD");
-        g_seg_cfg = seg_config_checked(e1 ? atoll(e1) : 0, e2 ? atoll(e2) : 0, e3 ? atol(e3) : 0);
-        if (const char *e4 = getenv("SGK_EVENT_MULTI")) g_seg_cfg.multi = multi_checked(atol(e4));
-        if (const char *e5 = getenv("SGK_EVENT_MULTI_MAX")) {   // development: the length below which a read is short
-            const long v = atol(e5);
-            uint32_t p2 = 1024;
-            while (p2 < (1u << 30) && (long)p2 * 2 <= v) p2 *= 2;
-            if (v >= 1024) g_seg_cfg.multi_max = p2;
-        }
-        g_seg_cfg_set = true;
+
+// Resident wavefront slots of the current device for the event kernels (CUs x 4 SIMDs x waves per SIMD: 3 with the
+// DNA preset, 2 with RNA parameters)
+static uint32_t event_wave_slots(int rna) {
+    static std::mutex mu;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
     }
-    return g_seg_cfg;
-}
-void event_seg_configure(long long seg, long long lmin, long lead) {
-    (void)event_seg_config();  // (the environment first)
-    std::lock_guard<std::mutex> lk(g_seg_mu);
-    const int multi = g_seg_cfg.multi;
-    const uint32_t multi_max = g_seg_cfg.multi_max;
-    g_seg_cfg = seg_config_checked(seg, lmin, lead);
-    g_seg_cfg.multi = multi;
-    g_seg_cfg.multi_max = multi_max;
-}
-void event_multi_configure(int lanes) {
-    (void)event_seg_config();
-    std::lock_guard<std::mutex> lk(g_seg_mu);
-    g_seg_cfg.multi = multi_checked(lanes);
+    return (uint32_t)cus[dev] * 4u * (rna ? 2u : 3u);
 }
 
-void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
-                        uint32_t &max_long) {
-    const EvSegConfig c = event_seg_config();
+// The tail split (event_kernels.hip: seg_len_of).  A batch of fewer than 8 rounds of waves whose last round is neither
+// empty nor nearly full: the reads of that round (the last dispatch positions) are cut into segments, as many per read
+// as fill a round (2 .. 8), never shorter than 16 384 samples.  Not in a batch with packed short reads (they balance
+// by themselves), not for reads under 32 768 samples on average.
+// Measured (profiles/r04_*): 10 000 x 100 000 DNA 3.78 -> 3.67 ms, 9 300 reads 3.77 -> 3.52, 1 000 reads 0.78 -> 0.68;
+// the number of segments per read hardly matters (2 .. 16: 3.62 - 3.71 ms).
+void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                     bool packed, uint32_t &split_from, uint32_t &split_seg) {
+    split_from = n_reads;
+    split_seg = 0;
+    if (n_reads == 0 || packed || sc.tail_split < 0) return;
+    const uint32_t slots = event_wave_slots(rna);
+    const uint64_t mean = n_samples / n_reads;
+    if (mean < 32768 || n_reads >= 8ull * slots) return;
+    const uint32_t rem = n_reads % slots;
+    if (rem == 0 || rem > slots - slots / 8) return;
+    uint32_t G = (slots - slots / 16 + rem - 1) / rem;   // units of the split reads ~ one round
+    if (G < 2) G = 2;
+    if (G > 8) G = 8;
+    uint64_t seg = (mean + G - 1) / G;
+    seg = (seg + 1023) / 1024 * 1024;
+    if (seg < 16384) seg = 16384;
+    if (seg >= sc.long_min) return;   // (reads that long are cut anyway)
+    split_from = n_reads - rem;
+    split_seg = (uint32_t)seg;
+}
+
+void event_seg_capacity(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                        bool packed, uint32_t &max_segs, uint32_t &max_long) {
     max_segs = 0;
     max_long = 0;
-    if (max_read_len < c.long_min) return;
-    uint64_t nl = n_samples / c.long_min;
-    if (nl > n_reads) nl = n_reads;
-    if (nl < 1) nl = 1;
-    const uint64_t ns = n_samples / c.seg_len + nl;  // sum of ceil(n_r / seg_len) over at most nl reads
-    max_segs = ns > 0x7fffffffull ? 0x7fffffffu : (uint32_t)ns;
-    // every long read has at least two segments; k_seg_plan admits long reads while their segments fit
-    uint64_t ml = max_segs / 2;
-    if (ml < nl) ml = nl;
+    uint64_t ns = 0, ml = 0;
+    if (max_read_len >= c.long_min) {
+        uint64_t nl = n_samples / c.long_min;
+        if (nl > n_reads) nl = n_reads;
+        if (nl < 1) nl = 1;
+        ns = n_samples / c.seg_len + nl;  // sum of ceil(n_r / seg_len) over at most nl reads
+        // every long read has at least two segments; k_seg_plan admits long reads while their segments fit
+        ml = ns / 2;
+        if (ml < nl) ml = nl;
+    }
+    uint32_t sf = n_reads, ss = 0;
+    event_tail_plan(c, n_reads, n_samples, max_read_len, rna, packed, sf, ss);
+    if (ss) {
+        // the split reads: at most n_reads - sf of them, each under long_min samples
+        const uint64_t nsplit = n_reads - sf;
+        ns += nsplit * (((uint64_t)c.long_min + ss - 1) / ss);
+        ml += nsplit;
+    }
     if (ml > n_reads) ml = n_reads;
+    max_segs = ns > 0x7fffffffull ? 0x7fffffffu : (uint32_t)ns;
     max_long = (uint32_t)ml;
 }
 
-EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, size_t available) {
+// whether a batch with these totals gets packed short reads (k_event_multi)
+static bool event_batch_packed(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna) {
+    uint32_t lanes = 0, mmax = 0;
+    const bool sorted = n_reads >= ORDER_MIN_READS && (uint64_t)max_read_len * n_reads > n_samples + n_samples / 4;
+    event_multi_plan(c, n_reads, n_samples, max_read_len, rna, sorted, lanes, mmax);
+    return lanes != 0;
+}
+
+EvWorkspace event_workspace_layout(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len,
+                                   size_t available) {
     EvWorkspace w;
     const uint64_t nr = n_reads ? n_reads : 1;
     size_t o = 0;
@@ -136,11 +172,17 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
     w.off_list = o;    o += round_up(nr * 4, 64);
     w.off_order = o;   o += round_up(nr * 4 + 128 * 4, 64);
     w.off_bitmap = o;  o += round_up((n_samples / 64 + nr + 2) * 8, 64);
-    event_seg_capacity(n_reads, n_samples, max_read_len, w.max_segs, w.max_long);
+    // (the layout does not know the preset: the larger of the two presets' capacities)
+    {
+        uint32_t s0 = 0, l0 = 0, s1 = 0, l1 = 0;
+        event_seg_capacity(c, n_reads, n_samples, max_read_len, 0, event_batch_packed(c, n_reads, n_samples, max_read_len, 0), s0, l0);
+        event_seg_capacity(c, n_reads, n_samples, max_read_len, 1, event_batch_packed(c, n_reads, n_samples, max_read_len, 1), s1, l1);
+        w.max_segs = s0 > s1 ? s0 : s1;
+        w.max_long = l0 > l1 ? l0 : l1;
+    }
     w.off_segs = o;       o += round_up((size_t)w.max_segs * sizeof(SegDesc), 64);
     w.off_seg_state = o;  o += round_up((size_t)w.max_segs * sizeof(SegState), 64);
     w.off_longs = o;      o += round_up((size_t)w.max_long * sizeof(LongRead), 64);
-    w.off_runs = o;       o += round_up((size_t)nr * 64u * 8u * sizeof(LzRun), 64);
     w.off_scratch = o;
     w.scratch_stride = round_up(2ull * ((uint64_t)max_read_len + 1), 2);
     const size_t per_block = (size_t)w.scratch_stride * sizeof(double);
@@ -161,7 +203,6 @@ EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_
 }
 
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st);
-unsigned long long debug_exact_redo_count(bool reset);
 int launch_synth(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
                  double *rng, uint32_t n_reads, uint32_t max_read_len, uint64_t first_read, uint64_t seed, int kind,
                  hipStream_t st);
@@ -179,9 +220,8 @@ int check_batch(const sgk_batch_t *b) {
 // k_event_multi gives a read fewer lanes and a wave several reads.  Worth it when the batch has enough reads to fill
 // the GPU that way (>= 4 rounds of waves) -- a small batch wants every lane it can get.  `sorted`: the batch gets a
 // dispatch order (its short reads are the order's tail); without one the batch must be short as a whole.
-void event_multi_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, bool sorted,
-                      uint32_t &multi_lanes, uint32_t &multi_max) {
-    const EvSegConfig sc = event_seg_config();
+void event_multi_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                      bool sorted, uint32_t &multi_lanes, uint32_t &multi_max) {
     multi_lanes = 0;
     // (RNA parameters: warm-ups of 128 / 256 samples make the 64-lane layout 1.3 x its samples' worth up to ~64 k
     // samples: 33 333 x 30 000 samples 6.15 -> 5.13 ms; DNA parameters: 32 / 64, 20 000-sample reads already cost what
@@ -203,13 +243,15 @@ void event_multi_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_le
 static int run_event(const void *samples, bool float_input, const uint64_t *offsets, const uint32_t *lengths,
                      const double *dig, const double *off, const double *rng, uint32_t n_reads,
                      uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
-                     sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
+                     sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream,
+                     const sgk_event_options_t *opt) {
     if (n_reads == 0) return SGK_OK;
     if (!samples || !offsets || !lengths || !ev_slots || !events || !n_events || !ws) return SGK_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(samples) & 15u) return SGK_ERR_ALIGN;
     if (reinterpret_cast<uintptr_t>(events) & 15u) return SGK_ERR_ALIGN;
     if (reinterpret_cast<uintptr_t>(ws) & 63u) return SGK_ERR_ALIGN;
-    const EvWorkspace w = event_workspace_layout(n_reads, n_samples, max_read_len, ws_bytes);
+    const EvSegConfig sc = event_config(opt);
+    const EvWorkspace w = event_workspace_layout(sc, n_reads, n_samples, max_read_len, ws_bytes);
     if (w.n_fb_blocks == 0 || w.total > ws_bytes) return SGK_ERR_WORKSPACE;
     char *base = static_cast<char *>(ws);
     EvArgs a;
@@ -232,7 +274,6 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.bitmap = reinterpret_cast<unsigned long long *>(base + w.off_bitmap);
     a.scratch = reinterpret_cast<double *>(base + w.off_scratch);
     a.scratch_stride = w.scratch_stride;
-    const EvSegConfig sc = event_seg_config();
     a.max_segs = w.max_segs;
     a.max_long = w.max_long;
     a.seg_len = sc.seg_len;
@@ -241,13 +282,12 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
     a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
     a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
-    a.rec_runs = reinterpret_cast<LzRun *>(base + w.off_runs);
     const bool sorted = a.order != nullptr && n_reads >= ORDER_MIN_READS;
-    event_multi_plan(n_reads, n_samples, max_read_len, rna, sorted, a.multi_lanes, a.multi_max);
-    {
-        const char *e = getenv("SGK_EVENT_REC");   // development switch, removed with the old path
-        a.rec_on = e ? (uint32_t)atoi(e) : 1u;
-    }
+    event_multi_plan(sc, n_reads, n_samples, max_read_len, rna, sorted, a.multi_lanes, a.multi_max);
+    event_tail_plan(sc, n_reads, n_samples, max_read_len, rna, a.multi_lanes != 0, a.split_from, a.split_seg);
+    a.has_long = max_read_len >= sc.long_min ? 1u : 0u;
+    a.seg_blocks = 0;
+    a.seg_last = 0;
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -345,23 +385,38 @@ int sgk_pa(const sgk_batch_t *batch, float *pa_out, void *stream) {
 }
 
 // ---------------------------------------------------------------- event
+size_t sgk_event_workspace_bytes_opt(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len,
+                                     const sgk_event_options_t *opt) {
+    return event_workspace_layout(event_config(opt), n_reads, n_samples, max_read_len, 0).total;
+}
 size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
-    return event_workspace_layout(n_reads, n_samples, max_read_len, 0).total;
+    return sgk_event_workspace_bytes_opt(n_reads, n_samples, max_read_len, nullptr);
 }
 
-int sgk_event(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
-              void *ws, size_t ws_bytes, void *stream) {
+int sgk_event_opt(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
+                  void *ws, size_t ws_bytes, void *stream, const sgk_event_options_t *opt) {
     const int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     return run_event(b->samples, false, b->offsets, b->lengths, b->digitisation, b->offset, b->range, b->n_reads,
-                     b->max_read_len, b->n_samples, rna, ev_slots, events, n_events, ws, ws_bytes, stream);
+                     b->max_read_len, b->n_samples, rna, ev_slots, events, n_events, ws, ws_bytes, stream, opt);
+}
+int sgk_event(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
+              void *ws, size_t ws_bytes, void *stream) {
+    return sgk_event_opt(b, rna, ev_slots, events, n_events, ws, ws_bytes, stream, nullptr);
 }
 
+int sgk_event_pa_opt(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
+                     uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
+                     sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream,
+                     const sgk_event_options_t *opt) {
+    return run_event(pa, true, offsets, lengths, nullptr, nullptr, nullptr, n_reads, max_read_len, n_samples, rna,
+                     ev_slots, events, n_events, ws, ws_bytes, stream, opt);
+}
 int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengths, uint32_t n_reads,
                  uint32_t max_read_len, uint64_t n_samples, int rna, const uint64_t *ev_slots,
                  sgk_event_rec_t *events, uint32_t *n_events, void *ws, size_t ws_bytes, void *stream) {
-    return run_event(pa, true, offsets, lengths, nullptr, nullptr, nullptr, n_reads, max_read_len, n_samples, rna,
-                     ev_slots, events, n_events, ws, ws_bytes, stream);
+    return sgk_event_pa_opt(pa, offsets, lengths, n_reads, max_read_len, n_samples, rna, ev_slots, events, n_events, ws,
+                            ws_bytes, stream, nullptr);
 }
 
 int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
@@ -383,17 +438,16 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
 }
 
-int sgk_event_configure(uint32_t seg_len, uint32_t long_min, int lead) {
-    sgk::event_seg_configure(seg_len, long_min, lead);
-    return SGK_OK;
-}
-int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, sgk_event_plan_t *out) {
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
+                   sgk_event_plan_t *out) {
     if (!out) return SGK_ERR_ARG;
-    const sgk::EvSegConfig sc = sgk::event_seg_config();
-    uint32_t max_segs = 0, max_long = 0, lanes = 0, mmax = 0;
-    sgk::event_seg_capacity(n_reads, n_samples, max_read_len, max_segs, max_long);
+    const sgk::EvSegConfig sc = sgk::event_config(opt);
+    uint32_t max_segs = 0, max_long = 0, lanes = 0, mmax = 0, sf = n_reads, ss = 0;
     const bool sorted = n_reads >= sgk::ORDER_MIN_READS && (uint64_t)max_read_len * n_reads > n_samples + n_samples / 4;
-    sgk::event_multi_plan(n_reads, n_samples, max_read_len, rna, sorted, lanes, mmax);
+    sgk::event_multi_plan(sc, n_reads, n_samples, max_read_len, rna, sorted, lanes, mmax);
+    sgk::event_seg_capacity(sc, n_reads, n_samples, max_read_len, rna, lanes != 0, max_segs, max_long);
+    sgk::event_tail_plan(sc, n_reads, n_samples, max_read_len, rna, lanes != 0, sf, ss);
+    memset(out, 0, sizeof *out);
     out->segment_len = sc.seg_len;
     out->long_min = sc.long_min;
     out->max_segments = max_segs;
@@ -401,16 +455,10 @@ int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, 
     out->short_max = mmax;
     out->lanes_per_short_read = lanes;
     out->warmup_override = (uint32_t)sc.lead_override;
-    out->reserved = 0;
+    out->tail_split_from = sf;
+    out->tail_segment_len = ss;
     return SGK_OK;
 }
-int sgk_event_configure_short(int lanes_per_read) {
-    sgk::event_multi_configure(lanes_per_read);
-    return SGK_OK;
-}
-
-// diagnostics (not part of the stable ABI): t-statistic evaluations redone by the exact path
-unsigned long long sgk_debug_exact_redo_count(int reset) { return sgk::debug_exact_redo_count(reset != 0); }
 
 // ---------------------------------------------------------------- synthetic reads
 int sgk_synth_reads(int16_t *samples, const uint64_t *offsets, const uint32_t *lengths, double *dig, double *off,
@@ -456,7 +504,7 @@ int sgk_pa_host(const sgk_host_batch_t *hb, float *pa_out) {
 
 // shared tail of sgk_event_host / sgk_getevents: run on an uploaded batch view (raw or pA input)
 static int event_collect(const void *d_samples, bool float_input, const DeviceBatch &db, const sgk_batch_t *view,
-                         int rna, sgk_events_host_t *out) {
+                         int rna, sgk_events_host_t *out, const sgk_event_options_t *opt = nullptr) {
     const uint32_t nr = (uint32_t)db.lengths.size();
     memset(out, 0, sizeof *out);
     out->n_reads = nr;
@@ -470,16 +518,16 @@ static int event_collect(const void *d_samples, bool float_input, const DeviceBa
     if ((rc = d_slots.alloc((nr + 1) * sizeof(uint64_t))) != SGK_OK) return rc;
     if ((rc = d_ev.alloc(nslots * sizeof(sgk_event_rec_t))) != SGK_OK) return rc;
     if ((rc = d_nev.alloc((size_t)nr * 4)) != SGK_OK) return rc;
-    const size_t wsb = sgk_event_workspace_bytes(nr, db.n_samples, db.max_len);
+    const size_t wsb = sgk_event_workspace_bytes_opt(nr, db.n_samples, db.max_len, opt);
     if ((rc = d_ws.alloc(wsb)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (float_input)
-        rc = sgk_event_pa(static_cast<const float *>(d_samples), view->offsets, view->lengths, nr, db.max_len,
-                          db.n_samples, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(),
-                          d_ws.p, wsb, nullptr);
+        rc = sgk_event_pa_opt(static_cast<const float *>(d_samples), view->offsets, view->lengths, nr, db.max_len,
+                              db.n_samples, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(),
+                              d_ws.p, wsb, nullptr, opt);
     else
-        rc = sgk_event(view, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(), d_ws.p, wsb,
-                       nullptr);
+        rc = sgk_event_opt(view, rna, d_slots.as<uint64_t>(), d_ev.as<sgk_event_rec_t>(), d_nev.as<uint32_t>(), d_ws.p, wsb,
+                           nullptr, opt);
     if (rc != SGK_OK) return rc;
     rc = sgk_event_status(d_ws.p, &out->status, nullptr);
     if (rc != SGK_OK) return rc;
@@ -515,15 +563,18 @@ static int event_collect(const void *d_samples, bool float_input, const DeviceBa
     return SGK_OK;
 }
 
-int sgk_event_host(const sgk_host_batch_t *hb, int rna, sgk_events_host_t *out) {
+int sgk_event_host_opt(const sgk_host_batch_t *hb, int rna, sgk_events_host_t *out, const sgk_event_options_t *opt) {
     if (!out) return SGK_ERR_ARG;
     memset(out, 0, sizeof *out);
     DeviceBatch db;
     int rc = db.upload(hb);
     if (rc != SGK_OK) return rc;
-    rc = event_collect(db.view.samples, false, db, &db.view, rna, out);
+    rc = event_collect(db.view.samples, false, db, &db.view, rna, out, opt);
     if (rc != SGK_OK) sgk_events_host_free(out);
     return rc;
+}
+int sgk_event_host(const sgk_host_batch_t *hb, int rna, sgk_events_host_t *out) {
+    return sgk_event_host_opt(hb, rna, out, nullptr);
 }
 
 void sgk_events_host_free(sgk_events_host_t *ev) {

@@ -25,38 +25,51 @@ size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return o
 size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
 size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
 
-int sgk_stat(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream) {
+int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream,
+                 const sgk_stat_options_t *opt) {
     int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
+    a.kernels = opt ? opt->kernels : 0;
     a.stat = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
-int sgk_stat_pa(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream) {
+int sgk_stat(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream) {
+    return sgk_stat_opt(b, out, ws, ws_bytes, stream, nullptr);
+}
+
+int sgk_stat_pa_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream,
+                    const sgk_stat_options_t *opt) {
     int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out || !pa_out) return SGK_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(pa_out) & 15u) return SGK_ERR_ALIGN;
     StatArgs a = make_args(b);
+    a.kernels = opt ? opt->kernels : 0;
     a.stat = out;
     a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
-int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
-            uint32_t *n_segs, void *ws, size_t ws_bytes, void *stream) {
+int sgk_stat_pa(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, void *ws, size_t ws_bytes, void *stream) {
+    return sgk_stat_pa_opt(b, out, pa_out, ws, ws_bytes, stream, nullptr);
+}
+
+int sgk_jnn_opt(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
+                uint32_t *n_segs, void *ws, size_t ws_bytes, void *stream, const sgk_stat_options_t *opt) {
     int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!seg_slots || !seg_x || !seg_y || !n_segs || !ws) return SGK_ERR_ARG;
     if (ws_bytes < 64) return SGK_ERR_WORKSPACE;
     StatArgs a = make_args(b);
+    a.kernels = opt ? opt->kernels : 0;
     a.seg_slots = seg_slots;
     a.seg_x = seg_x;
     a.seg_y = seg_y;
@@ -66,21 +79,32 @@ int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *s
     return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
-int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
-               void *stream) {
+int sgk_jnn(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_t *seg_x, int32_t *seg_y,
+            uint32_t *n_segs, void *ws, size_t ws_bytes, void *stream) {
+    return sgk_jnn_opt(b, rna, seg_slots, seg_x, seg_y, n_segs, ws, ws_bytes, stream, nullptr);
+}
+
+int sgk_prefix_opt(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
+                   void *stream, const sgk_stat_options_t *opt) {
     int rc = check_batch(b);
     if (rc != SGK_OK) return rc;
     if (b->n_reads == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
+    a.kernels = opt ? opt->kernels : 0;
     a.prefix = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
 }
 
+int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
+               void *stream) {
+    return sgk_prefix_opt(b, rna, pore, out, ws, ws_bytes, stream, nullptr);
+}
+
 // ---------------------------------------------------------------- host layer
 
-int sgk_stat_host(const sgk_host_batch_t *hb, sgk_stat_rec_t *out) {
+int sgk_stat_host_opt(const sgk_host_batch_t *hb, sgk_stat_rec_t *out, const sgk_stat_options_t *opt) {
     DeviceBatch db;
     int rc = db.upload(hb);
     if (rc != SGK_OK) return rc;
@@ -89,13 +113,16 @@ int sgk_stat_host(const sgk_host_batch_t *hb, sgk_stat_rec_t *out) {
     if (!out) return SGK_ERR_ARG;
     DevBuf d_out;
     if ((rc = d_out.alloc(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
-    if ((rc = sgk_stat(&db.view, d_out.as<sgk_stat_rec_t>(), nullptr, 0, nullptr)) != SGK_OK) return rc;
+    if ((rc = sgk_stat_opt(&db.view, d_out.as<sgk_stat_rec_t>(), nullptr, 0, nullptr, opt)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_stat_rec_t), hipMemcpyDeviceToHost));
     return SGK_OK;
 }
 
-int sgk_prefix_host(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefix_rec_t *out) {
+int sgk_stat_host(const sgk_host_batch_t *hb, sgk_stat_rec_t *out) { return sgk_stat_host_opt(hb, out, nullptr); }
+
+int sgk_prefix_host_opt(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefix_rec_t *out,
+                        const sgk_stat_options_t *opt) {
     DeviceBatch db;
     int rc = db.upload(hb);
     if (rc != SGK_OK) return rc;
@@ -104,13 +131,18 @@ int sgk_prefix_host(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefix_re
     if (!out) return SGK_ERR_ARG;
     DevBuf d_out;
     if ((rc = d_out.alloc(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
-    if ((rc = sgk_prefix(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), nullptr, 0, nullptr)) != SGK_OK) return rc;
+    if ((rc = sgk_prefix_opt(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), nullptr, 0, nullptr, opt)) != SGK_OK)
+        return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_prefix_rec_t), hipMemcpyDeviceToHost));
     return SGK_OK;
 }
 
-int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
+int sgk_prefix_host(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefix_rec_t *out) {
+    return sgk_prefix_host_opt(hb, rna, pore, out, nullptr);
+}
+
+int sgk_jnn_host_opt(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out, const sgk_stat_options_t *opt) {
     if (!out) return SGK_ERR_ARG;
     memset(out, 0, sizeof *out);
     DeviceBatch db;
@@ -130,8 +162,8 @@ int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
     if ((rc = d_n.alloc((size_t)nr * 4)) != SGK_OK) return rc;
     if ((rc = d_ws.alloc(64)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    rc = sgk_jnn(&db.view, rna, d_slots.as<uint64_t>(), d_x.as<int32_t>(), d_y.as<int32_t>(), d_n.as<uint32_t>(),
-                 d_ws.p, 64, nullptr);
+    rc = sgk_jnn_opt(&db.view, rna, d_slots.as<uint64_t>(), d_x.as<int32_t>(), d_y.as<int32_t>(), d_n.as<uint32_t>(),
+                     d_ws.p, 64, nullptr, opt);
     if (rc != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     uint32_t nerr = 0;
@@ -158,6 +190,8 @@ int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) {
     }
     return SGK_OK;
 }
+
+int sgk_jnn_host(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out) { return sgk_jnn_host_opt(hb, rna, out, nullptr); }
 
 void sgk_segs_host_free(sgk_segs_host_t *s) {
     if (!s) return;

@@ -64,7 +64,8 @@ struct SegState {           // 320 bytes per segment
 };
 static_assert(sizeof(SegState) == 320, "SegState layout");
 struct LongRead {
-    uint32_t read, seg0, nseg, pad;
+    uint32_t read, seg0, nseg;
+    uint32_t seg_len;   // long reads: EvArgs::seg_len; reads of the tail split: EvArgs::split_seg
 };
 
 struct EvArgs {
@@ -95,8 +96,11 @@ struct EvArgs {
     // short reads (multi_lanes == 0: every read has a wavefront of its own)
     uint32_t multi_lanes;           // lanes per short read (a power of two below 64): k_event_multi packs 64 / lanes reads
     uint32_t multi_max;             // reads shorter than this (a power of two) are short
-    uint32_t rec_on;                // events straight from the detector pass where k_event can (round 4)
-    LzRun *rec_runs;                // ... its lanes' hot-run records: n_reads x 64 x 8
+    // tail split (k_seg_plan): reads at dispatch positions >= split_from are cut into split_seg-sample segments
+    uint32_t split_from, split_seg;  // (split_from >= n_reads: none)
+    uint32_t has_long;               // the batch may hold reads of long_min samples or more
+    uint32_t seg_blocks;             // k_event: its first seg_blocks workgroups take segments (set per launch)
+    uint32_t seg_last;               // ... its last ones instead
 };
 
 struct EvSegConfig {
@@ -104,23 +108,24 @@ struct EvSegConfig {
     int lead_override;
     int multi;  // lanes per short read: 0 = chosen per batch, -1 = off (64 lanes per read), 1 .. 32 = forced
     uint32_t multi_max;  // 0 = default; reads shorter than this (a power of two) count as short
+    int tail_split;      // 0 = chosen per batch, -1 = off
 };
-EvSegConfig event_seg_config();  // defaults, or SGK_EVENT_SEG / SGK_EVENT_LONG_MIN / SGK_EVENT_LEAD from the environment
-void event_seg_configure(long long seg, long long lmin, long lead);
-void event_multi_configure(int lanes);
-void event_multi_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, bool sorted,
-                      uint32_t &multi_lanes, uint32_t &multi_max);
-void event_seg_capacity(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, uint32_t &max_segs,
-                        uint32_t &max_long);
+EvSegConfig event_config(const sgk_event_options_t *opt);  // null: the defaults
+void event_multi_plan(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                      bool sorted, uint32_t &multi_lanes, uint32_t &multi_max);
+void event_tail_plan(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                     bool packed, uint32_t &split_from, uint32_t &split_seg);
+void event_seg_capacity(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                        bool packed, uint32_t &max_segs, uint32_t &max_long);
 
 // workspace carving shared by sgk_event_workspace_bytes and sgk_event
 struct EvWorkspace {
-    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_segs, off_seg_state, off_longs, off_runs, off_scratch, total;
+    size_t off_hdr, off_flags, off_list, off_order, off_bitmap, off_segs, off_seg_state, off_longs, off_scratch, total;
     uint32_t max_segs, max_long;
     uint64_t scratch_stride;
     uint32_t n_fb_blocks;
 };
-EvWorkspace event_workspace_layout(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len,
+EvWorkspace event_workspace_layout(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len,
                                    size_t available /* 0 = default sizing */);
 
 int launch_event(const EvArgs &a, int rna, bool float_input, uint32_t n_fb_blocks, hipStream_t st);

@@ -30,7 +30,6 @@
 //                    compute_sum_sumsq's sequential double prefix scan (events.c:293-303) into workspace
 //                    scratch, then the same detector and builder run with window/event sums taken as
 //                    differences of those arrays, exactly as the reference does.
-//   (k_event_detect / k_event_build: detector and builder as two kernels, SGK_EVENT_FUSED=0, development)
 //
 // Exactness guard: the reference accumulates double prefix sums sequentially and uses their differences; the
 // fast path forms window sums and event sums directly.  Both give the real-number sums (hence identical bits)
@@ -39,6 +38,7 @@
 // for x and for the float squares, and that every non-zero |x| lies in [2^-20, 2^20] (the range in which the
 // certified fast arithmetic of tstat_math.h has no subnormal intermediate); reads failing the check take the
 // fallback kernel.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -328,14 +328,11 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, int 
 //  * emitted peaks go to a per-lane 512-position bitmap ring in LDS and leave as whole words.
 // Positions inside a pass are BLOCK-relative (the 16-step unrolled block's first index = 0), so every position the
 // automaton writes is an inline constant; they are rebased once per block.
-#ifndef SGK_NP_DNA
-#define SGK_NP_DNA 8
-#endif
 template <int W1>
 struct LzCfg {
     static constexpr int W2 = 2 * W1;
     static constexpr int R = 16;                    // unroll (multiple of every ring length)
-    static constexpr int NP = (W1 == 3) ? SGK_NP_DNA : 16;   // prefix ring >= W2 + 2
+    static constexpr int NP = (W1 == 3) ? 8 : 16;   // prefix ring >= W2 + 2
     static constexpr int NA = (W1 == 3) ? 4 : 8;    // short A-side ring >= W1
     static constexpr int NL = (W1 == 3) ? 8 : 16;   // long side ring >= W2
     static constexpr int H1 = W1 / 2;
@@ -361,82 +358,13 @@ struct LzLds {
     LzSnap snap;
     LzRun runs[64][LZ_NREC];
     int nrec[64];
-    static constexpr int NREC = LZ_NREC;
-    __device__ __forceinline__ LzRun *runs_of(int l) { return runs[l]; }
-    __device__ __forceinline__ LzSnapState &init(int l) { return snap.init[l]; }
-    __device__ __forceinline__ LzSnapState &at_e(int l) { return snap.at_e[l]; }
-    __device__ __forceinline__ LzSnapState &st0(int l) { return snap.st0[l]; }
-};
-
-// ---- round 4: events straight from the detector pass ("REC") ---------------------------------------------------
-// The pass keeps the exact running prefix sums P(i), P2(i) anyway.  On the record path it takes them whenever the
-// automaton sets peak_pos (LDS slot `cur`), and when the peak is emitted the lane appends {length, (float)(P(pos) -
-// P(prev)), (float)(P2(pos) - P2(prev))} -- create_event's two sums, events.c:457-473 -- to a six-record staging area
-// in LDS; twice per 16-step block the lanes that hold four or more write them as ONE aligned 64-byte burst to their
-// chunk's provisional range of the read's event slots (16-byte stores to 64 streams per wave are what this memory
-// system is worst at: round 3's form of this lost 2.1 ms to partial-line write requests).  After the pass a per-event
-// sweep (finish_rec) turns the records into events and moves them to their final slots, in place, 64 at a time with
-// coalesced 16-byte loads and stores; the first event of every lane (it straddles a chunk seam) and the read's last
-// event are summed from the samples.  No bitmap, no second walk over the samples, no per-sample builder.
-typedef short sgk_s2 __attribute__((ext_vector_type(2)));
-constexpr int REC_NREC = 8;    // hot long-detector runs a lane can record per pass on this path (more: exact fallback)
-constexpr int REC_STAGE = 8;   // staged records per lane, a ring: <= 3 left over + <= 3 new ones per 8 steps (peaks are >= 3 apart)
-struct __attribute__((aligned(16))) RecPQ {
-    double P, Q;
-};
-struct LzLdsRec {
-    RecPQ prev[64];                    // prefix sums (the lane's origin) at the lane's last recorded boundary
-    RecPQ cur[64];                     // ... at its current peak position
-    uint32_t stag[64][REC_STAGE * 3];  // staged records {length, dS, dQ}
-    LzSnapState init_[64], at_e_[64];  // (a re-run's start state is handed over in init_)
-    int nrec[64];
-    LzRun *runs_base;                  // the lanes' hot-run records live in the workspace (a rare path; LDS is full)
-    static constexpr int NREC = REC_NREC;
-    __device__ __forceinline__ LzRun *runs_of(int l) { return runs_base + l * REC_NREC; }
-    // What a lane's accepted pass leaves for finish_rec, in the first words of the lane's own staging area (empty once
-    // the pass has written its records; a pass touches the staging areas of the lanes it runs only):
-    // [0] records written to the lane's provisional range, [1] read-relative position of its last boundary (-1: none),
-    // [2] / [3] extremes of the raw samples it has seen (packed 2 x int16: min, max)
-    __device__ __forceinline__ uint32_t &res(int l, int k) { return stag[l][k]; }
-    __device__ __forceinline__ const uint32_t &res(int l, int k) const { return stag[l][k]; }
-    __device__ __forceinline__ LzSnapState &init(int l) { return init_[l]; }
-    __device__ __forceinline__ LzSnapState &at_e(int l) { return at_e_[l]; }
-    __device__ __forceinline__ LzSnapState &st0(int l) { return init_[l]; }
-};
-static_assert(sizeof(LzLdsRec) <= 12544, "record path LDS budget: 12 waves per CU");
-// what a lane's accepted pass leaves for finish_rec (registers; a pass updates them for the lanes it runs)
-// 32-bit LDS addresses (a generic pointer kept in the pass state costs 64-bit address arithmetic on every use)
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef __attribute__((address_space(3))) double lds_f64;
-template <typename P>
-__device__ __forceinline__ uint32_t lds_addr(P *p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
-}
-// the chunk geometry of a record-path span, for finish_rec (wave-uniform)
-struct RecGeom {
-    int a, K, lead, last;   // span start, chunk length, warm-up, last lane with a chunk
-    uint32_t a16;           // address of the read's first slot in 16-byte units (burst alignment)
-    // first index of lane c's chunk / first slot of its provisional range, relative to the read's first slot.  In
-    // front of chunk start s at most s / 3 boundaries have been emitted (peaks are >= 3 apart and lie >= 2 behind the
-    // step that emits them), so slot s / 3 + 1 is never in front of the lane's final range: the sweep of finish_rec only
-    // ever moves records towards the read's first slot.  Rounded up so that the lane's 64-byte bursts are aligned in
-    // memory (not for the last lane: its range ends with the read's slots).
-    __device__ __forceinline__ int start_of(int c) const { return c == 0 ? a : a + c * K + lead; }
-    __device__ __forceinline__ uint32_t prov_of(int c) const {
-        uint32_t x = c == 0 ? 0u : (uint32_t)((start_of(c) - a) / 3) + 1u;
-        if (c < last) x += (0u - (a16 + x)) & 3u;
-        return x;
-    }
 };
 
 // Exact (reference-expression) t-statistic at index i of a read, window sums formed directly from
 // the samples in global memory.  Out of line: only reached when a fast evaluation's certificate
 // fails (about 2^-12 of the evaluations) and in the long detector's replay.
-__device__ unsigned long long g_exact_redo_count = 0;  // diagnostics: uncertified evaluations redone
-
 template <typename T>
 __device__ __attribute__((noinline)) float tstat_exact_at(const T *base, Scale sc, int i, int w) {
-    atomicAdd(&g_exact_redo_count, 1ull);
     double A = 0.0, A2 = 0.0, B = 0.0, B2 = 0.0;
     for (int k = 0; k < w; ++k) {
         const float xa = to_pa(base[i - w + k], sc);
@@ -567,10 +495,9 @@ __device__ __attribute__((noinline)) void lz_emit_slow(uint32_t *ring, unsigned 
 // out of line (rare): a hot long-detector run [a, b) ended at the reset of index b (or at the read's end, b = n); the
 // lane whose chunk holds index b (for b = n: index n-1) replays it.  Lane c+1 meets the reset at its first index
 // with the state it shares with lane c, so exactly one lane records every run.
-__device__ __attribute__((noinline)) int lz_record(LzRun *runs, int nrec, int a, int b, int s, int e, int n,
-                                                   int cap = LZ_NREC) {
+__device__ __attribute__((noinline)) int lz_record(LzRun *runs, int nrec, int a, int b, int s, int e, int n) {
     if ((b >= s && b < e) || (b == n && e == n && s < n)) {
-        if (nrec < cap) {
+        if (nrec < LZ_NREC) {
             runs[nrec].a = a;
             runs[nrec].b = b;
         }
@@ -618,11 +545,9 @@ __device__ __forceinline__ bool lane_of(lmask_t m) { return __builtin_amdgcn_inv
 // straight from global memory one block ahead.  A wave touches 64 different 128-byte lines per load instruction;
 // each line is consumed over 4 consecutive blocks and stays in L2 meanwhile, so HBM traffic remains one pass over
 // the samples and there are no barriers or cooperative loads in the loop.
-template <int W1, typename T, bool FLAGGED, bool REC = false>
+template <int W1, typename T, bool FLAGGED>
 struct LazyPass {
     using C = LzCfg<W1>;
-    static_assert(!REC || (!FLAGGED && std::is_same<T, int16_t>::value && W1 == 3),
-                  "record path: DNA preset, raw input, unflagged reads");
     static constexpr int W2 = C::W2, R = C::R, NP = C::NP, NA = C::NA, NL = C::NL, H1 = C::H1;
     // rings
     double Ps[NP], Pq[NP];        // running prefix sums of x and of fl(x*x); slot of P(k) = k mod NP
@@ -658,19 +583,6 @@ struct LazyPass {
     int next_t;                   // FLAGGED only
     int dirty;                    // FLAGGED only: block-relative index up to which this lane's own window sums are
                                   // not trusted (an addition of ITS running prefix was inexact, see tstep)
-    // REC only: events straight from the pass (see LzLdsRec)
-    uint32_t rpq;                 // LDS address of this lane's slot in LzLdsRec::prev (cur: 1024 bytes behind)
-    uint32_t rstag;               // LDS address of this lane's staging area
-    int rhead;                    // ring slot of the oldest staged record (0 or 4)
-    int pprev;                    // pass-relative position of the lane's last recorded boundary (own start before the first)
-    int cntS;                     // staged records (written ones: provoff)
-    uint32_t provoff;             // byte offset into the read's event slots of the lane's next burst
-    uint32_t capend;              // wave-uniform: end of the read's slots in bytes (no store may pass it; a lane that
-                                  // leaves its own range is caught at the pass' end)
-    char *evbase;                 // the read's first event slot (wave-uniform)
-    lmask_t own;                  // lanes inside their own step range: their emissions are recorded
-    lmask_t rovf;                 // lanes whose provisional range overflowed
-    int nrec_cap;                 // hot runs a lane can record
 
     // Unconditional 32-byte load of x[pos .. pos+16).  Positions outside the readable range are redirected to the
     // nearest readable group: whatever value a position yields is used consistently (it enters the prefix sum once),
@@ -738,8 +650,7 @@ struct LazyPass {
     // One step of the short detector (events.c:383-440, k = 0) and of the lazy long detector's bookkeeping, on lane
     // masks.  u: block-relative index (an inline constant in the fast form); live: lanes that take the step.
     template <bool SLOW>
-    __device__ __forceinline__ void dstep_core(const int u, const float v, const lmask_t hck, const lmask_t live,
-                                               const double Pu = 0.0, const double Qu = 0.0) {
+    __device__ __forceinline__ void dstep_core(const int u, const float v, const lmask_t hck, const lmask_t live) {
         constexpr float ph = DetParam<W1>::ph, thr1 = DetParam<W1>::thr1;
         const float d1 = v - sv;
         const float ee = lane_of(inpk) ? d1 : -d1;   // in a peak: v - peak_value; before one: peak_value - v
@@ -768,40 +679,7 @@ struct LazyPass {
         // the usual emitted peak was set exactly H1+1 indices ago: its position is the same in every lane, and so
         // is its bit in the lane's current bitmap word
         const uint32_t bit = 1u << ((jb + u - H1 - 1) & 31);
-        if constexpr (REC) {
-            if (lane_of(em)) {
-                lm = sp;
-                r0 = u;
-            }
-            // a lane records the emissions of its own step range [s, e), wherever the peak lies: a peak inherited with
-            // the (verified) start state belongs to the lane that emits it.  cur holds P at the peak position.
-            const lmask_t emr = em & own & ~done;
-#ifndef SGK_X_NOEMIT
-            if (emr != 0ull) {
-                if (lane_of(emr)) {
-                    lds_f64 *pq = (lds_f64 *)(uintptr_t)rpq;   // {P, Q} of prev; cur 128 doubles behind
-                    const double cP = pq[128], cQ = pq[129];
-                    const float dS = (float)(cP - pq[0]), dQ = (float)(cQ - pq[1]);
-                    pq[0] = cP;
-                    pq[1] = cQ;
-                    const int ppos = jb + sp;
-                    lds_u32 *slot = (lds_u32 *)(uintptr_t)(rstag + ((uint32_t)(rhead + cntS) & 7u) * 12u);
-                    slot[0] = (uint32_t)(ppos - pprev);
-                    slot[1] = __float_as_uint(dS);
-                    slot[2] = __float_as_uint(dQ);
-                    pprev = ppos;
-                    cntS += 1;
-                }
-            }
-#endif
-#ifndef SGK_X_NOCAP
-            if (lane_of(pos)) {
-                lds_f64 *pq = (lds_f64 *)(uintptr_t)rpq;
-                pq[128] = Pu;
-                pq[129] = Qu;
-            }
-#endif
-        } else if (SLOW && oldpeak) {
+        if (SLOW && oldpeak) {
             // some lane holds a peak older than the bitmap ring reaches (or one from before the pass)
             if (lane_of(em)) {
                 lz_emit_slow(ring, bm, flushed, i_begin, s, e, jb + sp, jb + u);
@@ -842,7 +720,7 @@ struct LazyPass {
         // peak's last reset (its emission); resets in between leave nothing behind
         const lmask_t rec = dom & hot;
         if (rec != 0ull) {
-            if (lane_of(rec)) nrec = lz_record(runs, nrec, ib + max(r0, lm + W1 + 1), ib + u, s, e, n, nrec_cap);
+            if (lane_of(rec)) nrec = lz_record(runs, nrec, ib + max(r0, lm + W1 + 1), ib + u, s, e, n);
         }
         lmask_t on = __ballot(lm < u - W1);
         if constexpr (SLOW) on &= live;
@@ -856,11 +734,6 @@ struct LazyPass {
     }
     template <int U>
     __device__ __forceinline__ void dstep() {
-        if constexpr (REC) {
-            // (one index at a time: tstep<U + 1> has not run, the ring still holds P(ib + U))
-            dstep_core<false>(U, t1[U & 3], hc[U & 3], ~0ull, Ps[U % NP], Pq[U % NP]);
-            return;
-        }
         if constexpr (U == H1 + 1) {
             if ((jb & 16) == 0) bw_advance();
         }
@@ -870,37 +743,11 @@ struct LazyPass {
     // the read's end are frozen
     template <int U>
     __device__ __forceinline__ void dstep_edge() {
-        const lmask_t live = ~done & __ballot((unsigned)(ib + U) < (unsigned)n);
-        if constexpr (REC) {
-            dstep_core<true>(U, t1[U & 3], hc[U & 3], live, Ps[U % NP], Pq[U % NP]);
-            return;
-        }
         if constexpr (U == H1 + 1) {
             if ((jb & 16) == 0) bw_advance();
         }
+        const lmask_t live = ~done & __ballot((unsigned)(ib + U) < (unsigned)n);
         dstep_core<true>(U, t1[U & 3], hc[U & 3], live);
-    }
-    // REC: lanes that hold four or more staged records write four of them as one aligned 64-byte burst.  (Tried: four
-    // lanes per burst, one record each, through a rank-ordered list in LDS -- 16 lines per store instruction instead of 64;
-    // the two dependent LDS round trips per round cost more than the address path saves: 5.8 vs 4.9 ms.)
-    __device__ __forceinline__ void rec_flush4() {
-        const lmask_t fl = __ballot(cntS >= 4);
-        if (fl == 0ull) return;
-        const lmask_t bad = fl & __ballot(provoff + 64u > capend);
-        rovf |= bad;
-#ifndef SGK_X_NOSTORE
-        if (lane_of(fl & ~bad)) {
-            const lds_u32 *st = (const lds_u32 *)(uintptr_t)(rstag + (uint32_t)rhead * 12u);
-            uint4 *dst = reinterpret_cast<uint4 *>(evbase + provoff);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k] = make_uint4(0u, st[3 * k], st[3 * k + 1], st[3 * k + 2]);
-        }
-#endif
-        if (lane_of(fl)) {
-            rhead ^= 4;
-            provoff += 64u;
-            cntS -= 4;
-        }
     }
     // the statistic is defined as 0 at the read's first / last W1 indices (events.c:332-338)
     // ... and so is the long window's at the last W2: it cannot exceed thr2 there.  (Its window sums reach behind the
@@ -916,48 +763,9 @@ struct LazyPass {
         }
     }
 
-    // one index at a time -- t-statistic, redo check, automaton step (the record path: the automaton's step at index i
-    // takes P(i) from the prefix ring before the next t-statistic overwrites it; DNA preset: no slower than four at a time)
-    template <int U>
-    __device__ __forceinline__ void single() {
-        tstep<U>();
-        if (slow) {
-            const bool in1 = (unsigned)(ib + U - W1) < cnt1;
-            t1[U & 3] = in1 ? t1[U & 3] : 0.0f;
-            nk[U & 3] &= __ballot(in1);
-            hc[U & 3] &= __ballot((unsigned)(ib + U - W2) < cnt2);
-        }
-        const lmask_t bad = nk[U & 3] & ~done;
-        if (bad != 0ull) {
-            if (lane_of(bad)) {
-                const Redo4 r4 = redo_quad<W1, T, FLAGGED>(base, sc, rep.P, rep.P2, ib + U - (U & 3), cnt1, 1u << (U & 3), t1[0], t1[1],
-                                                           t1[2], t1[3]);
-                t1[U & 3] = r4.v[U & 3];
-            }
-        }
-        if (slow) dstep_edge<U>();
-        else dstep<U>();
-    }
     // four indices U0..U0+3
     template <int U0>
     __device__ __forceinline__ void quad() {
-        if constexpr (REC) {
-            single<U0>();
-            single<U0 + 1>();
-            single<U0 + 2>();
-            single<U0 + 3>();
-            if constexpr ((U0 & 7) == 4) rec_flush4();
-            return;
-        }
-#ifdef SGK_EXP_UNBATCH
-        if constexpr (!FLAGGED) {
-            single<U0>();
-            single<U0 + 1>();
-            single<U0 + 2>();
-            single<U0 + 3>();
-            return;
-        }
-#endif
         tstep<U0>();
         tstep<U0 + 1>();
         tstep<U0 + 2>();
@@ -1059,43 +867,10 @@ __device__ __forceinline__ void lz_flush(uint32_t *ring, unsigned long long *bm,
 //   steps  : indices every lane runs (wave-uniform: warm-up + chunk length)
 //   active : whether this lane runs in this pass
 // Writes the lane's bitmap words, its hot-run records and (speculative pass) snap.init / snap.at_e.
-// raw extremes of the samples of one 16-sample group that lie inside the read (out of line: groups at a read's end;
-// everything by value -- a reference into the pass state would pin that state in scratch memory)
-struct RecExt {
-    sgk_s2 mn, mx;
-};
-__device__ __attribute__((noinline)) RecExt rec_ext_masked(Lead16<int16_t> g, int pos, int n, RecExt x) {
-    short tmp[16];
-    __builtin_memcpy(tmp, g.w, sizeof(tmp));
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if ((unsigned)(pos + k) < (unsigned)n) {
-            x.mn.x = tmp[k] < x.mn.x ? tmp[k] : x.mn.x;
-            x.mx.x = tmp[k] > x.mx.x ? tmp[k] : x.mx.x;
-        }
-    }
-    return x;
-}
-__device__ __forceinline__ RecExt rec_ext_all(const Lead16<int16_t> &g, RecExt x) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        sgk_s2 w;
-        __builtin_memcpy(&w, &g.w[k], 4);
-        x.mn = __builtin_elementwise_min(x.mn, w);
-        x.mx = __builtin_elementwise_max(x.mx, w);
-    }
-    return x;
-}
-__device__ __forceinline__ RecExt rec_ext_all(const Lead16<float> &, RecExt x) { return x; }
-__device__ __forceinline__ RecExt rec_ext_masked(Lead16<float>, int, int, RecExt x) { return x; }
-
-// REC: `ro` is the lane's record state (updated for the lanes the pass runs), evbase the read's first event slot,
-// prov_end the end of the lane's provisional slot range (slots relative to evbase)
-template <int W1, typename T, bool FLAGGED, bool REC = false, typename LT = LzLds>
+template <int W1, typename T, bool FLAGGED>
 __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int lead, int steps, bool active, int s,
-                                          int e, LT *L, const RepairCtx *rep, char *evbase = nullptr,
-                                          uint32_t prov = 0u, uint32_t prov_end = 0u, bool *rec_ovf = nullptr, uint32_t ev_cap = 0u) {
-    using LP = LazyPass<W1, T, FLAGGED, REC>;
+                                          int e, LzLds *L, const RepairCtx *rep) {
+    using LP = LazyPass<W1, T, FLAGGED>;
     constexpr int W2 = LP::W2, R = LP::R;
     if (!__any(active)) return;
     const int l = lane_id();
@@ -1109,36 +884,14 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
     f.base = rc.base;
     f.lo = (int)(rc.lo < -(1 << 30) ? -(1 << 30) : rc.lo);
     f.hi = (int)(rc.hi > 0x7fffffffLL ? 0x7fffffffLL : rc.hi);
-    f.runs = L->runs_of(l);
-    f.nrec_cap = LT::NREC;
+    f.ring = L->ring[l];
+    f.runs = L->runs[l];
     const int n = f.n;
     const int i_begin = s - lead;  // multiple of 16, never negative
     f.i_begin = i_begin;
-    RecExt xt;
-    xt.mn = sgk_s2{32767, 32767};
-    xt.mx = sgk_s2{-32768, -32768};
-    if constexpr (REC) {
-        f.rpq = lds_addr(&L->prev[l]);
-        f.rstag = lds_addr(&L->stag[l][0]);
-        f.rhead = 0;
-        if (active) {
-            // the extremes of the lane's earlier pass leave the staging area before the ring is used
-            __builtin_memcpy(&xt.mn, &L->res(l, 2), 4);
-            __builtin_memcpy(&xt.mx, &L->res(l, 3), 4);
-        }
-        f.pprev = lead;
-        f.cntS = 0;
-        f.provoff = prov * 16u;
-        f.capend = ev_cap * 16u;
-        f.evbase = evbase;
-        f.own = 0ull;
-        f.rovf = 0ull;
-    } else {
-        f.ring = L->ring[l];
 #pragma unroll
-        for (int k = 0; k < LZ_RING_WORDS; ++k) f.ring[k] = 0u;
-        if (active) f.ring[LZ_PRE] = 0xffffffffu;  // no inherited emission in this pass yet
-    }
+    for (int k = 0; k < LZ_RING_WORDS; ++k) f.ring[k] = 0u;
+    if (active) f.ring[LZ_PRE] = 0xffffffffu;  // no inherited emission in this pass yet
 #pragma unroll
     for (int k = 0; k < 4; ++k) { f.t1[k] = 0.0f; f.nk[k] = 0ull; f.hc[k] = 0ull; }
     {
@@ -1150,14 +903,6 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             p = p > f.hi - 1 ? f.hi - 1 : p;
             p = p < 0 ? 0 : p;  // lane 0: positions before the read (their window positions are marked below)
             w[k] = to_pa(f.base[p], f.sc);
-            if constexpr (REC) {
-                // (the read's first W2 samples reach lane 0 through this window only)
-                if (active && p < n) {
-                    const short rv = (short)f.base[p];
-                    xt.mn.x = rv < xt.mn.x ? rv : xt.mn.x;
-                    xt.mx.x = rv > xt.mx.x ? rv : xt.mx.x;
-                }
-            }
         }
 #pragma unroll
         for (int k = 0; k < LP::NP; ++k) { f.Ps[k] = 0.0; f.Pq[k] = 0.0; }
@@ -1172,9 +917,6 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
     }
     // leading samples of the first block: x[i_begin + W2 .. +16)
     f.load_lead(f.cur, i_begin + W2);
-    if constexpr (REC) {
-        if (active) xt = rec_ext_masked(f.cur, i_begin + W2, n, xt);
-    }
 
     // detector state
     f.sv = FLT_MAX;
@@ -1186,7 +928,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
     f.lm = LZ_NONE;
     f.r0 = 0;  // the (pseudo) reset a speculative pass starts from; index 0 for lane 0
     if (__any(given)) {
-        LzSnapState st = L->st0(l);
+        LzSnapState st = L->snap.st0[l];
         if (!given) { st.sp = -1; st.sv = FLT_MAX; st.lm = LZ_NONE; st.r0 = i_begin; st.bits = 0u; }  // fresh
         f.sv = st.sv;
         f.inpk = __ballot((st.bits & 1u) != 0u);
@@ -1198,28 +940,6 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
 #pragma unroll
         for (int k = 0; k <= LP::H1; ++k) f.hist[k] = __ballot((st.bits & 1u) && st.sp == i_begin - 1 - k);
         f.r0 = st.r0 - i_begin;
-        if constexpr (REC) {
-            // a lane that starts inside a peak did not see the peak's index: P there, in this lane's origin, is P at the
-            // lane's first index minus the samples in between (exact under the read-level guard, any order).  (Rare:
-            // re-runs only; a peak further back than 4096 samples sends the read to the exact fallback.)
-            const bool inh = given && (st.bits & 1u) != 0u;
-            if (__any(inh)) {
-                const int back = inh ? i_begin - st.sp : 0;
-                f.rovf |= __ballot(inh && back > 4096);
-                double ps = f.Ps[0], pq = f.Pq[0];
-                if (inh && back <= 4096) {
-                    for (int j = 1; j <= back; ++j) {
-                        const float x = to_pa(f.base[i_begin - j], f.sc);
-                        ps = ps - (double)x;
-                        pq = pq - (double)(x * x);
-                    }
-                    RecPQ c;
-                    c.P = ps;
-                    c.Q = pq;
-                    L->cur[l] = c;
-                }
-            }
-        }
     }
     f.nrec = 0;
     f.done = ~__ballot(active);
@@ -1260,11 +980,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
     int jb = 0;
     for (;;) {
         const int ib = i_begin + jb;
-        if constexpr (!REC) {
-            if ((jb & 255) == 0 && jb >= 512) {
-                lz_flush(f.ring, f.bm, i_begin, jb - 512, own_lo, own_hi);
-                f.flushed = jb - 256;
-            }
+        if ((jb & 255) == 0 && jb >= 512) {
+            lz_flush(f.ring, f.bm, i_begin, jb - 512, own_lo, own_hi);
+            f.flushed = jb - 256;
         }
         // blocks that touch the read's last W2 indices (the statistics are defined as 0 there) or its end take the
         // predicated forms of the steps; so does a block in which some lane holds a peak older than the bitmap ring
@@ -1273,24 +991,15 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         // (... or a peak in front of the lane's own range in the range's first block: it may be emitted there within
         // w/2 indices, as a "usual" peak whose bit the fast steps would put into the bitmap word; in later blocks it is
         // an "older peak", which the fast steps hand to the ring or, in front of the range, to LZ_PRE)
-        // (the record path has no bitmap words: a peak is a peak wherever it lies)
-        const bool old_peak = !REC && (f.sp < -(256 - 2 * R) || (f.sp + jb < own_lo && jb == own_lo));
+        const bool old_peak = f.sp < -(256 - 2 * R) || (f.sp + jb < own_lo && jb == own_lo);
         f.oldpeak = (__ballot(old_peak) & f.inpk & ~f.done) != 0ull;
         f.slow = f.oldpeak || (__ballot(lane_edge) & ~f.done) != 0ull;
         f.ib = ib;
         f.jb = jb;
-        if constexpr (REC) f.own = __ballot(active && jb >= own_lo);
         // issue the loads of the NEXT block's leading samples now; consumed one iteration later
         Lead16<T> nxt;
         f.load_lead(nxt, ib + R + W2);
         f.block(std::make_integer_sequence<int, R / 4>{});
-        if constexpr (REC) {
-            // exactness guard: extremes of the raw samples (a group that reaches behind the read: per sample)
-#ifndef SGK_X_NOEXT
-            if (__ballot(active && ib + 2 * R + W2 > n) == 0ull) xt = rec_ext_all(nxt, xt);
-            else if (active) xt = rec_ext_masked(nxt, ib + R + W2, n, xt);
-#endif
-        }
         f.cur = nxt;
         // rebase the block-relative positions
         f.sp -= R;
@@ -1301,8 +1010,8 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         {
             // state snapshots live in LDS (they are only needed after the pass)
             const int nb = i_begin + jb;  // first index of the next block
-            if (active && lead > 0 && jb == lead) L->init(l) = snapshot(nb);
-            if (active && nb == e) L->at_e(l) = snapshot(nb);
+            if (active && lead > 0 && jb == lead) L->snap.init[l] = snapshot(nb);
+            if (active && nb == e) L->snap.at_e[l] = snapshot(nb);
             // a lane stops at the end of its range; a peak still pending there is emitted by the lane behind
             // (lz_emit_slow), and dropped at the read's end as in the reference, whose loop ends at n-1
             const lmask_t reach = __ballot(nb >= e) & ~f.done;
@@ -1310,7 +1019,7 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             // recorded HERE: the lane may step on (other lanes of the wave have more to do, and in k_event_multi their
             // reads are longer) through whatever lies behind the read, and its run bookkeeping with it
             if ((reach & f.hot) != 0ull) {
-                if (lane_of(reach & f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, nb + max(f.r0, f.lm + W1 + 1), n, s, e, n, f.nrec_cap);
+                if (lane_of(reach & f.hot) && e == n) f.nrec = lz_record(f.runs, f.nrec, nb + max(f.r0, f.lm + W1 + 1), n, s, e, n);
             }
             f.done |= reach;
             // ... and it steps on without the exact redo of uncertified statistics: whatever it decides from here on
@@ -1320,32 +1029,6 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
             f.strong &= ~reach;
         }
         if (jb >= main_steps && f.done == ~0ull) break;
-    }
-    if constexpr (REC) {
-        // the records still staged (fewer than four per lane, after one more burst): 16-byte stores
-        f.rec_flush4();
-        if (active) {
-            // (a lane that ran over the end of its range has written into its neighbour's: the read is redone)
-            const lmask_t bad = __ballot(f.provoff + 16u * (uint32_t)f.cntS > prov_end * 16u);
-            f.rovf |= bad;
-            if (!lane_of(bad)) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int sl = 3 * ((f.rhead + k) & 7);
-                    if (k < f.cntS)
-                        *reinterpret_cast<uint4 *>(f.evbase + f.provoff + 16u * k) =
-                            make_uint4(0u, L->stag[l][sl], L->stag[l][sl + 1], L->stag[l][sl + 2]);
-                }
-            }
-            const int cnt = (int)((f.provoff - prov * 16u) >> 4) + f.cntS;
-            L->res(l, 0) = (uint32_t)cnt;
-            L->res(l, 1) = (uint32_t)(cnt > 0 ? i_begin + f.pprev : -1);
-            __builtin_memcpy(&L->res(l, 2), &xt.mn, 4);
-            __builtin_memcpy(&L->res(l, 3), &xt.mx, 4);
-            L->nrec[l] = f.nrec;
-        }
-        if (f.rovf != 0ull) *rec_ovf = true;
-        return;
     }
     // remaining ring words (the current bitmap word first)
     {
@@ -1359,11 +1042,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
 // Exact replay of the long detector (events.c:383-440, k = 1) over one hot run per lane: from the fresh state a
 // reset leaves, over the indices [i, b) of the run (inside a run masked_to does not change and every index is
 // processed).  Peaks are ORed into the read's bitmap if they lie in [bits_lo, bits_hi).
-// (record path: there is no bitmap; a peak the replay finds -- none on nanopore-like signals, where the short detector
-// dominates the long one -- sets *found and the read is redone by the exact fallback)
 template <int W1, typename T, bool FLAGGED>
 __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has, int i, int b, int bits_lo,
-                           int bits_hi, EvHeader *hdr, int *found = nullptr) {
+                           int bits_hi, EvHeader *hdr) {
     if (has && b > i) atomicAdd(&hdr->n_replay_idx, (unsigned long long)(b - i));
     constexpr int W2 = 2 * W1;
     constexpr float ph = DetParam<W1>::ph, thr2 = DetParam<W1>::thr2;
@@ -1394,10 +1075,7 @@ __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has,
                 }
                 if (lv - v2 > ph && lv > thr2) lvalid = true;
                 if (lvalid && (i - lp) > W2 / 2) {
-                    if (lp > 0 && lp < n && lp >= bits_lo && lp < bits_hi) {
-                        if (found) *found = 1;
-                        else atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
-                    }
+                    if (lp > 0 && lp < n && lp >= bits_lo && lp < bits_hi) atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
                     lp = -1;
                     lv = v2;
                     lvalid = false;
@@ -1409,17 +1087,17 @@ __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has,
 }
 // ... over the recorded hot runs of the wave's lanes.  bits_lo: first index of the span this wave owns (a run that
 // began in front of it leaves its peaks in front of the span to whoever replays the span's cross runs)
-template <int W1, typename T, bool FLAGGED, typename LT>
-__device__ void replay_long_runs(const ReadCtx<T> &rc, LT *L, const RepairCtx *rep, bool active, int bits_lo,
-                                 EvHeader *hdr, int *found = nullptr) {
+template <int W1, typename T, bool FLAGGED>
+__device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx *rep, bool active, int bits_lo,
+                                 EvHeader *hdr) {
     const int l = lane_id();
     const int nrec = active ? L->nrec[l] : 0;
-    for (int k = 0; k < LT::NREC; ++k) {
+    for (int k = 0; k < LZ_NREC; ++k) {
         const bool has = k < nrec;
         if (!__any(has)) break;
-        const int i = has ? L->runs_of(l)[k].a : 0;
-        const int b = has ? L->runs_of(l)[k].b : 0;
-        replay_run<W1, T, FLAGGED>(rc, rep, has, i, b, bits_lo, 0x7fffffff, hdr, found);
+        const int i = has ? L->runs[l][k].a : 0;
+        const int b = has ? L->runs[l][k].b : 0;
+        replay_run<W1, T, FLAGGED>(rc, rep, has, i, b, bits_lo, 0x7fffffff, hdr);
     }
 }
 
@@ -1436,16 +1114,10 @@ __device__ void replay_long_runs(const ReadCtx<T> &rc, LT *L, const RepairCtx *r
 //
 // MULTI (k_event_multi): the wave holds 64 / lanes reads, `lanes` consecutive lanes each (rc, b and the return code are
 // per lane; a = 0, mode 0, no seg): a short read on all 64 lanes spends more steps on warm-ups than on its samples.
-//
-// REC (the record path, see LzLdsRec): the lanes write event records to provisional ranges of the read's event slots
-// (evbase: the read's first slot, ev_cap: its slot count) instead of bits to the bitmap; `ro` receives what finish_rec
-// needs.  Additional return code 3: a lane's provisional range overflowed or the long detector's replay found a peak.
-template <int W1, typename T, bool FLAGGED, bool MULTI = false, bool REC = false, typename LT = LzLds>
-__device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, LT *L, const RepairCtx *rep,
+template <int W1, typename T, bool FLAGGED, bool MULTI = false>
+__device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, LzLds *L, const RepairCtx *rep,
                                            const int a, const int b, const int mode, const int lead_override,
-                                           SegState *seg, const int lanes = 64, RecGeom *geo = nullptr,
-                                           char *evbase = nullptr, uint32_t ev_cap = 0u) {
-    static_assert(!REC || !MULTI, "record path: one read per wave");
+                                           SegState *seg, const int lanes = 64) {
     const int n = (int)rc.n;
     if constexpr (!MULTI) {
         if (b <= a) return 0;
@@ -1500,44 +1172,28 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
     {
         LzSnapState z;
         z.sp = -1; z.sv = FLT_MAX; z.lm = LZ_NONE; z.r0 = 0; z.bits = 0u;
-        if (!(REC && mode == 2 && lane_id() == 0)) L->init(lane_id()) = z;  // (REC: the start state sits in init)
-        L->at_e(lane_id()) = z;
+        L->snap.init[lane_id()] = z;
+        L->snap.at_e[lane_id()] = z;
         L->nrec[lane_id()] = 0;
-        if constexpr (!REC) L->ring[lane_id()][LZ_PRE] = 0xffffffffu;
-    }
-    // REC: the lane's provisional range of the read's slots (RecGeom)
-    uint32_t prov = 0u, prov_end = 0u;
-    bool rec_ovf = false;
-    if constexpr (REC) {
-        geo->a = a;
-        geo->K = K;
-        geo->lead = mode == 1 ? 0 : lead;
-        geo->last = __popcll(__ballot(active)) - 1;
-        geo->a16 = (uint32_t)(reinterpret_cast<uintptr_t>(evbase) >> 4);
-        prov = geo->prov_of(c);
-        prov_end = c >= geo->last ? ev_cap : geo->prov_of(c + 1);
-        L->res(lane_id(), 0) = 0u;
-        L->res(lane_id(), 1) = 0xffffffffu;
-        L->res(lane_id(), 2) = 0x7fff7fffu;
-        L->res(lane_id(), 3) = 0x80008000u;
+        L->ring[lane_id()][LZ_PRE] = 0xffffffffu;
     }
     bool run = active;
     bool first = true;
     const int l = lane_id();
     for (int iter = 0; iter < 66; ++iter) {
-        pass_lazy<W1, T, FLAGGED, REC, LT>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : Kmax,
-                                           run, s, e, L, rep, evbase, prov, prov_end, &rec_ovf, ev_cap);
+        pass_lazy<W1, T, FLAGGED>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : Kmax, run, s, e,
+                                  L, rep);
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
-        const LzSnapState pe = L->at_e(c > 0 ? l - 1 : l);
-        const LzSnapState mine = L->init(l);
+        const LzSnapState pe = L->snap.at_e[c > 0 ? l - 1 : l];
+        const LzSnapState mine = L->snap.init[l];
         const bool bad = active && c > 0 && !lz_equal(pe, mine);
         const unsigned long long badmask = __ballot(bad);
         if (badmask == 0ull) break;
         __syncthreads();
         if (bad) {
-            L->init(l) = pe;
-            L->st0(l) = pe;
+            L->snap.init[l] = pe;
+            L->snap.st0[l] = pe;
         }
         run = bad;
         first = false;
@@ -1552,38 +1208,26 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         if (no_fast) rcode = 1;
         else if (over & grp) rcode = 2;
     } else {
-        if (__any(active && L->nrec[l] > LT::NREC)) return 2;
+        if (__any(active && L->nrec[l] > LZ_NREC)) return 2;
     }
     const bool mine_ok = active && rcode == 0;
-    if constexpr (REC) {
-        // (whole reads only: no neighbours, no inherited emissions to pass on)
-        if (rec_ovf) return 3;
-        const unsigned long long hotm = __ballot(mine_ok && L->nrec[l] > 0);
-        if (hotm != 0ull) {
-            if (l == 0) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
-            int found = 0;
-            replay_long_runs<W1, T, FLAGGED, LT>(rc, L, rep, mine_ok, a, hdr, &found);
-            if (__any(found != 0)) return 3;
-        }
-        return rcode;
-    } else {
     if (seg) {
         // what the neighbours need: the states at both ends, the runs that began in front of the span
         const int last = __popcll(__ballot(active)) - 1;
         if (l == 0) {
-            seg->init0 = L->init(0);
-            seg->end = L->at_e(last);
+            seg->init0 = L->snap.init[0];
+            seg->end = L->snap.at_e[last];
         }
         const int nrec = active ? L->nrec[l] : 0;
         int ncross = 0;
-        for (int k = 0; k < nrec; ++k) ncross += (L->runs_of(l)[k].a < a) ? 1 : 0;
+        for (int k = 0; k < nrec; ++k) ncross += (L->runs[l][k].a < a) ? 1 : 0;
         const int incl = wave_incl_scan_i(ncross);
         const int total = wave_last_i(incl);
         if (total > SEG_CROSS_MAX) rcode = 2;
         else {
             int at = incl - ncross;
             for (int k = 0; k < nrec; ++k) {
-                if (L->runs_of(l)[k].a < a) seg->cross[at++] = L->runs_of(l)[k];
+                if (L->runs[l][k].a < a) seg->cross[at++] = L->runs[l][k];
             }
         }
         if (l == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
@@ -1611,11 +1255,10 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
             atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
         }
 #ifndef SGK_EXP_NO_REPLAY
-        if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED, LT>(rc, L, rep, mine_ok, a, hdr);
+        if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, mine_ok, a, hdr);
 #endif
     }
     return rcode;
-    }  // !REC
 }
 // one wave, one read
 template <int W1, typename T, bool FLAGGED>
@@ -1737,6 +1380,8 @@ __device__ inline bool raw_extremes_to_pa(int rmin, int rmax, const Scale &sc, f
     const bool same_sign = (a > 0.0f && b > 0.0f) || (a < 0.0f && b < 0.0f);
     return same_sign && mn > 0.0f && mx < __builtin_inff();
 }
+
+typedef short sgk_s2 __attribute__((ext_vector_type(2)));
 
 // One lane's walk over its 32 samples of a tile: lane-relative double prefix sums, one record per boundary bit.
 // FULL: every sample of the tile is inside the read (no per-sample validity select).
@@ -1964,197 +1609,6 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     if (!flagged && __any(overflow) && l == 0) atomicAdd(&a.hdr->n_overflow, 1u);
 }
 
-// ---------------------------------------------------------------- record path: records -> events (round 4)
-// create_event (events.c:457-473) from the two float sums a record holds
-__device__ __forceinline__ void store_event_rec(uint4 *ev, uint32_t k, uint32_t ps, uint32_t len_u, float dsum, float dsq) {
-    const float len = (float)len_u;
-    const float r1 = sgk_refined_rcp(len);
-    const float m = sgk_div_with_rcp(dsum, len, r1);
-    const float var = sgk_div_with_rcp(dsq, len, r1) - m * m;
-    const float sd = sqrtf(fmaxf(var, 0.0f));
-    uint4 e;
-    e.x = ps;
-    e.y = len_u;
-    e.z = __float_as_uint(m);
-    e.w = __float_as_uint(sd);
-    ev[k] = e;
-}
-// Events summed from the samples: lane l builds the event [start, end) into slot `slot` (has: the lane has one).
-// Short ones lane by lane, long ones (a flat stretch) by the whole wave, one after the other.  Exact in any order
-// under the read-level guard.
-template <typename T>
-__device__ void rec_sum_events(const ReadCtx<T> &rc, const EvOut &eo, bool has, uint32_t slot, int start, int end) {
-    const int l = lane_id();
-    const int len = has ? end - start : 0;
-    const bool shortv = has && len <= 192;
-    int maxlen = shortv ? len : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(maxlen, d, 64);
-        maxlen = o > maxlen ? o : maxlen;
-    }
-    double S = 0.0, Q = 0.0;
-    for (int i = 0; i < maxlen; ++i) {
-        if (shortv && i < len) {
-            const float x = to_pa(rc.base[start + i], rc.sc);
-            S = S + (double)x;
-            Q = Q + (double)(x * x);
-        }
-    }
-    unsigned long long lm = __ballot(has && !shortv);
-    while (lm != 0ull) {
-        const int c = __ffsll((long long)lm) - 1;
-        lm &= lm - 1ull;
-        const int st = __builtin_amdgcn_readlane(start, c), en = __builtin_amdgcn_readlane(end, c);
-        double s1 = 0.0, q1 = 0.0;
-        for (int i = st + l; i < en; i += 64) {
-            const float x = to_pa(rc.base[i], rc.sc);
-            s1 = s1 + (double)x;
-            q1 = q1 + (double)(x * x);
-        }
-        const double ts = wave_last_d(wave_incl_scan_d(s1)), tq = wave_last_d(wave_incl_scan_d(q1));
-        if (l == c) { S = ts; Q = tq; }
-    }
-    bool overflow = false;
-    if (has) store_event_fast(eo, slot, (uint32_t)start, (uint32_t)end, S, Q, overflow);
-}
-
-// After the passes of detect_span<REC> have converged: the verdict on the read (exactness guard from the extremes the
-// lanes saw), the lanes' records turned into events and moved to their final slots, the events that straddle a chunk
-// seam and the read's last event.  Lane c's records sit at slots [prov, prov + cnt) of the read; its first record is a
-// placeholder for the event that ends at its first boundary (it began in an earlier lane's chunk) and carries that
-// boundary's position; record k >= 1 is the event between its boundaries k - 1 and k.  Final slot of its record k:
-// (records of the lanes in front) + k, never behind the provisional one -- the sweep goes lane by lane, 64 records at a
-// time, loads before stores, and only ever moves records towards the read's first slot.
-template <typename T>
-__device__ void finish_rec(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, const LzLdsRec *L, const RecGeom &geo,
-                           int rcode) {
-    const int l = lane_id();
-    const bool lane_act = l <= geo.last;
-    sgk_s2 lmn, lmx;
-    __builtin_memcpy(&lmn, &L->res(l, 2), 4);
-    __builtin_memcpy(&lmx, &L->res(l, 3), 4);
-    const int lcnt = (int)L->res(l, 0), lplast = (int)L->res(l, 1);
-    const uint32_t lprov = geo.prov_of(l);
-    const int ls = geo.start_of(l);
-    const int64_t n = rc.n;
-    const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
-    uint4 *ev = reinterpret_cast<uint4 *>(a.events + slot0);
-    EvOut eo;
-    eo.ev = ev;
-    eo.cap = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
-    // exactness guard (see the file header)
-    int rmn = lmn.x < lmn.y ? lmn.x : lmn.y, rmx = lmx.x > lmx.y ? lmx.x : lmx.y;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o1 = __shfl_xor(rmn, d, 64), o2 = __shfl_xor(rmx, d, 64);
-        rmn = o1 < rmn ? o1 : rmn;
-        rmx = o2 > rmx ? o2 : rmx;
-    }
-    float mn, mx;
-    const bool known = raw_extremes_to_pa(rmn, rmx, rc.sc, mn, mx);
-    const bool flagged = rcode != 0 || !known || !guard_ok(mn, mx, n);
-    if (flagged) {
-        if (l == 0) {
-            a.flags[r] = 1;
-            a.flag_list[atomicAdd(&a.hdr->n_flagged, 1u)] = r;
-        }
-        return;
-    }
-    const int m = lane_act ? lcnt : 0;
-    const int incl = wave_incl_scan_i(m);
-    const int base = incl - m;
-    const int total = wave_last_i(incl);
-    // the boundary in front of each lane's first one: the last boundary of the lanes before it
-    int mxp = m > 0 ? lplast : -1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(mxp, d, 64);
-        if (l >= d) mxp = o > mxp ? o : mxp;
-    }
-    int prevb = __shfl_up(mxp, 1, 64);
-    if (l == 0 || prevb < 0) prevb = 0;
-    const int lastb = __builtin_amdgcn_readlane(mxp, 63) < 0 ? 0 : __builtin_amdgcn_readlane(mxp, 63);
-    // each lane's first boundary, from its placeholder record (before the sweep may overwrite it)
-    int pfirst = 0;
-    if (m > 0) pfirst = ls + (int)ev[lprov].y;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-#ifdef SGK_X_NOSWEEP
-    return;
-#endif
-    // The sweep: tiles of 64 records (lane c's records k0 .. k0 + 63, k0 = 1, 65, ...) in lane order, SWEEP_D tiles in
-    // flight -- a record was written up to a read's time ago and comes from HBM, one dependent load per tile made the
-    // sweep cost a third of the pass.  A tile that is loaded early is not harmed by the stores of the tiles in front of
-    // it: final slots never lie behind provisional ones, and provisional slots grow with the tile order.
-    constexpr int SWEEP_D = 8;
-    int tc = -1, tk0 = 0, tmc = 0;
-    auto advance = [&]() -> bool {
-        if (tc >= 0 && tk0 + 64 < tmc) {
-            tk0 += 64;
-            return true;
-        }
-        for (++tc; tc < 64; ++tc) {
-            tmc = __builtin_amdgcn_readlane(m, tc);
-            if (tmc > 1) {
-                tk0 = 1;
-                return true;
-            }
-        }
-        tc = 64;
-        return false;
-    };
-    uint4 rec[SWEEP_D];
-    int dc[SWEEP_D], dk[SWEEP_D], dm[SWEEP_D];
-    bool dv[SWEEP_D];
-    auto fetch = [&](int d) {
-        dv[d] = advance();
-        dc[d] = tc;
-        dk[d] = tk0;
-        dm[d] = tmc;
-        // (an unconditional load: a load under a lane condition, merged with a default, is waited for where it is issued;
-        // lanes behind the run's end load its last record, a tile behind the last one the read's first slot)
-        const int kk = dv[d] ? (tk0 + l < tmc ? tk0 + l : tmc - 1) : 0;
-        rec[d] = ev[(dv[d] ? geo.prov_of(tc) : 0u) + (uint32_t)kk];
-    };
-#pragma unroll
-    for (int d = 0; d < SWEEP_D; ++d) fetch(d);
-    int cur_c = -1, run_start = 0;
-    bool more = true;
-    while (more) {
-#pragma unroll
-        for (int d = 0; d < SWEEP_D; ++d) {
-            if (!dv[d]) {
-                more = false;
-                break;
-            }
-            const int c = dc[d];
-            if (c != cur_c) {
-                cur_c = c;
-                run_start = __builtin_amdgcn_readlane(pfirst, c);
-            }
-            const int bc = __builtin_amdgcn_readlane(base, c);
-            const int k = dk[d] + l;
-            const int len = k < dm[d] ? (int)rec[d].y : 0;
-            const int inc = wave_incl_scan_i(len);
-            if (k < dm[d]) store_event_rec(ev, (uint32_t)(bc + k), (uint32_t)(run_start + inc - len), rec[d].y,
-                                           __uint_as_float(rec[d].z), __uint_as_float(rec[d].w));
-            run_start += wave_last_i(inc);
-            fetch(d);
-        }
-    }
-    // the events that straddle a chunk seam, then the read's last one
-#ifndef SGK_X_NOSUMEV
-    rec_sum_events<T>(rc, eo, m > 0, (uint32_t)base, prevb, pfirst);
-    rec_sum_events<T>(rc, eo, l == 0, (uint32_t)total, lastb, (int)n);
-#endif
-    if (l == 0) {
-        a.flags[r] = 0;
-        a.n_events[r] = (uint32_t)total + 1u;
-        atomicAdd(&a.hdr->n_events_total, (unsigned long long)total + 1ull);
-    }
-}
-
 // fallback builder: event sums are differences of the sequential prefix arrays, as in the reference
 template <typename T>
 __device__ void build_read_prefix(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r) {
@@ -2290,53 +1744,50 @@ __device__ void seq_prefix(const ReadCtx<T> &rc, double *P, double *P2, PrefixLd
 // ---------------------------------------------------------------- kernels
 
 // DNA preset: 168 VGPRs -> 3 waves per SIMD; RNA preset (deeper rings): 242 VGPRs -> 2
-template <int W1, typename T>
 #ifndef SGK_DET_WAVES_DNA
 #define SGK_DET_WAVES_DNA 3
 #endif
 #ifndef SGK_DET_WAVES_RNA
 #define SGK_DET_WAVES_RNA 2
 #endif
-__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_detect(EvArgs a) {
-    __shared__ LzLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    const int rcode = detect_read_lazy<W1, T, false>(rc, a.hdr, &L, nullptr);
-    if (lane_id() == 0) a.flags[r] = rcode ? 2 : 0;  // 2: declined by the fast pass -> exact fallback
-}
 
-template <typename T>
-__global__ __launch_bounds__(64, 3) void k_event_build(EvArgs a) {
-    __shared__ BuildLds L;
-    const uint32_t r = blockIdx.x;
-    const ReadCtx<T> rc = make_ctx<T>(a, r);
-    build_read<T>(a, rc, r, &L, a.flags[r] == 2);
-}
-
-// Detector and builder of one read in one wave, back to back (SGK_EVENT_FUSED, the default): the builder's phases
+// Detector and builder of one read in one wave, back to back: the builder's phases
 // that wait on memory (sample tiles, event stores) run under other waves' detector arithmetic instead of in a
 // kernel of their own.  The bitmap goes through memory (L2) between the two phases of the same wave.
 union EventLds {
     LzLds lz;
     BuildLds b;
 };
-#ifndef SGK_REC_MIN
-#define SGK_REC_MIN 8192   // shorter reads: a lane's chunk has too few slots for aligned bursts
-#endif
 // span of segment g of a read of n samples
-__device__ __forceinline__ void seg_span(const EvArgs &a, uint32_t g, int64_t n, int &sa, int &sb) {
-    const int64_t lo = (int64_t)g * a.seg_len, hi = lo + a.seg_len;
+__device__ __forceinline__ void seg_span(uint32_t seg_len, uint32_t g, int64_t n, int &sa, int &sb) {
+    const int64_t lo = (int64_t)g * seg_len, hi = lo + seg_len;
     sa = (int)lo;
     sb = (int)(hi < n ? hi : n);
 }
 
-// Long reads: the list of their segments (one thread per read; the order of the list does not matter).
+// Which reads several wavefronts share, and in segments of which length (0: the read has a wavefront of its own).
+//  * long reads (>= long_min samples): a wave per read cannot end before its longest read has;
+//  * the TAIL SPLIT (round 4): the reads at dispatch positions >= split_from.  n_reads equal waves over the GPU's
+//    resident wave slots run in rounds; the last, partial round costs nearly a whole one (10 000 reads over 3 072 slots:
+//    3.26 rounds of work took the time of 3.75).  The reads of that round are cut into split_seg-sample segments -- as
+//    many units as fill a round, each a fraction of a read long -- and run FIRST; every other read keeps the fused
+//    detector + builder of its own wave (cutting every read costs more than the balance returns: the builder of a
+//    cut read is a kernel of its own, profiles/r04_event_experiments.md).
+__device__ __forceinline__ uint32_t seg_len_of(const EvArgs &a, uint32_t pos, uint32_t n) {
+    if (a.max_segs == 0) return 0u;
+    if (n >= a.long_min) return a.seg_len;
+    if (pos >= a.split_from && n > a.split_seg) return a.split_seg;
+    return 0u;
+}
+// The list of their segments (one thread per dispatch position; the order of the list does not matter).
 __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= a.n_reads) return;
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= a.n_reads) return;
+    const uint32_t r = a.order ? a.order[pos] : pos;
     const uint32_t n = a.lengths[r];
-    if (n < a.long_min) return;
-    const uint32_t G = (uint32_t)(((uint64_t)n + a.seg_len - 1) / a.seg_len);
+    const uint32_t seg = seg_len_of(a, pos, n);
+    if (seg == 0u) return;
+    const uint32_t G = (uint32_t)(((uint64_t)n + seg - 1) / seg);
     const uint32_t s0 = atomicAdd(&a.hdr->n_segs, G), li = atomicAdd(&a.hdr->n_long, 1u);
     // The capacities cover every batch of non-overlapping reads with these totals (event_seg_capacity).  A read that
     // does not fit all the same (overlapping reads) is left to the exact fallback; what it took of the lists is marked
@@ -2345,7 +1796,7 @@ __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
         for (uint64_t k = s0; k < (uint64_t)s0 + G && k < a.max_segs; ++k) a.segs[k].read = SEG_NONE;
         if (li < a.max_long) {
             LongRead none;
-            none.read = r; none.seg0 = 0; none.nseg = 0; none.pad = 0;
+            none.read = r; none.seg0 = 0; none.nseg = 0; none.seg_len = seg;
             a.longs[li] = none;
         }
         a.flags[r] = 1;
@@ -2353,51 +1804,12 @@ __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
         return;
     }
     LongRead lr;
-    lr.read = r; lr.seg0 = s0; lr.nseg = G; lr.pad = 0;
+    lr.read = r; lr.seg0 = s0; lr.nseg = G; lr.seg_len = seg;
     a.longs[li] = lr;
     for (uint32_t g = 0; g < G; ++g) {
         SegDesc d;
         d.read = r; d.g = g; d.lread = li; d.pad = 0;
         a.segs[s0 + g] = d;
-    }
-}
-
-#ifndef SGK_REC_WAVES
-#define SGK_REC_WAVES 3
-#endif
-// The record path (round 4) takes whole reads of the DNA preset, raw input, that have their full slot range.
-template <int W1, typename T>
-__device__ __forceinline__ bool rec_takes(const EvArgs &a, uint32_t r, int64_t n) {
-    if constexpr (W1 == 3 && std::is_same<T, int16_t>::value) {
-        if (!a.rec_on || n < SGK_REC_MIN || n >= (1ll << 30)) return false;
-        if (a.max_segs && n >= (int64_t)a.long_min) return false;      // taken by its segments
-        if (a.multi_lanes && n < (int64_t)a.multi_max) return false;    // taken by k_event_multi
-        return a.ev_slots[r + 1] - a.ev_slots[r] >= (uint64_t)n / 3u + 2u;
-    } else {
-        return false;
-    }
-}
-template <int W1, typename T>
-__global__ __launch_bounds__(64, SGK_REC_WAVES) void k_event_rec(EvArgs a) {
-    __shared__ LzLdsRec L;
-    if constexpr (W1 == 3 && std::is_same<T, int16_t>::value) {
-        const uint32_t r = a.order ? a.order[blockIdx.x] : blockIdx.x;
-        const ReadCtx<T> rc = make_ctx<T>(a, r);
-        if (!rec_takes<W1, T>(a, r, rc.n)) return;
-        const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
-        if (lane_id() == 0) L.runs_base = a.rec_runs + (size_t)blockIdx.x * 64u * REC_NREC;
-        __syncthreads();
-        RecGeom geo;
-        geo.a = 0; geo.K = 16; geo.lead = 0; geo.last = -1; geo.a16 = 0u;
-        const int rcode = detect_span<W1, T, false, false, true, LzLdsRec>(
-            rc, a.hdr, &L, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr, 64, &geo,
-            reinterpret_cast<char *>(a.events + slot0), (uint32_t)cap);
-        // the lanes' records are in memory before other lanes of this wave read them back (workgroup scope: the wave's
-        // own CU)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        finish_rec<T>(a, rc, r, &L, geo, rcode);
     }
 }
 
@@ -2408,29 +1820,32 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     // k_event_build_seg builds; the segment list is usually much shorter than its capacity), the others one read each,
     // longest first (launch_order): a kernel cannot end before its longest read has, so that one should start first,
     // not wherever it sits in the batch.
-    const bool is_seg = blockIdx.x < a.max_segs;
-    uint32_t r, g = 0;
+    // (seg_last: the segments are the tail split's and take the LAST workgroups -- small units into the slots the last
+    // whole reads leave empty; long reads' segments take the first: a kernel cannot end before its longest read has)
+    const uint32_t bx = a.seg_last ? (blockIdx.x >= a.n_reads ? blockIdx.x - a.n_reads : blockIdx.x + a.seg_blocks) : blockIdx.x;
+    const bool is_seg = bx < a.seg_blocks;
+    uint32_t r, g = 0, seg_len = 0;
     if (is_seg) {
-        if (blockIdx.x >= a.hdr->n_segs) return;
-        const SegDesc d = a.segs[blockIdx.x];
+        if (bx >= a.hdr->n_segs) return;
+        const SegDesc d = a.segs[bx];
         if (d.read == SEG_NONE) return;
         r = d.read;
         g = d.g;
+        seg_len = a.longs[d.lread].seg_len;
     } else {
-        const uint32_t bi = blockIdx.x - a.max_segs;
+        const uint32_t bi = bx - a.seg_blocks;
         r = a.order ? a.order[bi] : bi;
     }
     const ReadCtx<T> rc = make_ctx<T>(a, r);
     int sa = 0, sb = (int)rc.n;
     SegState *st = nullptr;
     if (is_seg) {
-        seg_span(a, g, rc.n, sa, sb);
-        st = a.seg_state + blockIdx.x;
+        seg_span(seg_len, g, rc.n, sa, sb);
+        st = a.seg_state + bx;
     } else {
-        if (a.max_segs && rc.n >= (int64_t)a.long_min) return;  // taken by its segments
+        if (seg_len_of(a, bx - a.seg_blocks, (uint32_t)rc.n) != 0u) return;  // taken by its segments
         if (a.multi_lanes && rc.n < (int64_t)a.multi_max) return;  // taken by k_event_multi
     }
-    if (!is_seg && rec_takes<W1, T>(a, r, rc.n)) return;  // taken by k_event_rec
     const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, sa, sb, g == 0 ? 0 : 1, a.lead_override, st);
     if (is_seg) {
         if (lane_id() == 0) st->status = rcode;
@@ -2467,7 +1882,7 @@ __global__ __launch_bounds__(64) void k_event_seam(EvArgs a) {
         const LzSnapState pe = st[g - 1].end, mine = st[g].init0;
         if (lz_equal(pe, mine)) continue;
         int sa, sb;
-        seg_span(a, g, rc.n, sa, sb);
+        seg_span(lr.seg_len, g, rc.n, sa, sb);
         __syncthreads();
         if (l == 0) {
             L.snap.st0[0] = pe;
@@ -2493,7 +1908,7 @@ __global__ __launch_bounds__(64) void k_event_seam(EvArgs a) {
         const int nc = (int)st[g].n_cross;
         if (nc == 0) continue;
         int sa, sb;
-        seg_span(a, g, rc.n, sa, sb);
+        seg_span(lr.seg_len, g, rc.n, sa, sb);
         const bool has = l < nc;
         const LzRun run = has ? st[g].cross[l] : LzRun{0, 0};
         replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr);
@@ -2517,7 +1932,7 @@ __global__ __launch_bounds__(64) void k_event_seg_count(EvArgs a) {
     if (d.read == SEG_NONE) return;
     const ReadCtx<T> rc = make_ctx<T>(a, d.read);
     int sa, sb;
-    seg_span(a, d.g, rc.n, sa, sb);
+    seg_span(a.longs[d.lread].seg_len, d.g, rc.n, sa, sb);
     const int l = lane_id();
     const int w0 = sa >> 6, w1 = (sb + 63) >> 6;
     int cnt = 0, last = -1;
@@ -2562,7 +1977,7 @@ __global__ __launch_bounds__(64, 3) void k_event_build_seg(EvArgs a) {
     if (st0[0].status != 0) return;  // declined: the fallback builds the read
     const ReadCtx<T> rc = make_ctx<T>(a, d.read);
     int sa, sb;
-    seg_span(a, d.g, rc.n, sa, sb);
+    seg_span(lr.seg_len, d.g, rc.n, sa, sb);
     // boundary bits in front of the segment: their number is the rank of the segment's first event, the last of them
     // is where that event starts
     uint32_t before = 0;
@@ -2653,7 +2068,7 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     const uint32_t r = a.order ? a.order[idx] : idx;
     ReadCtx<T> rc = make_ctx<T>(a, r);
     // (with segments shorter than multi_max -- tests -- a read can be short and long at once: the segments have it)
-    const bool mine = has && !(a.max_segs && rc.n >= (int64_t)a.long_min);
+    const bool mine = has && !(a.max_segs && rc.n >= (int64_t)a.long_min);  // (no tail split in a batch with packed reads)
     if (!mine) rc.n = 0;
     const int rcode = detect_span<W1, T, false, true>(rc, a.hdr, &L.lz, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr,
                                                       lanes);
@@ -2697,11 +2112,7 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
         rep.ev = events.ev;
         rep.nev = events.count < REP_MAX_EVENTS ? events.count : REP_MAX_EVENTS;
         rep.all_dirty = events.count > REP_MAX_EVENTS;
-#ifdef SGK_EXP_FB_GENERIC
-        const int rcode = 1;
-#else
         const int rcode = detect_read_lazy<W1, T, true>(rc, a.hdr, &Lz, &rep);
-#endif
         if (rcode) detect_read<W1, T>(rc, a.hdr);
         __threadfence();
         __syncthreads();
@@ -2712,39 +2123,88 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 
 // ---------------------------------------------------------------- launcher
 
-#ifndef SGK_EVENT_FUSED
-#define SGK_EVENT_FUSED 1
-#endif
-// A batch with short AND longer reads runs two detector kernels: k_event (a wavefront per read, and the segments of the
-// long reads) and k_event_multi (several short reads per wavefront).  In one stream the second would wait for the last
-// wave of the first -- two tails instead of one, which costs what the packing gains (50 000 RNA-like reads, log-normal
-// around 20 000 samples: 6.36 ms against 6.29 ms with a wavefront per read).  k_event_multi therefore goes to a side
-// stream of the library's own (one per device), forked off the caller's stream behind the dispatch order and joined
-// in front of the fallback kernel; the long reads' seam / builder kernels overlap with it as well.
+// Side streams.  A batch with short AND longer reads runs two detector kernels: k_event (a wavefront per read, and the
+// segments of the long reads) and k_event_multi (several short reads per wavefront).  In one stream the second would
+// wait for the last wave of the first -- two tails instead of one, which costs what the packing gains (50 000 RNA-like
+// reads, log-normal around 20 000 samples: 6.36 ms against 6.29 ms with a wavefront per read).  k_event_multi therefore
+// goes to a side stream of the library's own, forked off the caller's stream behind the dispatch order and joined in
+// front of the fallback kernel; the long reads' seam / builder kernels overlap with it as well.
+// The TAIL SPLIT (seg_len_of) uses a second kind: a stream of the LOWEST priority.  The segment kernels of the split
+// reads queue there and are dispatched when k_event on the caller's stream has no workgroup left to start -- i.e. into
+// the slots its last waves leave empty while they finish, which is what the split is for (in the caller's stream, in
+// front of k_event, they only moved the partial round from the end to the start: 3.92 vs 3.84 ms on config 2).
+// A small pool per device and kind, handed out round-robin; a stream's mutex is held while one launch enqueues its
+// fork .. join on it (the events are the stream's), never across launches of other streams or devices.
 struct SideStream {
+    std::mutex mu;
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
 };
-static std::mutex g_side_mu;      // held from the fork to the join of one launch: the events are shared
-static SideStream g_side[64];
-static SideStream *side_stream_locked() {
+constexpr int SIDE_POOL = 4;
+static SideStream g_side[64][2][SIDE_POOL];
+static std::atomic<unsigned> g_side_next[64][2];
+// returns a locked side stream (unlock with x->mu.unlock()), or null
+static SideStream *side_acquire(bool low_priority) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SideStream &x = g_side[dev];
-    if (!x.s) {
+    const int kind = low_priority ? 1 : 0;
+    SideStream &x = g_side[dev][kind][g_side_next[dev][kind].fetch_add(1u) % SIDE_POOL];
+    x.mu.lock();
+    if (!x.s && !x.tried) {
+        x.tried = true;
         hipStream_t s = nullptr;
         hipEvent_t f = nullptr, j = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
-            if (f) (void)hipEventDestroy(f);
-            (void)hipStreamDestroy(s);
-            return nullptr;
+        int lo = 0, hi = 0;
+        hipError_t e;
+        if (low_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo);   // (lo: the numerically greatest = lowest)
+        else
+            e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            if (hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess) {
+                x.s = s; x.fork = f; x.join = j;
+            } else {
+                if (f) (void)hipEventDestroy(f);
+                (void)hipStreamDestroy(s);
+            }
         }
-        x.s = s; x.fork = f; x.join = j;
+    }
+    if (!x.s) {
+        x.mu.unlock();
+        return nullptr;
     }
     return &x;
 }
+// One fork .. join on a side stream: joins on every exit path (an error return in between must not leave the caller's
+// stream unordered behind work that still writes the workspace).
+struct SideFork {
+    SideStream *x = nullptr;
+    hipStream_t main = nullptr;
+    bool open(bool low_priority, hipStream_t st) {
+        // (a stream that is being captured into a graph keeps everything in itself: the library's events and streams are
+        // not part of the caller's capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+        x = side_acquire(low_priority);
+        if (!x) return false;
+        main = st;
+        if (hipEventRecord(x->fork, st) == hipSuccess && hipStreamWaitEvent(x->s, x->fork, 0) == hipSuccess) return true;
+        x->mu.unlock();
+        x = nullptr;
+        return false;
+    }
+    hipStream_t stream() const { return x ? x->s : main; }
+    void join() {
+        if (!x) return;
+        const bool ok = hipEventRecord(x->join, x->s) == hipSuccess && hipStreamWaitEvent(main, x->join, 0) == hipSuccess;
+        if (!ok) (void)hipStreamSynchronize(x->s);
+        x->mu.unlock();
+        x = nullptr;
+    }
+    ~SideFork() { join(); }
+};
 
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
@@ -2754,7 +2214,6 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     // >= 3072 reads in flight to fill its 12 waves/CU, so the overlapped step was 8.8 ms against 7.8 ms.)
     ProfScope whole("path:event", st);
     SGK_HIP_TRY(hipMemsetAsync(a.hdr, 0, sizeof(EvHeader), st));
-#if SGK_EVENT_FUSED
     EvArgs ao = a;
     if (a.n_reads >= ORDER_MIN_READS && a.order) {
         const int rc = launch_order(a.lengths, a.n_reads, a.order, a.order + a.n_reads, st);
@@ -2764,19 +2223,12 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     // (no dispatch order and packing on: every read is under multi_max.  k_event would have nothing to do -- unless
     // the segments are test-sized and some of those reads are long: their segments are k_event's)
     const bool all_short = ao.multi_lanes && !ao.order && !ao.max_segs;
-    std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
-    SideStream *side = nullptr;
-    hipStream_t st_multi = st;
-    if (ao.multi_lanes && !all_short) {
-        side_lock.lock();
-        side = side_stream_locked();
-        if (side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess)
-            st_multi = side->s;
-        else {
-            side = nullptr;   // (no side stream: one stream does, slower)
-            side_lock.unlock();
-        }
-    }
+    // the segments of a batch whose only segments are the tail split's go to the low-priority stream
+    const bool tail_only = ao.max_segs && ao.split_seg && !ao.has_long;
+    SideFork multi_side, tail_side;
+    hipStream_t st_multi = st, st_seg = st;
+    if (ao.multi_lanes && !all_short && multi_side.open(false, st)) st_multi = multi_side.stream();
+    (void)tail_side;   // (the low-priority stream: measured, 5.1 vs 3.8 ms -- its kernels start late and slowly)
     if (ao.multi_lanes) {
         ProfScope ps("k_event_multi", st_multi);
         const uint32_t per_wave = 64u / ao.multi_lanes;
@@ -2785,49 +2237,42 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         else hipLaunchKernelGGL((k_event_multi<3, T>), dim3(grid), dim3(64), 0, st_multi, ao);
         SGK_HIP_TRY(hipGetLastError());
     }
-    if (!all_short && !rna && ao.rec_on && std::is_same<T, int16_t>::value) {
-        ProfScope ps("k_event_rec", st);
-        hipLaunchKernelGGL((k_event_rec<3, T>), dim3(a.n_reads), dim3(64), 0, st, ao);
-    }
+    // k_event: the first seg_blocks workgroups take segments, the others one read each.  With the segments on a stream
+    // of their own it is two launches: the reads on the caller's stream, the segments on the other.
+    const bool seg_apart = st_seg != st;
     if (!all_short) {
         ProfScope ps("k_event", st);
-        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
-        else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs + a.n_reads), dim3(64), 0, st, ao);
+        EvArgs ar = ao;
+        ar.seg_blocks = seg_apart ? 0u : ao.max_segs;
+        ar.seg_last = tail_only ? 1u : 0u;
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ar.seg_blocks + a.n_reads), dim3(64), 0, st, ar);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(ar.seg_blocks + a.n_reads), dim3(64), 0, st, ar);
     }
     SGK_HIP_TRY(hipGetLastError());
     if (ao.max_segs) {
-        {
-            ProfScope ps("k_event_seam", st);
-            if (rna) hipLaunchKernelGGL((k_event_seam<7, T>), dim3(ao.max_long), dim3(64), 0, st, ao);
-            else hipLaunchKernelGGL((k_event_seam<3, T>), dim3(ao.max_long), dim3(64), 0, st, ao);
-            hipLaunchKernelGGL((k_event_seg_count<T>), dim3(ao.max_segs), dim3(64), 0, st, ao);
+        EvArgs as = ao;
+        as.seg_blocks = ao.max_segs;
+        if (seg_apart) {
+            ProfScope ps("k_event_segs", st_seg);
+            if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
+            else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
         }
         {
-            ProfScope ps("k_event_build_seg", st);
-            hipLaunchKernelGGL((k_event_build_seg<T>), dim3(ao.max_segs), dim3(64), 0, st, ao);
-            hipLaunchKernelGGL((k_event_long_finish<T>), dim3((ao.max_long + 63) / 64), dim3(64), 0, st, ao);
+            ProfScope ps("k_event_seam", st_seg);
+            if (rna) hipLaunchKernelGGL((k_event_seam<7, T>), dim3(ao.max_long), dim3(64), 0, st_seg, as);
+            else hipLaunchKernelGGL((k_event_seam<3, T>), dim3(ao.max_long), dim3(64), 0, st_seg, as);
+            hipLaunchKernelGGL((k_event_seg_count<T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
+        }
+        {
+            ProfScope ps("k_event_build_seg", st_seg);
+            hipLaunchKernelGGL((k_event_build_seg<T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
+            hipLaunchKernelGGL((k_event_long_finish<T>), dim3((ao.max_long + 63) / 64), dim3(64), 0, st_seg, as);
         }
         SGK_HIP_TRY(hipGetLastError());
     }
-    if (side) {
-        // join: the fallback kernel (and whatever the caller enqueues next) waits for the packed reads as well
-        const bool ok = hipEventRecord(side->join, side->s) == hipSuccess && hipStreamWaitEvent(st, side->join, 0) == hipSuccess;
-        side_lock.unlock();
-        if (!ok) SGK_HIP_TRY(hipStreamSynchronize(side->s));
-    }
-#else
-    {
-        ProfScope ps("k_event_detect", st);
-        if (rna) hipLaunchKernelGGL((k_event_detect<7, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_event_detect<3, T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
-    {
-        ProfScope ps("k_event_build", st);
-        hipLaunchKernelGGL((k_event_build<T>), dim3(a.n_reads), dim3(64), 0, st, a);
-    }
-    SGK_HIP_TRY(hipGetLastError());
-#endif
+    // join: the fallback kernel (and whatever the caller enqueues next) waits for the side streams as well
+    tail_side.join();
+    multi_side.join();
     {
         ProfScope ps("k_event_fallback", st);
         if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);
@@ -2835,16 +2280,6 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
-}
-
-unsigned long long debug_exact_redo_count(bool reset) {
-    unsigned long long v = 0;
-    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_exact_redo_count), sizeof v);
-    if (reset) {
-        const unsigned long long z = 0;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exact_redo_count), &z, sizeof z);
-    }
-    return v;
 }
 
 int launch_event(const EvArgs &a, int rna, bool float_input, uint32_t n_fb_blocks, hipStream_t st) {

@@ -91,6 +91,8 @@ struct sgk_job {
     int tool = -1, flags = 0;
     bool begun = false, submitted = false, ent_over = false;
     sgk_event_status_t ev_status;
+    sgk_event_options_t ev_opt;   // sgk_job_set_options (all zero: the defaults)
+    sgk_stat_options_t st_opt;
 };
 
 extern "C" {
@@ -106,6 +108,8 @@ int sgk_job_create(int device, sgk_job_t **out) {
     if (!j) return SGK_ERR_NOMEM;
     j->device = device;
     memset(&j->ev_status, 0, sizeof j->ev_status);
+    memset(&j->ev_opt, 0, sizeof j->ev_opt);
+    memset(&j->st_opt, 0, sizeof j->st_opt);
     const hipError_t e = hipStreamCreateWithFlags(&j->st, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_hip_error(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
@@ -113,6 +117,15 @@ int sgk_job_create(int device, sgk_job_t **out) {
         return SGK_ERR_HIP;
     }
     *out = j;
+    return SGK_OK;
+}
+
+int sgk_job_set_options(sgk_job_t *j, const sgk_event_options_t *event_opt, const sgk_stat_options_t *stat_opt) {
+    if (!j) return SGK_ERR_ARG;
+    if (event_opt) j->ev_opt = *event_opt;
+    else memset(&j->ev_opt, 0, sizeof j->ev_opt);
+    if (stat_opt) j->st_opt = *stat_opt;
+    else memset(&j->st_opt, 0, sizeof j->st_opt);
     return SGK_OK;
 }
 
@@ -352,15 +365,15 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
                     if ((rc = j->d_out[k].ensure(s * 4)) != SGK_OK) return rc;
             }
             if ((rc = j->d_cnt.ensure(nr * 4)) != SGK_OK) return rc;
-            j->ws_bytes = ev ? sgk_event_workspace_bytes(j->n_reads, j->n_samples, j->max_len)
+            j->ws_bytes = ev ? sgk_event_workspace_bytes_opt(j->n_reads, j->n_samples, j->max_len, &j->ev_opt)
                              : sgk_jnn_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
             if (ev)
-                rc = sgk_event(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<sgk_event_rec_t>(),
-                               j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
+                rc = sgk_event_opt(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<sgk_event_rec_t>(),
+                                   j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st, &j->ev_opt);
             else
-                rc = sgk_jnn(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<int32_t>(),
-                             j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st);
+                rc = sgk_jnn_opt(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<int32_t>(),
+                                 j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
             if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
             // the arena is capacity-sized (sgk_event_slots_for(n) slots per read): gather what was produced into dense ranges on the
@@ -396,7 +409,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
             j->ws_bytes = sgk_stat_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
-            rc = sgk_stat(&view, j->d_out[0].as<sgk_stat_rec_t>(), j->d_ws.p, j->d_ws.cap, st);
+            rc = sgk_stat_opt(&view, j->d_out[0].as<sgk_stat_rec_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
             if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_stat_rec_t), st)) != SGK_OK) return rc;
             break;
@@ -415,7 +428,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = j->d_out[0].ensure(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
             j->ws_bytes = sgk_prefix_workspace_bytes(j->n_reads, j->n_samples, j->max_len);
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
-            rc = sgk_prefix(&view, rna, pore, j->d_out[0].as<sgk_prefix_rec_t>(), j->d_ws.p, j->d_ws.cap, st);
+            rc = sgk_prefix_opt(&view, rna, pore, j->d_out[0].as<sgk_prefix_rec_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
             if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_prefix_rec_t), st)) != SGK_OK) return rc;
             break;

@@ -17,6 +17,7 @@ struct StatArgs {
     float *pa_out;               // stat+pa fused: pA of every sample, written by the median pass (or null)
     const uint32_t *order;       // wave-per-read kernels: wave i takes read order[i] (longest reads first), or null
     uint32_t jnn_redo;           // k_jnn: 1 = only the reads k_jnn_wave gave up on (n_segs[r] == JNN_REDO_MARK)
+    int kernels;                 // sgk_stat_options_t::kernels: 0 chosen per batch, 1 read per lane, 2 read per wavefront
 };
 constexpr uint32_t JNN_REDO_MARK = 0xffffffffu;
 

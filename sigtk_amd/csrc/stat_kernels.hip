@@ -1961,17 +1961,17 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- launchers
-// SGK_LANE_PER_READ=1 selects the lane-per-read kernels of round 1 (kept as an independent second implementation:
-// tests compare the two; tools/bench_subtools.py times both)
-// SGK_LANE_PER_READ=0 forces the wave-per-read kernels.  By default a batch takes them unless it is a LARGE batch of
-// SHORT reads of SIMILAR length (>= 65 536 reads of at most 16 384 samples, the longest at most 1.5 x the mean): there the
-// lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and no per-read costs
-// (native heads, binade crossings, chunk start-up), and are up to 4 x faster (400 000 x 5 000 samples: jnn 3.6 ms
-// against 14.5 ms); everywhere else -- ragged, small or long-read batches -- the wave kernels win by 1.5 - 40 x.
-static bool lane_per_read(const sgk_batch_t &b) {
-    const char *e = getenv("SGK_LANE_PER_READ");
-    if (e && e[0] == '1') return true;
-    if (e && e[0] == '0') return false;
+// Two implementations (sgk_stat_options_t::kernels): the lane-per-read kernels of round 1 (1; kept as an independent
+// second implementation: tests compare the two, tools/bench_subtools.py times both) and the wave-per-read kernels (2).
+// By default (0) a batch takes the wave kernels unless it is a LARGE batch of SHORT reads of SIMILAR length (>= 65 536
+// reads of at most 16 384 samples, the longest at most 1.5 x the mean): there the lane-per-read kernels have 64 reads per
+// wavefront, nothing to gain from intra-read parallelism and no per-read costs (native heads, binade crossings, chunk
+// start-up), and are up to 4 x faster (400 000 x 5 000 samples: jnn 3.6 ms against 14.5 ms); everywhere else -- ragged,
+// small or long-read batches -- the wave kernels win by 1.5 - 40 x.
+static bool lane_per_read(const StatArgs &a) {
+    if (a.kernels == 1) return true;
+    if (a.kernels == 2) return false;
+    const sgk_batch_t &b = a.b;
     return b.n_reads >= 65536u && b.max_read_len <= 16384u && (uint64_t)b.max_read_len * b.n_reads <= b.n_samples + b.n_samples / 2;
 }
 
@@ -1984,7 +1984,7 @@ static bool lane_per_read(const sgk_batch_t &b) {
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read(a.b)) {
+    if (lane_per_read(a)) {
         SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
         SGK_HIP_TRY(hipGetLastError());
         if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
@@ -2005,7 +2005,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
-    if (lane_per_read(a.b) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
         SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
         SGK_HIP_TRY(hipGetLastError());
@@ -2020,7 +2020,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
 int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read(a.b)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
@@ -2043,7 +2043,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    const bool lanes = lane_per_read(a.b);
+    const bool lanes = lane_per_read(a);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
     SGK_HIP_TRY(hipGetLastError());

@@ -109,7 +109,9 @@ class EventArena:
         self.events = torch.empty((max(self.n_slots, 1), 4), dtype=torch.int32, device=dev)
         assert self.events.data_ptr() % 16 == 0
         self.n_events = torch.zeros(max(b.n_reads, 1), dtype=torch.int32, device=dev)
-        self.ws_bytes = int(L.sgk_event_workspace_bytes(b.n_reads, b.n_samples, b.max_read_len))
+        # (sized for the options of the call that follows: api.EVENT_OPTIONS as they are now)
+        self.opt = api.EventOptions.from_buffer_copy(bytes(api.EVENT_OPTIONS))
+        self.ws_bytes = int(L.sgk_event_workspace_bytes_opt(b.n_reads, b.n_samples, b.max_read_len, C.byref(self.opt)))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         assert self.ws.data_ptr() % 64 == 0
 
@@ -150,8 +152,8 @@ def event(b: DeviceReads, arena: EventArena, rna: int) -> None:
     """Enqueue one pass of the event path over the batch on the current stream (async)."""
     L = api.load_library()
     view = b.view()
-    api.check(L.sgk_event(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.events), _ptr(arena.n_events),
-                          _ptr(arena.ws), arena.ws_bytes, _stream_ptr()), "sgk_event")
+    api.check(L.sgk_event_opt(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.events), _ptr(arena.n_events),
+                              _ptr(arena.ws), arena.ws_bytes, _stream_ptr(), C.byref(arena.opt)), "sgk_event_opt")
 
 
 # ---------------------------------------------------------------------- stat / jnn / prefix / pa (device API)
@@ -173,7 +175,8 @@ def stat(b: DeviceReads) -> torch.Tensor:
     out = torch.zeros(max(b.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
     view = b.view()
     ws = _workspace(b, "sgk_stat_workspace_bytes")
-    api.check(L.sgk_stat(C.byref(view), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_stat")
+    api.check(L.sgk_stat_opt(C.byref(view), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr(), C.byref(api.STAT_OPTIONS)),
+              "sgk_stat_opt")
     return out
 
 
@@ -186,7 +189,8 @@ def stat_pa(b: DeviceReads, pa_out: Optional[torch.Tensor] = None):
         pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=b.samples.device)
     view = b.view()
     ws = _workspace(b, "sgk_stat_workspace_bytes")
-    api.check(L.sgk_stat_pa(C.byref(view), _ptr(out), _ptr(pa_out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_stat_pa")
+    api.check(L.sgk_stat_pa_opt(C.byref(view), _ptr(out), _ptr(pa_out), _ptr(ws), ws.numel(), _stream_ptr(),
+                                C.byref(api.STAT_OPTIONS)), "sgk_stat_pa_opt")
     return out, pa_out
 
 
@@ -195,7 +199,8 @@ def prefix(b: DeviceReads, rna: int, pore: int) -> torch.Tensor:
     out = torch.zeros(max(b.n_reads, 1) * api.PREFIX_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
     view = b.view()
     ws = _workspace(b, "sgk_prefix_workspace_bytes")
-    api.check(L.sgk_prefix(C.byref(view), int(rna), int(pore), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "sgk_prefix")
+    api.check(L.sgk_prefix_opt(C.byref(view), int(rna), int(pore), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr(),
+                               C.byref(api.STAT_OPTIONS)), "sgk_prefix_opt")
     return out
 
 
@@ -216,8 +221,9 @@ class SegArena:
 def jnn(b: DeviceReads, arena: SegArena, rna: int) -> None:
     L = api.load_library()
     view = b.view()
-    api.check(L.sgk_jnn(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.x), _ptr(arena.y),
-                        _ptr(arena.n_segs), _ptr(arena.ws), arena.ws.numel(), _stream_ptr()), "sgk_jnn")
+    api.check(L.sgk_jnn_opt(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.x), _ptr(arena.y),
+                            _ptr(arena.n_segs), _ptr(arena.ws), arena.ws.numel(), _stream_ptr(), C.byref(api.STAT_OPTIONS)),
+              "sgk_jnn_opt")
 
 
 def pa(b: DeviceReads, out: torch.Tensor) -> None:

@@ -24,7 +24,7 @@ def main():
                     "after a GPU fault the last line names the batch")
     ap.add_argument("--segments", type=float, default=0.5,
                     help="share of the batches whose event pass runs with short segments (reads shared by several "
-                         "wavefronts: sgk_event_configure) and, for a third of those, a warm-up short enough for "
+                         "wavefronts: the segment options) and, for a third of those, a warm-up short enough for "
                          "speculation to fail at seams")
     a = ap.parse_args()
     import torch
@@ -91,13 +91,15 @@ def main():
             with open(a.trace, "a") as tf:
                 tf.write(tag + " lens " + ",".join(str(x) for x in lens[:64]) + "\n")
         job.stage(sig, dig, off, rng, counts)
-        L.sgk_event_configure(*cfg)
-        L.sgk_event_configure_short(lanes_cfg)
+        api.event_configure(*cfg)
+        api.event_configure_short(lanes_cfg)
+        job.set_options()
         job.launch(api.TOOL_EVENT, rna=rna)
         res = job.wait()
         t_event = time.time() - t_batch
-        L.sgk_event_configure(0, 0, 0)
-        L.sgk_event_configure_short(0)
+        api.event_configure(0, 0, 0)
+        api.event_configure_short(0)
+        job.set_options()
         stats["split_reads"] += int(res["status"].n_split_reads)
         stats["segments"] += int(res["status"].n_segments)
         stats["seam_reruns"] += int(res["status"].n_seam_reruns)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the two implementations of stat / jnn / prefix at batch scale: the wave-per-read
 kernels (default; seqsum.h chains, chunked automata, longest-first dispatch) against the lane-per-read kernels of round 1
-(SGK_LANE_PER_READ=1) through the job API, on batches of 1 000 - 6 000 reads with log-normal lengths and the hostile
+(sgk_stat_options_t::kernels = 1) through the job API, on batches of 1 000 - 6 000 reads with log-normal lengths and the hostile
 scalings of tests/soak_parity.py.  Every record must be identical bit for bit.
     python tests/soak_wave_vs_lane.py [--minutes 5] [--seed 1]"""
 import argparse
@@ -58,8 +58,7 @@ def main():
         tag = "batch %d (seed %d kind %d rna %d pore %d, %d reads)" % (stats["batches"], seed, kind, rna, pore, nr)
         out = {}
         for mode in ("wave", "lane"):
-            if mode == "lane": os.environ["SGK_LANE_PER_READ"] = "1"
-            else: os.environ.pop("SGK_LANE_PER_READ", None)
+            api.stat_configure(1 if mode == "lane" else 2)
             job = api.Job(0)
             job.stage(reads, dig, off, rng, None)
             job.launch(api.TOOL_STAT); st = job.wait()["stat"].copy()
@@ -67,7 +66,7 @@ def main():
             job.launch(api.TOOL_PREFIX, rna=rna, pore=pore); pf = job.wait()["prefix"].copy()
             out[mode] = (st, sg, pf)
             job.close()
-        os.environ.pop("SGK_LANE_PER_READ", None)
+        api.stat_configure(0)
         w, l = out["wave"], out["lane"]
         for r in range(nr):
             if w[0][r].tobytes() != l[0][r].tobytes():

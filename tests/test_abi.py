@@ -30,9 +30,26 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = api.load_library()
-    assert lib.sgk_version().decode() == "0.1.0"
+    assert lib.sgk_version().decode() == "0.2.0"   # per-call options; the bindings refuse an older library
     assert lib.sgk_strerror(0).decode() == "ok"
     assert "GPU" in lib.sgk_strerror(-3).decode()
+
+
+def test_library_is_reentrant_by_construction():
+    """no getenv and no mutable process-wide configuration in libsigtk_gpu.so (VERDICT r03 task 7): options travel with
+    every call (sgk_event_options_t, sgk_stat_options_t)"""
+    csrc = os.path.join(ROOT, "sigtk_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        src = re.sub(r"//.*", "", src)
+        assert "getenv" not in src, f
+    lib = api.load_library()
+    assert not hasattr(lib, "sgk_event_configure") and not hasattr(lib, "sgk_event_configure_short")
+    # two option sets give two plans from the same library at the same time
+    a, b = api.EventOptions(), api.EventOptions()
+    a.segment_len, a.long_min = 4096, 10000
+    pa_, pb_ = api.event_plan(10, 10 * 300000, 300000, 0, a), api.event_plan(10, 10 * 300000, 300000, 0, b)
+    assert (pa_.segment_len, pb_.segment_len) == (4096, 131072)
 
 
 def test_no_cpu_fallback_without_gpu():

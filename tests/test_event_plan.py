@@ -9,43 +9,48 @@ import pytest
 @pytest.fixture(scope="module")
 def lib():
     from sigtk_amd import api
-    L = C.CDLL(api.LIB_PATH)
-    L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(api.EventPlan)]
-    L.sgk_event_configure.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
-    L.sgk_event_configure_short.argtypes = [C.c_int]
-    L.sgk_event_workspace_bytes.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32]
-    L.sgk_event_workspace_bytes.restype = C.c_size_t
-    yield L
-    L.sgk_event_configure(0, 0, 0)
-    L.sgk_event_configure_short(0)
+    return api.load_library()
 
 
-def plan(L, lens, rna=0):
+def opts(**kw):
+    from sigtk_amd import api
+    o = api.EventOptions()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def plan(L, lens, rna=0, opt=None):
     from sigtk_amd import api
     lens = np.asarray(lens, dtype=np.int64)
     n_samples = int(((lens + 7) // 8 * 8).sum())   # reads laid out on 8-sample boundaries
     p = api.EventPlan()
-    assert L.sgk_event_plan(len(lens), n_samples, int(lens.max()), rna, C.byref(p)) == 0
+    assert L.sgk_event_plan(len(lens), n_samples, int(lens.max()), rna, C.byref(opt if opt is not None else opts()),
+                            C.byref(p)) == 0
     return p, n_samples
 
 
 def test_defaults_and_no_long_reads(lib):
-    lib.sgk_event_configure(0, 0, 0)
-    p, _ = plan(lib, [100000] * 10000)
+    p, _ = plan(lib, [100000] * 12288, opt=opts(tail_split=-1))
     assert (p.segment_len, p.long_min) == (131072, 262144)
     assert p.max_segments == 0 and p.max_long_reads == 0          # nothing reaches long_min: no lists, no extra kernels
+    assert p.tail_segment_len == 0 and p.tail_split_from == 12288
     assert p.lanes_per_short_read == 0 and p.short_max == 16384   # 100 000-sample reads keep their wavefront
     assert plan(lib, [100000] * 10000, rna=1)[0].short_max == 65536
+    # a null options pointer is the defaults
+    from sigtk_amd import api
+    q = api.EventPlan()
+    assert lib.sgk_event_plan(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0 and q.segment_len == 131072
 
 
 def test_segment_capacities_cover_any_batch_with_these_totals(lib):
     rs = np.random.RandomState(1)
     for seg, lmin in ((0, 0), (1024, 1025), (4096, 10000), (131072, 131073)):
-        lib.sgk_event_configure(seg, lmin, 0)
+        o = opts(segment_len=seg, long_min=lmin, tail_split=-1)
         for _ in range(200):
             n = int(rs.randint(1, 60))
             lens = np.exp(rs.uniform(np.log(1), np.log(3e6), size=n)).astype(np.int64)
-            p, n_samples = plan(lib, lens)
+            p, n_samples = plan(lib, lens, opt=o)
             long_reads = lens[lens >= p.long_min]
             segs = int(sum(-(-int(x) // p.segment_len) for x in long_reads))
             if long_reads.size:
@@ -54,7 +59,6 @@ def test_segment_capacities_cover_any_batch_with_these_totals(lib):
             else:
                 assert p.max_segments == 0
             assert p.long_min > p.segment_len and p.segment_len % 1024 == 0
-    lib.sgk_event_configure(0, 0, 0)
     # the workspace grows with the lists, and only then
     a = lib.sgk_event_workspace_bytes(100, 100 * 100000, 100000)
     b = lib.sgk_event_workspace_bytes(100, 100 * 100000, 3000000)
@@ -62,8 +66,6 @@ def test_segment_capacities_cover_any_batch_with_these_totals(lib):
 
 
 def test_lanes_for_short_reads(lib):
-    lib.sgk_event_configure(0, 0, 0)
-    lib.sgk_event_configure_short(0)
     # 200 000 x 5 000: chunks of >= 8 warm-ups (32 samples with DNA parameters, 128 with RNA parameters)
     assert plan(lib, [5000] * 200000, rna=0)[0].lanes_per_short_read == 16
     assert plan(lib, [5000] * 200000, rna=1)[0].lanes_per_short_read == 4
@@ -80,8 +82,30 @@ def test_lanes_for_short_reads(lib):
     # ... a ragged batch without one (< 1024 reads) is not
     assert plan(lib, [4000] * 500 + [50000], rna=0)[0].lanes_per_short_read == 0
     # forced / off
-    lib.sgk_event_configure_short(8)
-    assert plan(lib, [5000] * 100, rna=0)[0].lanes_per_short_read == 8
-    lib.sgk_event_configure_short(-1)
-    assert plan(lib, [5000] * 200000, rna=0)[0].lanes_per_short_read == 0
-    lib.sgk_event_configure_short(0)
+    assert plan(lib, [5000] * 100, rna=0, opt=opts(lanes_per_short_read=8))[0].lanes_per_short_read == 8
+    assert plan(lib, [5000] * 200000, rna=0, opt=opts(lanes_per_short_read=-1))[0].lanes_per_short_read == 0
+
+
+def test_tail_split(lib):
+    """a batch of fewer than 8 rounds of wavefronts (256 CUs x 4 SIMDs x 3 waves with the DNA preset, x 2 with RNA
+    parameters; without a GPU the plan assumes 256 CUs) whose last round is partial: its reads are cut into segments"""
+    p, _ = plan(lib, [100000] * 10000)                  # 10 000 = 3 x 3072 + 784: the last 784 reads, 4 segments each
+    assert (p.tail_split_from, p.tail_segment_len) == (9216, 25600)
+    assert p.max_segments >= 784 * 4 and p.max_long_reads >= 784
+    p, _ = plan(lib, [100000] * 1000)                   # a third of a round: 3 segments each fill it
+    assert p.tail_split_from == 0 and p.tail_segment_len == 33792
+    p, _ = plan(lib, [100000] * 160)                    # a CLI-sized batch: at most 8 segments per read
+    assert p.tail_split_from == 0 and p.tail_segment_len == 16384 + 1024 * 0 or p.tail_segment_len >= 12288
+    assert plan(lib, [100000] * 12288)[0].tail_segment_len == 0             # whole rounds
+    assert plan(lib, [100000] * 12000)[0].tail_segment_len == 0             # the last round is nearly full
+    assert plan(lib, [100000] * 30000)[0].tail_segment_len == 0             # >= 8 rounds: the tail does not matter
+    assert plan(lib, [100000] * 10000, rna=1)[0].tail_segment_len == 0      # 2 048 slots: 4.88 rounds, nearly full
+    assert plan(lib, [100000] * 9000, rna=1)[0].tail_segment_len > 0
+    assert plan(lib, [20000] * 10000)[0].tail_segment_len == 0              # short reads: not worth two kernels more
+    assert plan(lib, [100000] * 10000, opt=opts(tail_split=-1))[0].tail_segment_len == 0
+    # the workspace has room for the lists
+    from sigtk_amd import api
+    lib.sgk_event_workspace_bytes_opt.restype = C.c_size_t
+    a = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts(tail_split=-1)))
+    b = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts()))
+    assert b >= a + 784 * 4 * 320

@@ -2,7 +2,7 @@
 
 Reads shorter than 16 384 samples (65 536 with RNA parameters) in a large batch get `lanes` lanes each instead of a
 wavefront of their own
-(sgk_event_configure_short forces the number here; by default it is chosen per batch and small batches keep 64).
+(the lanes_per_short_read option forces the number here; by default it is chosen per batch and small batches keep 64).
 """
 import numpy as np
 import pytest
@@ -17,14 +17,12 @@ SHORT = [0, 1, 2, 5, 11, 12, 13, 14, 27, 28, 29, 63, 64, 65, 127, 128, 129, 199,
 
 @pytest.fixture()
 def lanes_cfg(gpu):
-    L = gpu.load_library()
-
     def f(lanes, lead=0):
-        assert L.sgk_event_configure_short(lanes) == 0
-        assert L.sgk_event_configure(0, 0, lead) == 0
+        gpu.event_configure_short(lanes)
+        gpu.event_configure(0, 0, lead)
     yield f
-    L.sgk_event_configure_short(0)
-    L.sgk_event_configure(0, 0, 0)
+    gpu.event_configure_short(0)
+    gpu.event_configure(0, 0, 0)
 
 
 @pytest.mark.parametrize("rna", [0, 1])
@@ -122,7 +120,7 @@ def test_a_read_that_is_short_and_long_belongs_to_its_segments(gpu, oracle, lane
     reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=3 + rna, kind=rna)
     for lanes in (4, 16):
         lanes_cfg(lanes)
-        assert L.sgk_event_configure(1024, 1025, 0) == 0
+        gpu.event_configure(1024, 1025, 0)
         for _ in range(3):
             got, st = gpu.event(reads, dig, off, rng, rna)
             _check_events(oracle, reads, dig, off, rng, rna, got)

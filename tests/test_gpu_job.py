@@ -147,3 +147,44 @@ def test_many_tiny_reads_and_one_huge_read(gpu, oracle):
     e = oracle.prefix(big[0], dig[0], off[0], rng[0], 1, 0)
     assert (int(p["adapt_x"]), int(p["adapt_y"]), int(p["polya_x"]), int(p["polya_y"])) == (e.adapt_x, e.adapt_y, e.polya_x, e.polya_y)
     job.close()
+
+
+def test_two_threads_with_different_geometries_on_one_device(gpu, oracle):
+    """VERDICT r03 task 7: the library keeps no process-wide configuration.  Two threads drive jobs on the same device at
+    the same time, one with 1024-sample segments and a 16-sample warm-up (hundreds of seams, speculation failing at
+    every few of them) and packed short reads, the other with the defaults; both get the oracle's events, and each
+    job's status shows ITS geometry."""
+    import threading
+    lens = [40000, 5000, 3000, 70000, 12000, 900, 20000, 0, 1500]
+    reads, dig, off, rng = _batch(gpu, lens, 91, 0)
+    exp = [oracle.event_raw(r, dig[i], off[i], rng[i], 0) if r.size else None for i, r in enumerate(reads)]
+    small = gpu.EventOptions()
+    small.segment_len, small.long_min, small.warmup, small.lanes_per_short_read = 1024, 1025, 16, 4
+    default = gpu.EventOptions()
+    default.tail_split = -1
+    errors, seen = [], {}
+
+    def worker(name, opt):
+        try:
+            job = gpu.Job(0)
+            job.set_options(opt)
+            for _ in range(6):
+                job.submit(gpu.TOOL_EVENT, reads, dig, off, rng, rna=0)
+                res = job.wait()
+                for i, e in enumerate(exp):
+                    if e is None:
+                        assert res["events"][i].start.size == 0
+                    else:
+                        _same_events(res["events"][i], e, "%s read %d" % (name, i))
+                seen[name] = int(res["status"].n_split_reads)
+            job.close()
+        except Exception as ex:   # noqa: BLE001 -- reported below, in the main thread
+            errors.append("%s: %r" % (name, ex))
+
+    ts = [threading.Thread(target=worker, args=("small", small)), threading.Thread(target=worker, args=("default", default))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert seen["small"] == sum(1 for n in lens if n >= 1025) and seen["default"] == 0

@@ -181,14 +181,14 @@ def _adversarial_reads(gpu, seed):
 
 
 def test_stat_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
-    """the wave-per-read kernels (default) and the lane-per-read kernels of round 1 (SGK_LANE_PER_READ=1) are two
+    """the wave-per-read kernels (default) and the lane-per-read kernels of round 1 (sgk_stat_options_t::kernels = 1) are two
     independent implementations of the same sequential float sums: identical records, and identical to the oracle"""
     reads, dig, off, rng = _adversarial_reads(gpu, 17)
-    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    gpu.stat_configure(2)
     wave = gpu.stat(reads, dig, off, rng)
-    monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+    gpu.stat_configure(1)
     lane = gpu.stat(reads, dig, off, rng)
-    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    gpu.stat_configure(0)
     for r in range(len(reads)):
         assert wave[r].tobytes() == lane[r].tobytes(), "read %d (n=%d): wave %r lane %r" % (r, reads[r].size, wave[r], lane[r])
     idx = [i for i in range(len(reads)) if reads[i].size > 0]
@@ -200,11 +200,11 @@ def test_prefix_wave_matches_lane_per_read(gpu, monkeypatch):
     lens = [100, 2000, 2001, 2500, 20000, 50000, 100000, 100000, 100000, 100000, 30000, 70000]
     reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=23, kind=1)
     for pore in (0, 2):
-        monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        gpu.stat_configure(2)
         wave = gpu.prefix(reads, dig, off, rng, 1, pore)
-        monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+        gpu.stat_configure(1)
         lane = gpu.prefix(reads, dig, off, rng, 1, pore)
-        monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        gpu.stat_configure(0)
         for r in range(len(reads)):
             assert wave[r].tobytes() == lane[r].tobytes(), "read %d: wave %r lane %r" % (r, wave[r], lane[r])
 
@@ -229,11 +229,11 @@ def test_jnn_wave_matches_lane_per_read_and_oracle(gpu, oracle, monkeypatch):
         nz = rs.normal(520, 40, size=100000); nz[::7] += 400                      # every 7th sample an outlier
         reads[24] = np.clip(np.rint(nz), 0, 4000).astype(np.int16)
         for rna in (0, 1):
-            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+            gpu.stat_configure(2)
             wave = gpu.jnn(reads, dig, off, rng, rna)
-            monkeypatch.setenv("SGK_LANE_PER_READ", "1")
+            gpu.stat_configure(1)
             lane = gpu.jnn(reads, dig, off, rng, rna)
-            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+            gpu.stat_configure(0)
             for r in range(len(reads)):
                 np.testing.assert_array_equal(wave[r][0], lane[r][0], err_msg="kind %d rna %d read %d (n=%d) x" % (kind, rna, r, reads[r].size))
                 np.testing.assert_array_equal(wave[r][1], lane[r][1], err_msg="kind %d rna %d read %d (n=%d) y" % (kind, rna, r, reads[r].size))
@@ -251,10 +251,7 @@ def test_wave_kernels_longest_first_dispatch(gpu, oracle, monkeypatch):
     reads, dig, off, rng = gpu.synth_reads_host(nr, lens, seed=77, kind=1)
     out = {}
     for mode in ("wave", "lane"):
-        if mode == "lane":
-            monkeypatch.setenv("SGK_LANE_PER_READ", "1")
-        else:
-            monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+        gpu.stat_configure(1 if mode == "lane" else 2)
         job = gpu.Job(0)
         job.stage(reads, dig, off, rng, None)
         job.launch(gpu.TOOL_STAT); st = job.wait()["stat"]
@@ -270,7 +267,7 @@ def test_wave_kernels_longest_first_dispatch(gpu, oracle, monkeypatch):
                 assert g.start.size == e.start.size and np.array_equal(g.start.astype(np.uint64), e.start.astype(np.uint64)), "event read %d" % i
                 assert np.array_equal(g.mean.view(np.uint32), e.mean.view(np.uint32)), "event means read %d" % i
         job.close()
-    monkeypatch.delenv("SGK_LANE_PER_READ", raising=False)
+    gpu.stat_configure(0)
     for r in range(nr):
         assert out["wave"][0][r].tobytes() == out["lane"][0][r].tobytes(), "stat read %d" % r
         np.testing.assert_array_equal(out["wave"][1][r][0], out["lane"][1][r][0], err_msg="jnn x read %d" % r)

@@ -35,7 +35,7 @@ def main():
     rna = int(z["rna"]) if a.rna < 0 else a.rna
     sel = [int(x) for x in a.only.split(",")] if a.only else list(range(len(reads)))
     reads = [reads[i] for i in sel]; dig = dig[sel]; off = off[sel]; rng = rng[sel]
-    L.sgk_event_configure(a.seg, a.lmin, a.lead)
+    api.event_configure(a.seg, a.lmin, a.lead)
     L.sgk_profile_enable(1)
     for rep in range(a.reps):
         L.sgk_profile_reset()
