@@ -116,6 +116,7 @@ void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples
     if (mean < 32768 || n_reads >= 8ull * slots) return;
     const uint32_t rem = n_reads % slots;
     if (rem == 0 || rem > slots - slots / 8) return;
+    // (the number of segments per read hardly matters: 2 .. 16 per read, one or two rounds of them: 3.77 - 3.89 ms)
     uint32_t G = (slots - slots / 16 + rem - 1) / rem;   // units of the split reads ~ one round
     if (G < 2) G = 2;
     if (G > 8) G = 8;

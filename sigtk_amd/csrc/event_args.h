@@ -48,24 +48,32 @@ struct SegDesc {
 };
 struct SegState {           // 320 bytes per segment
     LzSnapState init0;      // state the speculative first lane reached at the segment's first index (g > 0)
-    LzSnapState end;        // state at the segment's end
+    LzSnapState end;        // state at the segment's end (final once `stage` is set)
     int status;             // detect_span's return code (non-zero: the read goes to the exact fallback)
-    uint32_t n_cross;       // hot long-detector runs that begin in front of the segment: replayed by k_event_seam
+    uint32_t n_cross;       // hot long-detector runs that begin in front of the segment
     LzRun cross[SEG_CROSS_MAX];
     uint32_t n_pre;         // peaks in front of the segment that were pending at its first index and emitted inside it
-    int pre[SEG_PRE_MAX];   // (their positions): k_event_seam sets the bits once the seam is verified
-    // k_event_seg_count: the segment's boundary bits
-    uint32_t cnt;           // how many
-    int last;               // the last one (-1: none)
+    int pre[SEG_PRE_MAX];   // (their positions): boundaries this segment owns although they lie in front of it
+    // the chain (round 4, chain_segment): what the segment behind needs, published with agent-scope atomic stores, `stage`
+    // last.  The wave of segment g + 1 polls `stage`, compares `end` with its own init0, and takes its event rank and
+    // the boundary its first event starts at from here -- every dependency points at a LOWER workgroup index.
+    uint32_t stage;         // 0: not yet, 1: the fields below and `end` are final
+    uint32_t cum_cnt;       // boundaries owned by the segments up to and including this one
+    int last_pos;           // the last of them (-1: none so far)
+    uint32_t cflags;        // 1: this or an earlier segment declined the read (it goes to the exact fallback)
     // builder outputs
     uint32_t ext_lo, ext_hi;  // extremes of the samples walked: raw int16 (as int) or float bit patterns
     uint32_t bflags;          // 1: a tile with more boundaries than the builder records, 2: event slots overflowed
     uint32_t pad;
 };
-static_assert(sizeof(SegState) == 320, "SegState layout");
+static_assert(sizeof(SegState) == 328, "SegState layout");
 struct LongRead {
     uint32_t read, seg0, nseg;
     uint32_t seg_len;   // long reads: EvArgs::seg_len; reads of the tail split: EvArgs::split_seg
+    // accumulated by the segments' waves (device-scope atomics); the wave that finishes last gives the verdict
+    uint32_t ext_lo, ext_hi;  // extremes over all segments (int16 input: as signed ints)
+    uint32_t flags;           // 1: declined / dense tile / failed seam chain, 2: slot overflow
+    uint32_t built;           // segments done
 };
 
 struct EvArgs {

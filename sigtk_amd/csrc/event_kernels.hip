@@ -23,8 +23,8 @@
 //
 //   k_event          a whole read: detector and builder back to back in the same wave (most reads);
 //                    its first workgroups run the detector over the SEGMENTS of reads too long for one wave
-//   k_event_seam / k_event_seg_count / k_event_build_seg / k_event_long_finish
-//                    the long reads: seams between segments verified (and re-run), builder per segment (round 3)
+//   chain_segment    (inside k_event) reads that several waves share -- long reads, the tail split: the wave of a
+//                    segment checks the seam against the segment in front and builds its own events (round 4)
 //   k_event_multi    several short reads per wave, `lanes` lanes each, on a side stream beside k_event (round 3)
 //   k_event_fallback persistent kernel over the reads that fail the exactness guard: lane 0 reproduces
 //                    compute_sum_sumsq's sequential double prefix scan (events.c:293-303) into workspace
@@ -688,11 +688,14 @@ struct LazyPass {
             }
         } else {
             if (lane_of(em)) {
+#ifndef SGK_X_NOBITS
                 bw |= bit;
+#endif
                 lm = sp;
                 r0 = u;
             }
             const lmask_t erare = em & ~hist[H1];
+#ifndef SGK_X_NOBITS
             if (erare != 0ull) {
                 if (lane_of(erare)) {  // an older peak: undo the bit, set the right one (its word is in the ring)
                     bw &= ~bit;
@@ -701,6 +704,7 @@ struct LazyPass {
                     else if (jb >= own) ring[LZ_PRE] = (uint32_t)(i_begin + p);  // inherited, see lz_emit_slow
                 }
             }
+#endif
         }
         sv = lane_of(upd) ? v : sv;
         sp = lane_of(pos) ? u : sp;
@@ -1042,9 +1046,11 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
 // Exact replay of the long detector (events.c:383-440, k = 1) over one hot run per lane: from the fresh state a
 // reset leaves, over the indices [i, b) of the run (inside a run masked_to does not change and every index is
 // processed).  Peaks are ORed into the read's bitmap if they lie in [bits_lo, bits_hi).
+// found != null: the peaks are not set in the bitmap, *found is set instead (chain_segment: a peak in front of a seam
+// lies in another wave's words)
 template <int W1, typename T, bool FLAGGED>
 __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has, int i, int b, int bits_lo,
-                           int bits_hi, EvHeader *hdr) {
+                           int bits_hi, EvHeader *hdr, int *found = nullptr) {
     if (has && b > i) atomicAdd(&hdr->n_replay_idx, (unsigned long long)(b - i));
     constexpr int W2 = 2 * W1;
     constexpr float ph = DetParam<W1>::ph, thr2 = DetParam<W1>::thr2;
@@ -1075,7 +1081,10 @@ __device__ void replay_run(const ReadCtx<T> &rc, const RepairCtx *rep, bool has,
                 }
                 if (lv - v2 > ph && lv > thr2) lvalid = true;
                 if (lvalid && (i - lp) > W2 / 2) {
-                    if (lp > 0 && lp < n && lp >= bits_lo && lp < bits_hi) atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
+                    if (lp > 0 && lp < n && lp >= bits_lo && lp < bits_hi) {
+                        if (found) *found = 1;
+                        else atomicOr(&bm32[lp >> 5], 1u << (lp & 31));
+                    }
                     lp = -1;
                     lv = v2;
                     lvalid = false;
@@ -1105,7 +1114,7 @@ __device__ void replay_long_runs(const ReadCtx<T> &rc, LzLds *L, const RepairCtx
 // (a multiple of 16; the whole read: a = 0, b = n).
 //   mode 0: the state at a is the fresh one (a = 0: the read's start)
 //   mode 1: unknown: the first lane warms up in front of a like every other lane; the state it reached at a is
-//           left in seg->init0 for the owner of the span in front to compare (k_event_seam)
+//           left in seg->init0, to be compared with the end state of the span in front (chain_segment)
 //   mode 2: the state at a is L->snap.st0[0], put there by the caller
 // seg (spans of a read that several waves share; null otherwise) receives the state at b and the hot runs that began
 // in front of a.
@@ -1232,13 +1241,13 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         }
         if (l == 0) seg->n_cross = total > SEG_CROSS_MAX ? 0u : (uint32_t)total;
     }
-    // inherited emissions (lz_emit_slow) of the lanes' accepted runs.  Inside the span the bit is set here; in front of
-    // it (another wave's words) only when nobody else is writing any more and the span's start state is the true one
-    // (mode 2: k_event_seam, one span at a time) -- a speculative span leaves them to k_event_seam (seg->pre).
+    // inherited emissions (lz_emit_slow) of the lanes' accepted runs.  Inside the span the bit is set here; one in
+    // front of it lies in another wave's words: it is left in seg->pre -- the segment OWNS that boundary (chain_segment
+    // builds the event that ends there), the bitmap never shows it.
     const int pre = mine_ok ? (int)L->ring[l][LZ_PRE] : -1;
     const bool pre_out = pre >= 0 && pre < a;
     if (seg) {
-        const int npre = (mode == 1 && pre_out) ? 1 : 0;
+        const int npre = pre_out ? 1 : 0;
         const int incl = wave_incl_scan_i(npre);
         const int total = wave_last_i(incl);
         if (total > SEG_PRE_MAX) rcode = 2;
@@ -1251,9 +1260,7 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         if (l == 0 && hotm != 0ull) atomicAdd(&hdr->n_hot_runs, (uint32_t)__popcll(hotm));
         __threadfence_block();
         __syncthreads();  // every lane's bitmap words are in memory before anything is ORed into them
-        if (pre >= 0 && (!pre_out || mode == 2)) {
-            atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
-        }
+        if (pre >= 0 && !pre_out) atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
 #ifndef SGK_EXP_NO_REPLAY
         if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, mine_ok, a, hdr);
 #endif
@@ -1421,11 +1428,13 @@ __device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, in
 // SEG: the wave builds the events of one segment [seg_a, seg_b) of a long read (several waves share the read): the
 // events that END at a boundary inside the segment, and the read's last event if the segment is the read's last.
 // It walks from the last boundary in front of the segment (prev_p; none: from the read's start), at the event rank the
-// boundaries in front give (cnt_before); extremes and flags go to st, the read's verdict is k_event_long_finish's.
+// boundaries in front give (cnt_before); extremes and flags go to st, the read's verdict is chain_segment's.  In front
+// of the segment the bitmap words are another wave's: the only boundaries the walk knows there are the one it starts
+// at (prev_p) and the ones this segment owns (pre: peaks that were pending at the seam).
 template <typename T, bool SEG = false>
 __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined,
                            int64_t seg_a = 0, int64_t seg_b = 0, SegState *st = nullptr, uint32_t cnt_before = 0,
-                           int prev_p = -1) {
+                           int prev_p = -1, const int *pre = nullptr, int n_pre = 0) {
     const int64_t n = rc.n;
     const int l = lane_id();
     const uint64_t slot0 = a.ev_slots[r], cap = a.ev_slots[r + 1] - slot0;
@@ -1467,6 +1476,15 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
         if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
         if constexpr (SEG) {
+            if (pos0 < seg_a) {
+                uint32_t sb = 0u;
+                if (prev_p >= pos0 && prev_p < pos0 + BT) sb |= 1u << (int)(prev_p - pos0);
+                for (int k = 0; k < n_pre; ++k) {
+                    const int64_t q = pre[k];
+                    if (q >= pos0 && q < pos0 + BT) sb |= 1u << (int)(q - pos0);
+                }
+                bits = sb;
+            }
             const int64_t dl = bit_lo - pos0, dh = bit_hi - pos0;
             if (dl > 0) bits = dl >= BT ? 0u : (bits & ~((1u << (int)dl) - 1u));
             if (dh < BT) bits = dh <= 0 ? 0u : (bits & ((1u << (int)dh) - 1u));
@@ -1584,7 +1602,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         known = mxb < 0x7f800000u;
     }
     if constexpr (SEG) {
-        // the read's last segment closes the read's last event; the verdict on the read is k_event_long_finish's
+        // the read's last segment closes the read's last event; the verdict on the read is chain_segment's
         if (l == 0 && seg_b == n) store_event_fast(eo, rank, prevp, (uint32_t)n, 0.0 - Gprev, 0.0 - G2prev, overflow);
         const bool ovf = __any(overflow);
         if (l == 0) {
@@ -1797,6 +1815,7 @@ __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
         if (li < a.max_long) {
             LongRead none;
             none.read = r; none.seg0 = 0; none.nseg = 0; none.seg_len = seg;
+            none.ext_lo = 0; none.ext_hi = 0; none.flags = 0; none.built = 0;
             a.longs[li] = none;
         }
         a.flags[r] = 1;
@@ -1805,32 +1824,37 @@ __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
     }
     LongRead lr;
     lr.read = r; lr.seg0 = s0; lr.nseg = G; lr.seg_len = seg;
+    lr.ext_lo = a.dig ? 32767u : 0xffffffffu;          // (int16 input: signed extremes; pA input: bit patterns)
+    lr.ext_hi = a.dig ? (uint32_t)-32768 : 0u;
+    lr.flags = 0; lr.built = 0;
     a.longs[li] = lr;
     for (uint32_t g = 0; g < G; ++g) {
         SegDesc d;
         d.read = r; d.g = g; d.lread = li; d.pad = 0;
         a.segs[s0 + g] = d;
+        a.seg_state[s0 + g].stage = 0u;   // (the chain: nothing of this segment is published yet)
     }
 }
 
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
     __shared__ EventLds L;
-    // The first max_segs workgroups take the segments of the long reads (detector only: k_event_seam checks the seams,
-    // k_event_build_seg builds; the segment list is usually much shorter than its capacity), the others one read each,
+    // The first (or last) seg_blocks workgroups take the segments of the reads that several waves share (chain_segment;
+    // the segment list is usually much shorter than its capacity), the others one read each,
     // longest first (launch_order): a kernel cannot end before its longest read has, so that one should start first,
     // not wherever it sits in the batch.
     // (seg_last: the segments are the tail split's and take the LAST workgroups -- small units into the slots the last
     // whole reads leave empty; long reads' segments take the first: a kernel cannot end before its longest read has)
     const uint32_t bx = a.seg_last ? (blockIdx.x >= a.n_reads ? blockIdx.x - a.n_reads : blockIdx.x + a.seg_blocks) : blockIdx.x;
     const bool is_seg = bx < a.seg_blocks;
-    uint32_t r, g = 0, seg_len = 0;
+    uint32_t r, g = 0, seg_len = 0, lread = 0;
     if (is_seg) {
         if (bx >= a.hdr->n_segs) return;
         const SegDesc d = a.segs[bx];
         if (d.read == SEG_NONE) return;
         r = d.read;
         g = d.g;
+        lread = d.lread;
         seg_len = a.longs[d.lread].seg_len;
     } else {
         const uint32_t bi = bx - a.seg_blocks;
@@ -1849,6 +1873,7 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, sa, sb, g == 0 ? 0 : 1, a.lead_override, st);
     if (is_seg) {
         if (lane_id() == 0) st->status = rcode;
+        chain_segment<W1, T>(a, rc, r, g, lread, seg_len, st, rcode, sa, sb, &L);
         return;
     }
     // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
@@ -1857,196 +1882,202 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifndef SGK_X_NOBUILD
     build_read<T>(a, rc, r, &L.b, rcode != 0);
+#endif
 }
 
-// Long reads, after every segment's detector pass: one wave per long read
-//  1. walks the seams: segment g was right iff its speculative first lane reached, at the segment's first index, the
-//     state segment g-1 ended with; a segment that was not is run again from that state (and may change its own end);
-//  2. replays the hot long-detector runs that cross a seam for the part in front of the seam (the segment itself
-//     replayed the part behind it).
+// ---- the chain: detector, seam check and builder of one segment in one wave (round 4) -------------------------
+// Round 3 ran the segments' detector passes in k_event and left the rest to four kernels behind it (seams, counts,
+// builders, verdict): a cut read lost the fusion of detector and builder, and every kernel had a tail of its own.  Now
+// the wave of segment g does everything itself and takes what it needs from segment g - 1 -- ALWAYS a lower workgroup
+// index, so with workgroups started in index order (what the hardware does, per XCD; decoupled look-back scans rely on
+// the same) the chain cannot deadlock; a wait that exceeds ~1 s all the same declines the read (exact fallback).
+//   1. detect_span over the segment, speculative start (mode 1): bitmap words of ITS range only;
+//   2. wait for segment g - 1's record {final end state, boundaries so far, the last of them, declined?} -- 40 bytes,
+//      published with agent-scope atomic stores (write-through) behind an s_waitcnt, read back with agent-scope atomic
+//      loads behind one agent acquire (MI355X_MICROARCH.md, inter-workgroup visibility: the XCDs' L2s are not coherent);
+//   3. the seam: end(g - 1) != its own init0 -> the segment is run again from the true state (mode 2);
+//   4. publish its own record (so the segments behind need not wait for its builder);
+//   5. build the events that end at the boundaries it OWNS: those inside its range and the peaks that were pending at
+//      the seam and emitted behind it (seg->pre: positions in front of the segment that no bitmap shows) -- from the
+//      last boundary of the segments in front, at the rank their boundaries give;
+//   6. extremes / flags into the read's record (atomics); the wave that finishes last gives the verdict (exactness
+//      guard over the whole read, n_events, counters, fallback list).
+// A hot long-detector run that crosses the seam is replayed for the part in front of it as well; a peak found there
+// (none on nanopore-like signals) would belong to another wave's events: the read is declined.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (out of line, arguments BY VALUE: inlined into k_event its second copy of the detector pass costs the whole-read path
+// 36 spilled registers; a reference parameter would pin the kernel's argument block and the read context in scratch)
 template <int W1, typename T>
-__global__ __launch_bounds__(64) void k_event_seam(EvArgs a) {
-    __shared__ LzLds L;
-    const uint32_t nl = a.hdr->n_long;
-    if (blockIdx.x >= (nl < a.max_long ? nl : a.max_long)) return;
-    const LongRead lr = a.longs[blockIdx.x];
-    if (lr.nseg == 0) return;
-    const ReadCtx<T> rc = make_ctx<T>(a, lr.read);
-    SegState *st = a.seg_state + lr.seg0;
+__device__ __attribute__((noinline)) void chain_segment(const EvArgs a, const ReadCtx<T> rc, uint32_t r, uint32_t g,
+                                                        uint32_t lread, uint32_t seg_len, SegState *st, int rcode, int sa,
+                                                        int sb, EventLds *L) {
     const int l = lane_id();
-    bool declined = false;
-    for (uint32_t g = l; g < lr.nseg; g += 64) declined = declined || st[g].status != 0;
-    declined = __any(declined);
-    for (uint32_t g = 1; g < lr.nseg && !declined; ++g) {
-        const LzSnapState pe = st[g - 1].end, mine = st[g].init0;
-        if (lz_equal(pe, mine)) continue;
-        int sa, sb;
-        seg_span(lr.seg_len, g, rc.n, sa, sb);
-        __syncthreads();
-        if (l == 0) {
-            L.snap.st0[0] = pe;
-            atomicAdd(&a.hdr->n_seam_rerun, 1u);
-        }
-        __syncthreads();
-        const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L, nullptr, sa, sb, 2, a.lead_override, st + g);
-        if (l == 0) {
-            st[g].status = rcode;
-            st[g].init0 = pe;
-        }
-        declined = rcode != 0;
-        __threadfence();
-        __syncthreads();
-    }
-    if (declined) {
-        if (l == 0) st[0].status = st[0].status ? st[0].status : 2;  // the whole read goes to the exact fallback
-        return;
-    }
-    __threadfence();
+    LongRead *lrp = a.longs + lread;
+    const uint32_t nseg = lrp->nseg;
+    bool declined = rcode != 0;
+    uint32_t prev_cum = 0u;
+    int prev_last = -1;
+    // (what detect_span's lanes stored -- st->end, cross runs, pre peaks -- is visible to the wave's other lanes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    for (uint32_t g = 1; g < lr.nseg; ++g) {
-        const int nc = (int)st[g].n_cross;
-        if (nc == 0) continue;
-        int sa, sb;
-        seg_span(lr.seg_len, g, rc.n, sa, sb);
-        const bool has = l < nc;
-        const LzRun run = has ? st[g].cross[l] : LzRun{0, 0};
-        replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr);
-    }
-    // peaks that were pending at a seam and emitted behind it
-    for (uint32_t g = 1; g < lr.nseg; ++g) {
-        const int np = (int)st[g].n_pre;
-        if (l < np) {
-            const int p = st[g].pre[l];
-            atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (p >> 5), 1u << (p & 31));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (g > 0) {
+        SegState *ps = st - 1;
+        int ok = 1;
+        if (l == 0) {
+            unsigned spins = 0;
+            while (ld_agent(&ps->stage) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > 4000000u) { ok = 0; break; }
+            }
         }
-    }
-}
-
-// Long reads: the boundary bits of every segment (how many, and the last one), one wave per segment.  A segment starts
-// on a multiple of 1024: whole 64-bit bitmap words.
-template <typename T>
-__global__ __launch_bounds__(64) void k_event_seg_count(EvArgs a) {
-    if (blockIdx.x >= a.hdr->n_segs) return;
-    const SegDesc d = a.segs[blockIdx.x];
-    if (d.read == SEG_NONE) return;
-    const ReadCtx<T> rc = make_ctx<T>(a, d.read);
-    int sa, sb;
-    seg_span(a.longs[d.lread].seg_len, d.g, rc.n, sa, sb);
-    const int l = lane_id();
-    const int w0 = sa >> 6, w1 = (sb + 63) >> 6;
-    int cnt = 0, last = -1;
-    for (int wb = w0; wb < w1; wb += 256) {
-        unsigned long long v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int w = wb + 64 * k + l;
-            v[k] = w < w1 ? rc.bm[w] : 0ull;
-            const int rem = sb - (w << 6);
-            if (rem < 64) v[k] = rem <= 0 ? 0ull : (v[k] & ((1ull << rem) - 1ull));
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        LzSnapState pe;
+        pe.sp = (int)ld_agent(reinterpret_cast<const uint32_t *>(&ps->end.sp));
+        pe.sv = __uint_as_float(ld_agent(reinterpret_cast<const uint32_t *>(&ps->end.sv)));
+        pe.lm = (int)ld_agent(reinterpret_cast<const uint32_t *>(&ps->end.lm));
+        pe.r0 = (int)ld_agent(reinterpret_cast<const uint32_t *>(&ps->end.r0));
+        pe.bits = ld_agent(&ps->end.bits);
+        prev_cum = ld_agent(&ps->cum_cnt);
+        prev_last = (int)ld_agent(reinterpret_cast<const uint32_t *>(&ps->last_pos));
+        if (!ok || (ld_agent(&ps->cflags) & 1u)) declined = true;
+        if (!declined) {
+            // the seam (st->init0 / st->end: this wave's own stores; the states are in LDS as well)
+            const LzSnapState mine = L->lz.snap.init[0];
+            if (!lz_equal(pe, mine)) {
+                __syncthreads();
+                if (l == 0) {
+                    L->lz.snap.st0[0] = pe;
+                    atomicAdd(&a.hdr->n_seam_rerun, 1u);
+                }
+                __syncthreads();
+                rcode = detect_span<W1, T, false>(rc, a.hdr, &L->lz, nullptr, sa, sb, 2, a.lead_override, st);
+                if (l == 0) st->status = rcode;
+                declined = rcode != 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (v[k]) {
-                cnt += __popcll(v[k]);
-                last = ((wb + 64 * k + l) << 6) + 63 - __clzll(v[k]);
+        if (!declined) {
+            // hot runs that began in front of the seam: the part in front of it
+            __syncthreads();
+            const int nc = (int)st->n_cross;
+            if (nc > 0) {
+                const bool has = l < nc;
+                const LzRun run = has ? st->cross[l] : LzRun{0, 0};
+                int found = 0;
+                replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr, &found);
+                if (__any(found != 0)) declined = true;
             }
         }
     }
+    // this wave's bitmap words (and the replay's atomics) are complete before any of its lanes reads them back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the boundaries the segment owns: the bits of its range + its pre peaks
+    int cnt = 0, last = -1, n_pre = 0;
+    if (!declined) {
+        const int w0 = sa >> 6, w1 = (sb + 63) >> 6;
+        for (int wb = w0; wb < w1; wb += 64) {
+            const int w = wb + l;
+            unsigned long long v = w < w1 ? rc.bm[w] : 0ull;
+            const int rem = sb - (w << 6);
+            if (rem < 64) v = rem <= 0 ? 0ull : (v & ((1ull << rem) - 1ull));
+            if (v) {
+                cnt += __popcll(v);
+                last = (w << 6) + 63 - __clzll(v);
+            }
+        }
 #pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) {
-        cnt += __shfl_xor(cnt, dd, 64);
-        const int o = __shfl_xor(last, dd, 64);
-        last = o > last ? o : last;
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            cnt += __shfl_xor(cnt, dd, 64);
+            const int o = __shfl_xor(last, dd, 64);
+            last = o > last ? o : last;
+        }
+        n_pre = (int)st->n_pre;
+        if (last < 0) {
+            for (int k = 0; k < n_pre; ++k) last = st->pre[k] > last ? st->pre[k] : last;
+            if (last < 0) last = prev_last;
+        }
     }
+    const uint32_t my_cum = prev_cum + (uint32_t)(cnt + n_pre);
+    // publish (the end state: what detect_span left in st->end -- lane 0's own store)
     if (l == 0) {
-        a.seg_state[blockIdx.x].cnt = (uint32_t)cnt;
-        a.seg_state[blockIdx.x].last = last;
+        const LzSnapState e = st->end;
+        st_agent(reinterpret_cast<uint32_t *>(&st->end.sp), (uint32_t)e.sp);
+        st_agent(reinterpret_cast<uint32_t *>(&st->end.sv), __float_as_uint(e.sv));
+        st_agent(reinterpret_cast<uint32_t *>(&st->end.lm), (uint32_t)e.lm);
+        st_agent(reinterpret_cast<uint32_t *>(&st->end.r0), (uint32_t)e.r0);
+        st_agent(&st->end.bits, e.bits);
+        st_agent(&st->cum_cnt, my_cum);
+        st_agent(reinterpret_cast<uint32_t *>(&st->last_pos), (uint32_t)(declined ? prev_last : last));
+        st_agent(&st->cflags, declined ? 1u : 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&st->stage, 1u);
     }
-}
-
-// Long reads: the builder, one wave per segment.
-template <typename T>
-__global__ __launch_bounds__(64, 3) void k_event_build_seg(EvArgs a) {
-    __shared__ BuildLds L;
-    if (blockIdx.x >= a.hdr->n_segs) return;
-    const SegDesc d = a.segs[blockIdx.x];
-    if (d.read == SEG_NONE) return;
-    const LongRead lr = a.longs[d.lread];
-    const SegState *st0 = a.seg_state + lr.seg0;
-    if (st0[0].status != 0) return;  // declined: the fallback builds the read
-    const ReadCtx<T> rc = make_ctx<T>(a, d.read);
-    int sa, sb;
-    seg_span(lr.seg_len, d.g, rc.n, sa, sb);
-    // boundary bits in front of the segment: their number is the rank of the segment's first event, the last of them
-    // is where that event starts
-    uint32_t before = 0;
-    int prev = -1;
-    for (uint32_t g = lane_id(); g < d.g; g += 64) {
-        before += st0[g].cnt;
-        const int q = st0[g].last;
-        prev = q > prev ? q : prev;
+    uint32_t fl = declined ? 1u : 0u;
+    if (!declined) {
+        build_read<T, true>(a, rc, r, &L->b, false, sa, sb, st, prev_cum, prev_last, st->pre, n_pre);
+        __syncthreads();
+        if (l == 0) {
+            const uint32_t lo = st->ext_lo, hi = st->ext_hi;
+            if constexpr (std::is_same<T, int16_t>::value) {
+                atomicMin(reinterpret_cast<int *>(&lrp->ext_lo), (int)lo);
+                atomicMax(reinterpret_cast<int *>(&lrp->ext_hi), (int)hi);
+            } else {
+                atomicMin(&lrp->ext_lo, lo);
+                atomicMax(&lrp->ext_hi, hi);
+            }
+            fl = st->bflags;
+        }
     }
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) {
-        before += (uint32_t)__shfl_xor((int)before, dd, 64);
-        const int o = __shfl_xor(prev, dd, 64);
-        prev = o > prev ? o : prev;
-    }
-    build_read<T, true>(a, rc, d.read, &L, false, sa, sb, a.seg_state + blockIdx.x, before, prev);
-}
-
-// Long reads: the read-level verdict (exactness guard over the whole read, counters), one thread per long read.
-template <typename T>
-__global__ __launch_bounds__(64) void k_event_long_finish(EvArgs a) {
-    const uint32_t li = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t nl = a.hdr->n_long;
-    if (li >= (nl < a.max_long ? nl : a.max_long)) return;
-    const LongRead lr = a.longs[li];
-    if (lr.nseg == 0) return;  // k_seg_plan sent the read to the fallback
-    const SegState *st = a.seg_state + lr.seg0;
-    const uint32_t r = lr.read;
-    const int64_t n = (int64_t)a.lengths[r];
-    bool flagged = st[0].status != 0, overflow = false;
+    if (l != 0) return;
+    if (fl) atomicOr(&lrp->flags, fl);
+    // (everything the verdict reads was written with device-scope atomics, which complete in memory: this lane's have
+    // before it counts itself done.  NO agent-scope fence: its write-back of the XCD's whole L2 -- megabytes of other
+    // waves' event stores -- once per segment made the chain slower than no split at all, 3.95 vs 3.86 ms)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t done = atomicAdd(&lrp->built, 1u);
+    if (done + 1u != nseg) return;
+    // the verdict (every segment has published its record and added its extremes / flags)
+    const uint32_t flags = atomicOr(&lrp->flags, 0u);
+    const int64_t n = rc.n;
+    bool flagged = (flags & 1u) != 0u;
     if (!flagged) {
         float mn, mx;
         bool known;
-        uint32_t bf = 0, nev = 1;
         if constexpr (std::is_same<T, int16_t>::value) {
-            int rmn = 32767, rmx = -32768;
-            for (uint32_t g = 0; g < lr.nseg; ++g) {
-                const int lo = (int)st[g].ext_lo, hi = (int)st[g].ext_hi;
-                rmn = lo < rmn ? lo : rmn;
-                rmx = hi > rmx ? hi : rmx;
-                bf |= st[g].bflags;
-                nev += st[g].cnt;
-            }
-            const Scale sc = make_scale(a.dig[r], a.off[r], a.rng[r]);
-            known = raw_extremes_to_pa(rmn, rmx, sc, mn, mx);
+            const int rmn = atomicMin(reinterpret_cast<int *>(&lrp->ext_lo), 32767);
+            const int rmx = atomicMax(reinterpret_cast<int *>(&lrp->ext_hi), -32768);
+            known = raw_extremes_to_pa(rmn, rmx, rc.sc, mn, mx);
         } else {
-            uint32_t mnb = 0xffffffffu, mxb = 0u;
-            for (uint32_t g = 0; g < lr.nseg; ++g) {
-                mnb = st[g].ext_lo < mnb ? st[g].ext_lo : mnb;
-                mxb = st[g].ext_hi > mxb ? st[g].ext_hi : mxb;
-                bf |= st[g].bflags;
-                nev += st[g].cnt;
-            }
+            const uint32_t mnb = atomicMin(&lrp->ext_lo, 0xffffffffu), mxb = atomicMax(&lrp->ext_hi, 0u);
             mn = (mnb == 0xffffffffu) ? FLT_MAX : __uint_as_float(mnb + 1u);
             mx = __uint_as_float(mxb);
             known = mxb < 0x7f800000u;
         }
-        flagged = (bf & 1u) || !known || !guard_ok(mn, mx, n);
-        overflow = (bf & 2u) != 0u;
-        if (!flagged) {
-            a.n_events[r] = nev;
-            atomicAdd(&a.hdr->n_events_total, (unsigned long long)nev);
-            if (overflow) atomicAdd(&a.hdr->n_overflow, 1u);
-        }
+        flagged = !known || !guard_ok(mn, mx, n);
     }
     a.flags[r] = flagged ? 1 : 0;
     if (flagged) {
-        const uint32_t k = atomicAdd(&a.hdr->n_flagged, 1u);
-        a.flag_list[k] = r;
+        a.flag_list[atomicAdd(&a.hdr->n_flagged, 1u)] = r;
+    } else {
+        const uint32_t nev = ld_agent(&a.seg_state[lrp->seg0 + nseg - 1u].cum_cnt) + 1u;
+        a.n_events[r] = nev;
+        atomicAdd(&a.hdr->n_events_total, (unsigned long long)nev);
+        if (flags & 2u) atomicAdd(&a.hdr->n_overflow, 1u);
     }
 }
 
@@ -2129,10 +2160,8 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 // reads, log-normal around 20 000 samples: 6.36 ms against 6.29 ms with a wavefront per read).  k_event_multi therefore
 // goes to a side stream of the library's own, forked off the caller's stream behind the dispatch order and joined in
 // front of the fallback kernel; the long reads' seam / builder kernels overlap with it as well.
-// The TAIL SPLIT (seg_len_of) uses a second kind: a stream of the LOWEST priority.  The segment kernels of the split
-// reads queue there and are dispatched when k_event on the caller's stream has no workgroup left to start -- i.e. into
-// the slots its last waves leave empty while they finish, which is what the split is for (in the caller's stream, in
-// front of k_event, they only moved the partial round from the end to the start: 3.92 vs 3.84 ms on config 2).
+// (Tried for the tail split's segments: a stream of the LOWEST priority, so that they would be dispatched into the slots
+// k_event's last waves leave empty -- 5.1 vs 3.8 ms on config 2: its kernels start late and slowly.)
 // A small pool per device and kind, handed out round-robin; a stream's mutex is held while one launch enqueues its
 // fork .. join on it (the events are the stream's), never across launches of other streams or devices.
 struct SideStream {
@@ -2223,12 +2252,12 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     // (no dispatch order and packing on: every read is under multi_max.  k_event would have nothing to do -- unless
     // the segments are test-sized and some of those reads are long: their segments are k_event's)
     const bool all_short = ao.multi_lanes && !ao.order && !ao.max_segs;
-    // the segments of a batch whose only segments are the tail split's go to the low-priority stream
+    // the tail split's segments take k_event's LAST workgroups (small units into the slots the last whole reads leave
+    // empty), long reads' segments its first (a kernel cannot end before its longest read has)
     const bool tail_only = ao.max_segs && ao.split_seg && !ao.has_long;
-    SideFork multi_side, tail_side;
-    hipStream_t st_multi = st, st_seg = st;
+    SideFork multi_side;
+    hipStream_t st_multi = st;
     if (ao.multi_lanes && !all_short && multi_side.open(false, st)) st_multi = multi_side.stream();
-    (void)tail_side;   // (the low-priority stream: measured, 5.1 vs 3.8 ms -- its kernels start late and slowly)
     if (ao.multi_lanes) {
         ProfScope ps("k_event_multi", st_multi);
         const uint32_t per_wave = 64u / ao.multi_lanes;
@@ -2237,41 +2266,15 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         else hipLaunchKernelGGL((k_event_multi<3, T>), dim3(grid), dim3(64), 0, st_multi, ao);
         SGK_HIP_TRY(hipGetLastError());
     }
-    // k_event: the first seg_blocks workgroups take segments, the others one read each.  With the segments on a stream
-    // of their own it is two launches: the reads on the caller's stream, the segments on the other.
-    const bool seg_apart = st_seg != st;
     if (!all_short) {
         ProfScope ps("k_event", st);
-        EvArgs ar = ao;
-        ar.seg_blocks = seg_apart ? 0u : ao.max_segs;
-        ar.seg_last = tail_only ? 1u : 0u;
-        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ar.seg_blocks + a.n_reads), dim3(64), 0, st, ar);
-        else hipLaunchKernelGGL((k_event<3, T>), dim3(ar.seg_blocks + a.n_reads), dim3(64), 0, st, ar);
+        ao.seg_blocks = ao.max_segs;
+        ao.seg_last = tail_only ? 1u : 0u;
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.seg_blocks + a.n_reads), dim3(64), 0, st, ao);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.seg_blocks + a.n_reads), dim3(64), 0, st, ao);
     }
     SGK_HIP_TRY(hipGetLastError());
-    if (ao.max_segs) {
-        EvArgs as = ao;
-        as.seg_blocks = ao.max_segs;
-        if (seg_apart) {
-            ProfScope ps("k_event_segs", st_seg);
-            if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
-            else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
-        }
-        {
-            ProfScope ps("k_event_seam", st_seg);
-            if (rna) hipLaunchKernelGGL((k_event_seam<7, T>), dim3(ao.max_long), dim3(64), 0, st_seg, as);
-            else hipLaunchKernelGGL((k_event_seam<3, T>), dim3(ao.max_long), dim3(64), 0, st_seg, as);
-            hipLaunchKernelGGL((k_event_seg_count<T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
-        }
-        {
-            ProfScope ps("k_event_build_seg", st_seg);
-            hipLaunchKernelGGL((k_event_build_seg<T>), dim3(ao.max_segs), dim3(64), 0, st_seg, as);
-            hipLaunchKernelGGL((k_event_long_finish<T>), dim3((ao.max_long + 63) / 64), dim3(64), 0, st_seg, as);
-        }
-        SGK_HIP_TRY(hipGetLastError());
-    }
     // join: the fallback kernel (and whatever the caller enqueues next) waits for the side streams as well
-    tail_side.join();
     multi_side.join();
     {
         ProfScope ps("k_event_fallback", st);

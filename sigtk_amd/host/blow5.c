@@ -220,15 +220,16 @@ static char *idx_path(const b5_file_t *f) {
 static int idx_load(b5_file_t *f) {
     char *ip = idx_path(f);
     if (!ip) return B5_ERR_MEM;
-    /* an index older than its BLOW5 describes another file of that name (slow5lib warns "Index file is older",
-     * slow5_idx.c:43, and goes on; here the file is scanned again and the index rewritten) */
+    /* an index older than its BLOW5 may describe another file of that name.  Like slow5lib (slow5_idx.c:43) this warns
+     * and goes on -- after cp / rsync without -t, tar extraction, or in a read-only directory a rescan of a large file on
+     * every invocation costs minutes -- and relies on the check of every fetched record (b5_get / b5_get_raw: id and
+     * size; a mismatch drops the index and scans the file) */
     struct stat st_idx, st_dat;
     if (stat(ip, &st_idx) == 0 && stat(f->path, &st_dat) == 0 &&
         (st_idx.st_mtim.tv_sec < st_dat.st_mtim.tv_sec ||
-         (st_idx.st_mtim.tv_sec == st_dat.st_mtim.tv_sec && st_idx.st_mtim.tv_nsec < st_dat.st_mtim.tv_nsec))) {
-        free(ip);
-        return B5_ERR_NOTFOUND;
-    }
+         (st_idx.st_mtim.tv_sec == st_dat.st_mtim.tv_sec && st_idx.st_mtim.tv_nsec < st_dat.st_mtim.tv_nsec)))
+        fprintf(stderr, "[b5_idx::WARNING] Index file '%s' is older than its BLOW5: using it, every fetched record is "
+                        "checked against it\n", ip);
     FILE *fp = fopen(ip, "rb");
     free(ip);
     if (!fp) return B5_ERR_NOTFOUND;
@@ -290,6 +291,7 @@ static void idx_write(const b5_file_t *f, const b5_idx_entry_t *in_file_order, u
     char *ip = idx_path(f);
     if (!ip) return;
     FILE *fp = fopen(ip, "wb");
+    if (!fp) fprintf(stderr, "[b5_idx::WARNING] cannot write index file '%s': the next run scans the file again\n", ip);
     if (fp) {
         uint8_t head[64];
         memset(head, 0, sizeof head);
@@ -422,8 +424,7 @@ int b5_next_raw(b5_file_t *f, uint8_t **buf, uint64_t *len, uint64_t *cap, uint6
 }
 
 /* raw bytes of the record `read_id` (as b5_next_raw).  The record is not parsed here, so an index from disk is checked
- * as far as the bytes allow: the size it records, and, when records are not compressed, the id stored in the record
- * (b5_parse_raw's caller sees the id of compressed records and compares it itself). */
+ * (the size it records and the id stored in the record). */
 int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, uint64_t *cap, uint64_t *size) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!f->idx) {
@@ -451,6 +452,16 @@ int b5_get_raw(b5_file_t *f, const char *read_id, uint8_t **buf, uint64_t *len, 
                 memcpy(&have, r, 2);
                 fits = have == idl && memcmp(r + 2, read_id, idl) == 0;
             }
+        } else if (fits) {
+            /* compressed records: the id is inside the deflate stream.  An index of another file of that name can point
+             * at ANOTHER record of the same compressed size; the record is inflated and parsed here to compare (read-id
+             * mode fetches a handful of reads: the extra inflate does not matter) */
+            uint8_t *sc = NULL;
+            uint64_t sc_cap = 0;
+            b5_view_t v;
+            const int prc = b5_parse_raw(f, *buf + len0, *size, &sc, &sc_cap, &v);
+            fits = prc == 0 && v.id_len == strlen(read_id) && memcmp(v.read_id, read_id, v.id_len) == 0;
+            free(sc);
         }
         if (fits || !f->idx_from_disk || attempt == 1) return rc == 0 && !fits ? B5_ERR_FORMAT : rc;
         *len = len0;

@@ -1,5 +1,6 @@
 """CPU: the sigtk-amd host CLI -- argument surface, the C BLOW5 reader, and the no-GPU error."""
 import os
+import time
 import subprocess
 
 import numpy as np
@@ -233,11 +234,59 @@ def test_index_of_another_file_is_detected(cli, tmp_path, sp1):
         assert open(a + ".idx", "rb").read() != good
         open(a + ".idx", "wb").write(good)
         os.utime(a + ".idx", (future, future))
-    # an index older than the data file is ignored outright
+    # an index older than the data file is used with a warning, as slow5lib does (after cp / rsync / tar
+    # every invocation would scan the whole file otherwise) -- the check of every fetched record still catches this one
     past = time.time() - 1000
     os.utime(a + ".idx", (past, past))
     p = run(cli, "_dump", "--id", sp1.reads[50].read_id, a)
     assert p.returncode == 0 and int(p.stdout.split("\t")[5], 16) == want[sp1.reads[50].read_id]
+    assert "older than its BLOW5" in p.stderr
+    # ... and a GOOD older index is simply used: no rescan, no rewrite
+    blow5.write_blow5(a, sp1.reads, {k: v[0] for k, v in sp1.attrs.items()}, 1, 1)
+    os.remove(a + ".idx")
+    assert run(cli, "_dump", "--id", sp1.reads[0].read_id, a).returncode == 0
+    fresh = open(a + ".idx", "rb").read()
+    os.utime(a + ".idx", (past, past))
+    mt = os.stat(a + ".idx").st_mtime
+    p = run(cli, "_dump", "--id", sp1.reads[7].read_id, a)
+    assert p.returncode == 0 and int(p.stdout.split("\t")[5], 16) == want[sp1.reads[7].read_id]
+    assert open(a + ".idx", "rb").read() == fresh and os.stat(a + ".idx").st_mtime == mt
+
+
+def test_read_id_mode_of_the_cli_checks_the_id_of_compressed_records(cli, tmp_path, sp1):
+    """the pipeline's read-id path (b5_get_raw) only compared the SIZE of a compressed record with its
+    index entry; an index of another file that points at another record of the same compressed size returned the wrong
+    read.  Two reads are given identical signals (identical compressed sizes up to the id, which has a fixed length)
+    and the index entries of the two are swapped."""
+    import copy
+    import struct
+    reads = [copy.copy(r) for r in sp1.reads[:6]]
+    reads[4] = copy.copy(reads[1]); reads[4].read_id = sp1.reads[4].read_id   # same bytes but the id
+    reads[4].raw = reads[1].raw.copy()
+    a = str(tmp_path / "b.blow5")
+    blow5.write_blow5(a, reads, {k: v[0] for k, v in sp1.attrs.items()}, 1, 1)
+    assert run(cli, "_dump", "--id", reads[0].read_id, a).returncode == 0          # writes b.blow5.idx
+    idx = bytearray(open(a + ".idx", "rb").read())
+    # parse the entries: (u16 len, id, u64 offset, u64 size)
+    pos, ent = 64, {}
+    while pos < len(idx) - 8:
+        n = struct.unpack_from("<H", idx, pos)[0]
+        rid = bytes(idx[pos + 2:pos + 2 + n]).decode()
+        ent[rid] = pos + 2 + n
+        pos += 2 + n + 16
+    p1, p4 = ent[reads[1].read_id], ent[reads[4].read_id]
+    e1, e4 = bytes(idx[p1:p1 + 16]), bytes(idx[p4:p4 + 16])
+    if struct.unpack_from("<Q", e1, 8)[0] != struct.unpack_from("<Q", e4, 8)[0]:
+        pytest.skip("the two records did not deflate to the same size")
+    idx[p1:p1 + 16], idx[p4:p4 + 16] = e4, e1
+    open(a + ".idx", "wb").write(bytes(idx))
+    future = time.time() + 100
+    os.utime(a + ".idx", (future, future))
+    # the CLI's read-id mode (the pipeline: b5_get_raw + b5_parse_raw), not _dump
+    p = run(cli, "stat", a, reads[4].read_id)
+    assert p.returncode == 0, p.stderr
+    rows = [ln for ln in p.stdout.splitlines() if ln and not ln.startswith("read_id")]
+    assert len(rows) == 1 and rows[0].split("\t")[0] == reads[4].read_id
 
 
 @pytest.fixture(scope="module")
