@@ -633,15 +633,10 @@ struct LazyPass {
         }
         ar[U % NA] = sgk_arole<W1, !FLAGGED>(b1, b1q);
         // long window: bound only
-#ifdef SGK_EXP_NO_LONG
-        bool cold = true;
-        (void)b2; (void)b2q;
-#else
         const SgkLSide lb = sgk_lside<W2>(b2, b2q);
         bool cold = sgk_long_cold<W2>(ls[(U + NL - W2) % NL], lb);
         if constexpr (FLAGGED) cold = cold && clean && sgk_lside_domain(ls[(U + NL - W2) % NL]) && sgk_lside_domain(lb);
         ls[U % NL] = lb;
-#endif
         t1[U & 3] = v;
         nk[U & 3] = ~__ballot(ok);
         hc[U & 3] = ~__ballot(cold);
@@ -688,14 +683,11 @@ struct LazyPass {
             }
         } else {
             if (lane_of(em)) {
-#ifndef SGK_X_NOBITS
                 bw |= bit;
-#endif
                 lm = sp;
                 r0 = u;
             }
             const lmask_t erare = em & ~hist[H1];
-#ifndef SGK_X_NOBITS
             if (erare != 0ull) {
                 if (lane_of(erare)) {  // an older peak: undo the bit, set the right one (its word is in the ring)
                     bw &= ~bit;
@@ -704,7 +696,6 @@ struct LazyPass {
                     else if (jb >= own) ring[LZ_PRE] = (uint32_t)(i_begin + p);  // inherited, see lz_emit_slow
                 }
             }
-#endif
         }
         sv = lane_of(upd) ? v : sv;
         sp = lane_of(pos) ? u : sp;
@@ -1261,9 +1252,7 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
         __threadfence_block();
         __syncthreads();  // every lane's bitmap words are in memory before anything is ORed into them
         if (pre >= 0 && !pre_out) atomicOr(reinterpret_cast<uint32_t *>(rc.bm) + (pre >> 5), 1u << (pre & 31));
-#ifndef SGK_EXP_NO_REPLAY
         if (hotm != 0ull) replay_long_runs<W1, T, FLAGGED>(rc, L, rep, mine_ok, a, hdr);
-#endif
     }
     return rcode;
 }
@@ -1882,9 +1871,7 @@ __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RN
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifndef SGK_X_NOBUILD
     build_read<T>(a, rc, r, &L.b, rcode != 0);
-#endif
 }
 
 // ---- the chain: detector, seam check and builder of one segment in one wave (round 4) -------------------------

@@ -1173,7 +1173,7 @@ static int qtsmain(int argc, char *argv[]) {
 }
 
 /* hidden helper for tests: dump id, length, scaling and a checksum of every record.  `--split` goes
- * through the pipelined reader's split API (b5_next_raw + b5_parse_raw + b5_svb_zd_decode). */
+ * through the pipelined reader's split API (b5_next_raw + b5_parse_raw + b5_svb_zd_decode; with --id: b5_get_raw). */
 static uint64_t fnv_i16(const int16_t *x, uint64_t n) {
     uint64_t h = 1469598103934665603ull;
     for (uint64_t i = 0; i < n; i++) {
@@ -1198,6 +1198,27 @@ static int dumpmain(int argc, char *argv[]) {
         return 1;
     }
     int ret;
+    if (want_id && split) {
+        /* the pipeline's read-id path: b5_get_raw (index + verification of the fetched record) + b5_parse_raw */
+        uint8_t *raw = NULL, *scratch = NULL;
+        uint64_t len = 0, cap = 0, scap = 0, size = 0;
+        ret = b5_get_raw(f, want_id, &raw, &len, &cap, &size);
+        b5_view_t v;
+        if (ret == 0) ret = b5_parse_raw(f, raw, size, &scratch, &scap, &v);
+        if (ret == 0) {
+            int16_t *sig = (int16_t *)malloc(sizeof(int16_t) * (v.n_samples ? v.n_samples : 1));
+            if (f->signal_press == 1) ret = b5_svb_zd_decode(v.signal, v.signal_bytes, sig, v.n_samples);
+            else memcpy(sig, v.signal, v.signal_bytes);
+            if (ret == 0)
+                printf("%.*s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", (int)v.id_len, v.read_id, (unsigned long)v.n_samples,
+                       v.digitisation, v.offset, v.range, (unsigned long)fnv_i16(sig, v.n_samples));
+            free(sig);
+        }
+        free(raw);
+        free(scratch);
+        b5_close(f);
+        return ret == 0 ? 0 : 1;
+    }
     if (want_id) {
         b5_rec_t rec;
         memset(&rec, 0, sizeof rec);

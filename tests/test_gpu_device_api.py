@@ -289,3 +289,81 @@ def test_baseline_config4_and_5_at_their_shard_size(gpu, oracle):
         assert g.start.size == exp.start.size and np.array_equal(g.start.astype(np.uint64), exp.start)
         assert np.array_equal(g.mean.view(np.uint32), exp.mean.view(np.uint32))
         assert np.array_equal(g.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+def test_baseline_config3_at_its_size(gpu, oracle):
+    """BASELINE config 3 at its size (50 000 RNA-headed reads x 100 000 samples: 10 GB of samples, 27 GB of event
+    slots): `event` with RNA parameters + `prefix`.  Properties of every read, idempotence, the tail split at work
+    (50 000 reads are 24.4 rounds of RNA wavefronts: no split; the same call on the first 9 000 reads has one), and the
+    oracle bit for bit on a sample of reads for both subtools."""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free HBM (this device has %.0f GB free)" % (free / (1 << 30)))
+    R, N = 50000, 100000
+    b = device.synth_reads(R, N, seed=2, kind=1, device=dev)
+    arena = device.EventArena(b)
+    device.event(b, arena, 1)
+    torch.cuda.synchronize()
+    st = arena.status()
+    nev = arena.n_events[:R].to(torch.int64)
+    assert st.n_capacity_overflow == 0 and int(nev.sum().item()) == st.n_events_total and st.n_split_reads == 0
+    slots = torch.from_numpy(arena.slots_host[:-1]).to(dev)
+    assert bool((arena.start[slots].to(torch.int64) == 0).all())
+    last = slots + nev - 1
+    assert bool(((arena.start[last].to(torch.int64) + arena.length[last].to(torch.int64)) == N).all())
+    # events per read in the range the RNA-like generator gives (25.4 samples per event on average)
+    assert 3000 < float(nev.double().mean().item()) < 5000
+    snap_n = nev.clone()
+    snap = {r: arena.read_events(r) for r in (5, 31234)}
+    device.event(b, arena, 1)
+    torch.cuda.synchronize()
+    assert bool((arena.n_events[:R].to(torch.int64) == snap_n).all())
+    for r, e in snap.items():
+        g = arena.read_events(r)
+        assert np.array_equal(g.start, e.start) and np.array_equal(g.stdv.view(np.uint32), e.stdv.view(np.uint32))
+    for r in (0, 1, 24999, 49998, 49999):
+        o = int(b.offsets_host[r])
+        raw = b.samples[o:o + N].cpu().numpy()
+        exp = oracle.event_raw(raw, float(b.dig[r]), float(b.off[r]), float(b.rng[r]), 1)
+        got = arena.read_events(r)
+        assert np.array_equal(got.start.astype(np.uint64), exp.start)
+        assert np.array_equal(got.length.astype(np.float32), exp.length)
+        assert np.array_equal(got.mean.view(np.uint32), exp.mean.view(np.uint32))
+        assert np.array_equal(got.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+    # prefix over the same resident batch
+    rec = device.prefix(b, 1, 0)
+    torch.cuda.synchronize()
+    pf = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.PREFIX_DTYPE)[:R]
+    assert bool((pf["n"] == N).all())
+    found = pf["adapt_y"] > 0
+    assert found.mean() > 0.9                       # the synthetic RNA reads carry an adaptor stall
+    assert bool((pf["adapt_x"][found] < pf["adapt_y"][found]).all()) and bool((pf["adapt_y"][found] <= N).all())
+    rec2 = device.prefix(b, 1, 0)
+    torch.cuda.synchronize()
+    assert rec2.cpu().numpy().tobytes() == rec.cpu().numpy().tobytes()
+    for r in (0, 24999, 49999):
+        o = int(b.offsets_host[r])
+        raw = b.samples[o:o + N].cpu().numpy()
+        e = oracle.prefix(raw, float(b.dig[r]), float(b.off[r]), float(b.rng[r]), 1, 0)
+        g = pf[r]
+        for name in ("adapt_x", "adapt_y", "polya_x", "polya_y"):
+            assert int(g[name]) == int(getattr(e, name)), (r, name)
+        if e.adapt_y > 0:
+            for name in ("adapt_mean", "adapt_std", "adapt_median"):
+                assert np.float32(g[name]).view(np.uint32) == np.float32(getattr(e, name)).view(np.uint32), (r, name)
+        if e.polya_y > 0:
+            for name in ("polya_mean", "polya_std", "polya_median"):
+                assert np.float32(g[name]).view(np.uint32) == np.float32(getattr(e, name)).view(np.uint32), (r, name)
+    # the tail split: the first 9 000 reads of the same batch are 4.4 rounds of RNA wavefronts
+    del arena
+    torch.cuda.empty_cache()
+    b9 = device.synth_reads(9000, N, seed=2, kind=1, device=dev)
+    a9 = device.EventArena(b9)
+    device.event(b9, a9, 1)
+    torch.cuda.synchronize()
+    s9 = a9.status()
+    assert s9.n_split_reads == 9000 % 2048 and s9.n_fallback_reads == 0
+    assert bool((a9.n_events[:9000].to(torch.int64) == snap_n[:9000]).all())

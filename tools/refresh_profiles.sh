@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/${1:-r02}
+O=gpurun_out/${1:-r04}
 mkdir -p $O
 timeout -s KILL 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout -s KILL 600 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>> $O/bench.err
@@ -29,6 +29,16 @@ timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format cs
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_sq.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_rna -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --rna 1 > $O/pmc_sq_rna.log 2>&1
+# round 4: the packed short reads (k_event_multi) and the chained segments (ragged batch: k_event's first workgroups)
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_5k -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --read-len 5000 --reads 200000 > $O/pmc_sq_5k.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_ragged -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --ragged 0.8 > $O/pmc_sq_ragged.log 2>&1
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ragged -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 --ragged 0.8 > $O/prof_ragged.log 2>&1
+# the tail split off / small and odd batch sizes
+SGK_EVENT_TAIL=0 timeout -s KILL 600 python bench.py --cpu-reads 0 > $O/bench_no_tail_split.json 2>> $O/bench.err
+for n in 1000 4000 9300; do
+timeout -s KILL 600 python bench.py --reads $n --cpu-reads 0 > $O/bench_${n}.json 2>> $O/bench.err
+SGK_EVENT_TAIL=0 timeout -s KILL 600 python bench.py --reads $n --cpu-reads 0 > $O/bench_${n}_no_tail_split.json 2>> $O/bench.err
+done
 if [ "$2" != "nosub" ]; then
 timeout -s KILL 900 python bench.py --config 3 > $O/bench_c3.json 2>> $O/bench.err
 timeout -s KILL 900 python bench.py --config 4 --steps 5 > $O/bench_c4.json 2>> $O/bench.err
@@ -36,6 +46,7 @@ timeout -s KILL 900 python bench.py --config 5 --steps 3 > $O/bench_c5.json 2>> 
 timeout -s KILL 600 python tools/bench_subtools.py --reads 125000 --rna 0 > $O/subtools_c4.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --reads 50000 --rna 1 > $O/subtools_c3.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --ragged 0.8 > $O/subtools_ragged.json 2>> $O/bench.err
+timeout -s KILL 900 python -m pytest tests/test_gpu_device_api.py -q -k config3 > $O/test_config3.txt 2>&1; tail -3 $O/test_config3.txt
 fi
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
