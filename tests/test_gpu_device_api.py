@@ -158,6 +158,21 @@ def test_getevents_shim_matches_reference_signature(gpu, oracle, sp1):
         assert np.array_equal(got[:, 1].astype(np.float32), exp.length)
         assert np.array_equal(got[:, 2].astype(np.float32).view(np.uint32), exp.mean.view(np.uint32))
         libc.free(t.event)
+    # pA input through the chained segments (round 4): a batch of one read is a partial round of wavefronts, so the tail
+    # split cuts a 100 000-sample read into 8 segments; a 700 000-sample read is long anyway (6 segments of 131 072)
+    for n, rna in ((100000, 0), (700000, 0), (300000, 1)):
+        reads, dig, off, rng = gpu.synth_reads_host(1, n, seed=5 + rna, kind=rna)
+        pa = oracle.pa(reads[0], dig[0], off[0], rng[0])
+        exp = oracle.getevents(pa, rna)
+        t = L.sgk_getevents(pa.size, pa.ctypes.data, rna)
+        assert t.n == exp.start.size, (n, rna, t.n, exp.start.size)
+        ev = np.ctypeslib.as_array(C.cast(t.event, C.POINTER(C.c_uint8)), shape=(t.n * C.sizeof(Ev),)).copy()
+        rec = np.frombuffer(ev.tobytes(), dtype=np.dtype([("start", "<u8"), ("length", "<f4"), ("mean", "<f4"), ("stdv", "<f4"),
+                                                          ("pad", "<u4")]))
+        assert np.array_equal(rec["start"], exp.start) and np.array_equal(rec["length"], exp.length)
+        assert np.array_equal(rec["mean"].view(np.uint32), exp.mean.view(np.uint32))
+        assert np.array_equal(rec["stdv"].view(np.uint32), exp.stdv.view(np.uint32))
+        libc.free(t.event)
 
 
 @pytest.mark.parametrize("kind", [0, 1])
