@@ -50,7 +50,6 @@ static inline float perturbed_rcp32(float v) {
 }
 #define SGK_RCP32(v) perturbed_rcp32(v)
 #include "../sigtk_amd/csrc/tstat_math.h"
-#include "../tools/proto/event_r3/tstat_math_r3.h"   // round-3 experiment (not in the product): checks #10..#12
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -306,7 +305,7 @@ static uint64_t check_div_len(uint64_t count) {
 }
 
 
-// ---------------------------------------------------------------- round 3 ("robust decisions", tstat_math.h)
+// ---------------------------------------------------------------- round 3 (the one piece of it that is in the product)
 // 9. the A-side mean (sgk_arole<W, SHORT = true>): (float)(S * RN64(1/W)) == (float)(S / (double)W) for exact sums of W
 //    floats spanning <= 2^16
 template <int W>
@@ -329,227 +328,19 @@ static uint64_t check_mean1(uint64_t count) {
                 Sq += (double)(f * f);
             }
             const SgkARole a = sgk_arole<W, true>(S, Sq);   // the product's form (event_kernels.hip: LazyPass, fast path)
-            const SgkA3 a3 = sgk_a3<W>(S, Sq);               // the round-3 experiment's
             const float want = (float)(S / (double)(float)W);
-            if (f2u(a.mean1) != f2u(want) || f2u(a3.mean1) != f2u(want)) bad++;
+            if (f2u(a.mean1) != f2u(want)) bad++;
         }
     }
     return bad;
-}
-
-// 10. sgk_tq: W * tq within SGK_RHO (relative) of the reference float whenever cv_ok; reports the largest ratio seen
-template <int W>
-static uint64_t check_tq(uint64_t count, double *worst, double *notok) {
-    uint64_t bad = 0, nk = 0;
-    double wmax = 0.0;
-#pragma omp parallel for reduction(+ : bad, nk) reduction(max : wmax) schedule(static)
-    for (int64_t t = 0; t < 64; ++t) {
-        uint64_t s = 0x5EEDULL * (t + 9) + W;
-        g_pert_state = 2024 + t;
-        for (uint64_t k = 0; k < count / 64; ++k) {
-            double A, A2, B, B2;
-            make_windows<W>(s, k, A, A2, B, B2);
-            const float ref = sgk_tstat_ref<W>(A, A2, B, B2);
-            const SgkA3 a = sgk_a3<W>(A, A2);
-            bool ok;
-            const float tq = sgk_tq<W>((float)B, (float)B2, a, ok);
-            if (!ok) { nk++; continue; }
-            const double got = (double)tq * (double)W;
-            const double err = fabs(got - (double)ref);
-            if (ref == 0.0f) { if (tq != 0.0f) bad++; continue; }
-            const double rel = err / (double)ref;
-            if (!(rel <= (double)SGK_RHO)) bad++;
-            if (rel > wmax) wmax = rel;
-        }
-    }
-    *worst = wmax;
-    *notok = (double)nk / (double)count;
-    return bad;
-}
-
-// 11. sgk_cold2<2W> (long window from the float sums of its two short halves) true => reference statistic <= 9
-template <int W>
-static uint64_t check_cold2(uint64_t count, double *false_hot) {
-    constexpr int W2 = 2 * W;
-    uint64_t bad = 0, fh = 0, low = 0;
-#pragma omp parallel for reduction(+ : bad, fh, low) schedule(static)
-    for (int64_t t = 0; t < 64; ++t) {
-        uint64_t s = 0xC01DULL * (t + 7) + W;
-        const float unit = 1402.882324f / 8192.0f;
-        for (uint64_t k = 0; k < count / 64; ++k) {
-            // four short windows a0 a1 | b0 b1 with a level jump steered to put the long statistic near 9 now and then
-            const uint64_t r = rng_next(s);
-            const int base = 200 + (int)(r % 600), noise = 1 + (int)((r >> 40) % 12);
-            int jump = (int)((r >> 20) % 200) - 100;
-            if ((k & 3) == 1) jump = (int)((double)noise * (1.2 + (double)((r >> 50) % 400) * 0.01));
-            const float off = (float)((r >> 52) % 20) + (((r >> 57) & 1) ? 0.25f : 0.0f);
-            const float scale = ((k & 15) == 7) ? ldexpf(1.0f, (int)((r >> 58) % 30) - 15) : 1.0f;
-            double S[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 4 * W; ++j) {
-                const uint64_t q = rng_next(s);
-                int raw = base + (j >= 2 * W ? jump : 0) + (int)(q % (uint64_t)(2 * noise + 1)) - noise;
-                if ((k % 97) == 0) raw = base;
-                const float x = (((float)raw + off) * unit) * scale;
-                S[j / W] += (double)x;
-                Q[j / W] += (double)(x * x);
-            }
-            const float ref = sgk_tstat_ref<W2>(S[0] + S[1], Q[0] + Q[1], S[2] + S[3], Q[2] + Q[3]);
-            const SgkL2 la = sgk_l2<W2>((float)S[0], (float)S[1], (float)Q[0], (float)Q[1]);
-            const SgkL2 lb = sgk_l2<W2>((float)S[2], (float)S[3], (float)Q[2], (float)Q[3]);
-            const bool cold = sgk_cold2<W2>(la, lb);
-            if (cold && !(ref <= 9.0f)) bad++;
-            if (ref <= 8.0f) { low++; if (!cold) fh++; }
-        }
-    }
-    *false_hot = (double)fh / (double)(low ? low : 1);
-    return bad;
-}
-
-// 12. the short detector on tq with the uncertainty band + exact resolution (what FastPass::dstep does, one lane)
-//     against events.c:383-440 on the reference floats, over whole synthetic reads; the long detector runs exactly in
-//     both.  Returns the number of reads whose peak lists differ; reports the fraction of uncertain decisions.
-template <int W1>
-struct DetP;
-template <> struct DetP<3> { static constexpr float thr1 = 1.4f, thr2 = 9.0f, ph = 0.2f; };
-template <> struct DetP<7> { static constexpr float thr1 = 2.5f, thr2 = 9.0f, ph = 1.0f; };
-
-template <int W1>
-static uint64_t check_sequence(int n_reads, int n, int flavour, double *unc_frac, double *ncv_frac) {
-    constexpr int W2 = 2 * W1;
-    constexpr float ph = DetP<W1>::ph, thr1 = DetP<W1>::thr1, thr2 = DetP<W1>::thr2;
-    const float phs = ph / (float)W1, thrs = thr1 / (float)W1, rw = 1.0f / (float)W1;
-    uint64_t badreads = 0, unc = 0, ncv = 0, tot = 0;
-#pragma omp parallel for reduction(+ : badreads, unc, ncv, tot) schedule(dynamic)
-    for (int rd = 0; rd < n_reads; ++rd) {
-        uint64_t s = 0xFACEULL * (rd + 1) + W1 * 131 + flavour;
-        g_pert_state = 5150 + rd;
-        // signal: piecewise constant levels + noise, quantised like a BLOW5 read
-        float *x = (float *)malloc(sizeof(float) * n);
-        const float unit = 1402.882324f / 8192.0f;
-        const float off = (float)(rng_next(s) % 20) + ((flavour == 2) ? 0.375f : 0.0f);
-        const double noise_sd = (flavour == 1) ? 0.15 : (flavour == 3 ? 4.0 : 1.5);
-        const int dwell = (W1 == 7) ? 36 : 9;
-        double level = 90.0;
-        for (int i = 0; i < n; ++i) {
-            const uint64_t q = rng_next(s);
-            if (i == 0 || (q % (uint64_t)dwell) == 0) {
-                double g = 0; for (int z = 0; z < 12; ++z) g += (double)(rng_next(s) >> 11) / 9007199254740992.0; g -= 6.0;
-                level = 90.0 + 12.0 * g;
-            }
-            double g = 0; for (int z = 0; z < 12; ++z) g += (double)(rng_next(s) >> 11) / 9007199254740992.0; g -= 6.0;
-            double pa = level + noise_sd * g;
-            if (flavour == 1 && (i / 500) % 7 == 3) pa = level;   // exactly constant stretches
-            int raw = (int)lrint(pa / (double)unit - (double)off);
-            raw = raw < 0 ? 0 : (raw > 4000 ? 4000 : raw);
-            x[i] = ((float)raw + off) * unit;
-        }
-        double *P = (double *)malloc(sizeof(double) * (n + 1)), *Pq = (double *)malloc(sizeof(double) * (n + 1));
-        P[0] = Pq[0] = 0.0;
-        for (int i = 0; i < n; ++i) { P[i + 1] = P[i] + (double)x[i]; Pq[i + 1] = Pq[i] + (double)(x[i] * x[i]); }
-        auto T = [&](int i, int w) -> float {   // reference statistic (compute_tstat incl. its zero edges)
-            if (n < 2 * w || i < w || i > n - w) return 0.0f;
-            const double A = P[i] - P[i - w], A2 = Pq[i] - Pq[i - w], B = P[i + w] - P[i], B2 = Pq[i + w] - Pq[i];
-            if (w == 3) return sgk_tstat_ref<3>(A, A2, B, B2);
-            if (w == 6) return sgk_tstat_ref<6>(A, A2, B, B2);
-            if (w == 7) return sgk_tstat_ref<7>(A, A2, B, B2);
-            return sgk_tstat_ref<14>(A, A2, B, B2);
-        };
-        // ---- reference detector
-        int *pk_ref = (int *)malloc(sizeof(int) * n), n_ref = 0;
-        int *pk_new = (int *)malloc(sizeof(int) * n), n_new = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-            int *pk = pass ? pk_new : pk_ref; int &np = pass ? n_new : n_ref;
-            // short state
-            bool inpk = false, val = false, strong = false;
-            float sv = FLT_MAX; int sp = -1, svpos = -1;
-            // long state
-            int lmask = 0, lp = -1; float lv = FLT_MAX; bool lvalid = false;
-            for (int i = 0; i < n; ++i) {
-                // ---- short
-                if (i > 0) {
-                    bool Pm, Qm, Tt; bool em = false;
-                    if (pass == 0) {
-                        // events.c:383-440, k = 0, literally
-                        const float v = T(i, W1);
-                        if (sp < 0) {
-                            if (v < sv) sv = v;
-                            else if (v - sv > ph) { sv = v; sp = i; }
-                        } else {
-                            if (v > sv) { sv = v; sp = i; }
-                            if (sv > thr1) { lmask = sp + W1; lp = -1; lv = FLT_MAX; lvalid = false; }
-                            if (sv - v > ph && sv > thr1) val = true;
-                            if (val && (i - sp) > W1 / 2) { pk[np++] = sp; sp = -1; sv = v; val = false; }
-                        }
-                        (void)Pm; (void)Qm; (void)Tt; (void)em; (void)inpk; (void)strong; (void)svpos;
-                    } else {
-                        float v;
-                        bool cvok = true;
-                        if (n < 2 * W1 || i < W1 || i > n - W1) v = 0.0f;
-                        else {
-                            const SgkA3 a = sgk_a3<W1>(P[i] - P[i - W1], Pq[i] - Pq[i - W1]);
-                            v = sgk_tq<W1>((float)(P[i + W1] - P[i]), (float)(Pq[i + W1] - Pq[i]), a, cvok);
-                        }
-                        float ee = inpk ? v - sv : sv - v;
-                        Pm = ee > 0.0f; Qm = ee < -phs; Tt = v > thrs;
-                        const float a2 = ee + phs, a3 = v - thrs, m = sgk_band(v, phs);
-                        const float umin = fminf(fminf(fabsf(ee), fabsf(a2)), fabsf(a3));
-                        const bool uncertain = !(umin > m) || !cvok;
-                        tot++;
-                        if (!cvok) ncv++;
-                        if (uncertain) {
-                            unc++;
-                            const float Ti = T(i, W1);
-                            const float Ts = (svpos < 0) ? FLT_MAX : T(svpos, W1);
-                            const float ex = inpk ? Ti - Ts : Ts - Ti;
-                            Pm = ex > 0.0f; Qm = ex < -ph; Tt = Ti > thr1;
-                            v = Ti * rw;
-                            sv = (svpos < 0) ? FLT_MAX : Ts * rw;
-                        }
-                        const bool ent = Qm && !inpk;
-                        const bool pos = (inpk && Pm) || ent;
-                        if (pos) strong = Tt;
-                        const bool dom = inpk && strong;
-                        val = inpk && (val || (Qm && strong));
-                        em = val && !Pm && (i - sp) > W1 / 2;
-                        if (Pm || ent || em) { sv = v; svpos = i; }
-                        if (pos) sp = i;
-                        if (dom) { lmask = sp + W1; lp = -1; lv = FLT_MAX; lvalid = false; }
-                        if (em) { pk[np++] = sp; }
-                        inpk = (inpk && !em) || ent; if (em) val = false;
-                    }
-                }
-                // ---- long (exact in both passes)
-                if (!(lmask >= i)) {
-                    const float v2 = T(i, W2);
-                    if (lp < 0) {
-                        if (v2 < lv) lv = v2;
-                        else if (v2 - lv > ph) { lv = v2; lp = i; }
-                    } else {
-                        if (v2 > lv) { lv = v2; lp = i; }
-                        if (lv - v2 > ph && lv > thr2) lvalid = true;
-                        if (lvalid && (i - lp) > W2 / 2) { pk[np++] = lp; lp = -1; lv = v2; lvalid = false; }
-                    }
-                }
-            }
-        }
-        bool same = n_ref == n_new;
-        for (int k = 0; same && k < n_ref; ++k) same = pk_ref[k] == pk_new[k];
-        if (!same) badreads++;
-        free(pk_new); free(pk_ref); free(Pq); free(P); free(x);
-    }
-    *unc_frac = (double)unc / (double)(tot ? tot : 1);
-    *ncv_frac = (double)ncv / (double)(tot ? tot : 1);
-    return badreads;
 }
 
 int main(int argc, char **argv) {
-    const bool r3 = argc > 1 && strcmp(argv[1], "r3") == 0;   // only the round-3 checks, at 1/4 of the full counts
     const bool quick = argc > 1 && strcmp(argv[1], "quick") == 0;
     const uint32_t step = quick ? 257 : 1;
-    const uint64_t n64 = quick ? 4000000ULL : (r3 ? 250000000ULL : 1000000000ULL);
+    const uint64_t n64 = quick ? 4000000ULL : 1000000000ULL;
     uint64_t bad = 0, b;
     double uf;
-    if (!r3) {
     b = check_div32<3>(step);  printf("div_f32<3>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div32<6>(step);  printf("div_f32<6>   mismatches: %llu\n", (unsigned long long)b); bad += b;
     b = check_div32<7>(step);  printf("div_f32<7>   mismatches: %llu\n", (unsigned long long)b); bad += b;
@@ -571,25 +362,11 @@ int main(int argc, char **argv) {
     b = check_long_cold<6>(n64 / 4, &uf);  printf("long_cold<6>  violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
     b = check_long_cold<14>(n64 / 4, &uf); printf("long_cold<14> violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
     b = check_div_len(n64);            printf("div_with_rcp (event length) mismatches: %llu\n", (unsigned long long)b); bad += b;
-    }
-    // ---- round 3
-    b = check_mean1<3>(n64);  printf("a3 mean1<3>  mismatches: %llu\n", (unsigned long long)b); bad += b;
-    b = check_mean1<6>(n64);  printf("a3 mean1<6>  mismatches: %llu\n", (unsigned long long)b); bad += b;
-    b = check_mean1<7>(n64);  printf("a3 mean1<7>  mismatches: %llu\n", (unsigned long long)b); bad += b;
-    b = check_mean1<14>(n64); printf("a3 mean1<14> mismatches: %llu\n", (unsigned long long)b); bad += b;
-    double wr, nk;
-    b = check_tq<3>(n64 / 4, &wr, &nk); printf("tq<3>  outside rho: %llu (worst relative error %.3g = 2^%.2f, rho 2^-20; cv not ok %.3g)\n", (unsigned long long)b, wr, log2(wr), nk); bad += b;
-    b = check_tq<7>(n64 / 4, &wr, &nk); printf("tq<7>  outside rho: %llu (worst relative error %.3g = 2^%.2f; cv not ok %.3g)\n", (unsigned long long)b, wr, log2(wr), nk); bad += b;
-    b = check_cold2<3>(n64 / 4, &uf); printf("cold2<6>   violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
-    b = check_cold2<7>(n64 / 4, &uf); printf("cold2<14>  violations: %llu (hot although ref <= 8: %.3g)\n", (unsigned long long)b, uf); bad += b;
-    {
-        const int nr = quick ? 64 : 2000, nn = quick ? 20000 : 100000;
-        for (int fl = 0; fl < 4; ++fl) {
-            double ufr, ncv;
-            b = check_sequence<3>(nr, nn, fl, &ufr, &ncv); printf("sequence<3> flavour %d: reads with different peaks %llu of %d (uncertain %.3g, cv not ok %.3g)\n", fl, (unsigned long long)b, nr, ufr, ncv); bad += b;
-            b = check_sequence<7>(nr, nn, fl, &ufr, &ncv); printf("sequence<7> flavour %d: reads with different peaks %llu of %d (uncertain %.3g, cv not ok %.3g)\n", fl, (unsigned long long)b, nr, ufr, ncv); bad += b;
-        }
-    }
+    // the A side's mean by one multiply (sgk_arole<W, SHORT>, round 3)
+    b = check_mean1<3>(n64);  printf("arole mean1<3>  mismatches: %llu\n", (unsigned long long)b); bad += b;
+    b = check_mean1<6>(n64);  printf("arole mean1<6>  mismatches: %llu\n", (unsigned long long)b); bad += b;
+    b = check_mean1<7>(n64);  printf("arole mean1<7>  mismatches: %llu\n", (unsigned long long)b); bad += b;
+    b = check_mean1<14>(n64); printf("arole mean1<14> mismatches: %llu\n", (unsigned long long)b); bad += b;
     printf("%s\n", bad ? "FAILED" : "ALL EXACT");
     return bad ? 1 : 0;
 }
