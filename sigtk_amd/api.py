@@ -76,7 +76,7 @@ def _env_int(name, default=0):
 #: SGK_LANE_PER_READ (1 / 0 = one read per lane / per wavefront).  Tests set them with event_configure() & co.
 EVENT_OPTIONS = EventOptions(_env_int("SGK_EVENT_SEG"), _env_int("SGK_EVENT_LONG_MIN"), _env_int("SGK_EVENT_LEAD"),
                              _env_int("SGK_EVENT_MULTI"), _env_int("SGK_EVENT_MULTI_MAX"),
-                             -1 if os.environ.get("SGK_EVENT_TAIL", "1") == "0" else 0)
+                             {"0": -1, "1": 0}.get(os.environ.get("SGK_EVENT_TAIL", "1"), _env_int("SGK_EVENT_TAIL")))
 STAT_OPTIONS = StatOptions({"1": 1, "0": 2}.get(os.environ.get("SGK_LANE_PER_READ", ""), 0))
 
 

@@ -80,7 +80,7 @@ EvSegConfig event_config(const sgk_event_options_t *o) {
         while (p2 < (1u << 30) && (uint64_t)p2 * 2 <= o->short_max) p2 *= 2;
         c.multi_max = p2;
     }
-    c.tail_split = o->tail_split < 0 ? -1 : 0;
+    c.tail_split = o->tail_split < 0 ? -1 : o->tail_split;   // (> 0: that many reads are cut, whatever the batch)
     return c;
 }
 
@@ -113,9 +113,10 @@ void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples
     if (n_reads == 0 || packed || sc.tail_split < 0) return;
     const uint32_t slots = event_wave_slots(rna);
     const uint64_t mean = n_samples / n_reads;
-    if (mean < 32768 || n_reads >= 8ull * slots) return;
-    const uint32_t rem = n_reads % slots;
-    if (rem == 0 || rem > slots - slots / 8) return;
+    if (mean < 32768 || (sc.tail_split == 0 && n_reads >= 8ull * slots)) return;
+    uint32_t rem = n_reads % slots;
+    if (sc.tail_split > 0) rem = (uint32_t)sc.tail_split < n_reads ? (uint32_t)sc.tail_split : n_reads;   // the caller's number
+    else if (rem == 0 || rem > slots - slots / 8) return;
     // (the number of segments per read hardly matters: 2 .. 16 per read, one or two rounds of them: 3.77 - 3.89 ms)
     uint32_t G = (slots - slots / 16 + rem - 1) / rem;   // units of the split reads ~ one round
     if (G < 2) G = 2;

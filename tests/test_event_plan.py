@@ -103,6 +103,8 @@ def test_tail_split(lib):
     assert plan(lib, [100000] * 9000, rna=1)[0].tail_segment_len > 0
     assert plan(lib, [20000] * 10000)[0].tail_segment_len == 0              # short reads: not worth two kernels more
     assert plan(lib, [100000] * 10000, opt=opts(tail_split=-1))[0].tail_segment_len == 0
+    p = plan(lib, [100000] * 30000, opt=opts(tail_split=2000))[0]      # the caller's number, whatever the batch
+    assert (p.tail_split_from, p.tail_segment_len) == (28000, 50176)
     # the workspace has room for the lists
     from sigtk_amd import api
     lib.sgk_event_workspace_bytes_opt.restype = C.c_size_t
