@@ -57,6 +57,10 @@ def main():
                          "size is split over the ranks in contiguous ranges balanced by cumulative samples")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / MAX-reduce "
                     "(nccl = RCCL; 'gloo' lets several ranks share one GPU for testing)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="(config 2; NOT the contract line) batches in flight: step i runs on stream i %% N with output "
+                         "arena i %% N, as the CLI's jobs do -- the next batch's first waves fill the slots the last "
+                         "waves of this one leave empty.  The default, 1, is what the driver measures.")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.reads:
@@ -110,7 +114,21 @@ def main():
     arena = device.EventArena(batch) if args.config in (2, 3, 5) else None
     pa_out = torch.empty(batch.n_samples, dtype=torch.float32, device=dev) if args.config in (4, 5) else None
 
+    inflight = max(1, args.inflight) if args.config == 2 else 1
+    lanes = [(torch.cuda.Stream(device=dev), device.EventArena(batch)) for _ in range(inflight - 1)]
+    step_no = [0]
+
     def step():
+        if args.config == 2 and inflight > 1:
+            k = step_no[0] % inflight
+            step_no[0] += 1
+            if k == 0:
+                device.event(batch, arena, rna)
+            else:
+                st_k, ar_k = lanes[k - 1]
+                with torch.cuda.stream(st_k):
+                    device.event(batch, ar_k, rna)
+            return
         if args.config == 2:
             device.event(batch, arena, rna)
         elif args.config == 3:
@@ -236,6 +254,7 @@ def main():
                        "long_detector_replays": int(st.n_long_replays) if st is not None else None,
                        "long_detector_replay_indices": int(st.n_replay_indices) if st is not None else None,
                        "split_reads": int(st.n_split_reads) if st is not None else None,
+                       "batches_in_flight": inflight,
                        "parallelism": "reads sharded across ranks, no collective"},
             "parity_spot_check": parity,
             "roofline": roofline,
