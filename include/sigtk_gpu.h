@@ -249,7 +249,10 @@ int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *ou
  * 1 one read per lane, 2 one read per wavefront.  Results do not depend on it (the tests compare the two bit for bit). */
 typedef struct sgk_stat_options {
     int32_t kernels;
-    uint32_t reserved[3];
+    int32_t long_min;   /* reads of at least this many samples get a workgroup of 16 wavefronts for their sequential
+                         * float sums before the wave-per-read kernel runs: 0 = 262 144, -1 = never, else >= 8 192.
+                         * Needs the workspace sgk_*_workspace_bytes asks for (with less, such reads run on one wave). */
+    uint32_t reserved[2];
 } sgk_stat_options_t;
 int sgk_stat_opt(const sgk_batch_t *batch, sgk_stat_rec_t *out, void *workspace, size_t workspace_bytes, void *stream,
                  const sgk_stat_options_t *opt);
@@ -259,6 +262,14 @@ int sgk_jnn_opt(const sgk_batch_t *batch, int rna, const uint64_t *seg_slots, in
                 uint32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
 int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
                    size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
+/* What the long-read path of the last stat / jnn / prefix call on `workspace` did (copied from the device: call it when
+ * the stream has drained).  A long read's sequential float sums (src/stat.h:17-54, src/jnn.c:106-124, 195-199) are
+ * composed from per-tile summaries; n_true_tiles of the n_tiles tile sums had to be evaluated from the true accumulator
+ * instead (binade crossings, mispredicted binades).  All zero when the call had no long read or no room for them. */
+typedef struct sgk_long_status {
+    uint32_t n_long_reads, n_tiles, n_true_tiles, reserved;
+} sgk_long_status_t;
+int sgk_stat_long_status(const void *workspace, size_t workspace_bytes, uint32_t n_reads, sgk_long_status_t *out);
 
 /* ---- ent: the histograms behind `sigtk ent` (src/ent.c) ----------------- */
 /* The counting runs on the GPU, the sum of -p*log2(p) over the (few thousand) non-empty bins on the host

@@ -60,7 +60,12 @@ class EventOptions(C.Structure):   # sgk_event_options_t (all zero = the default
 
 
 class StatOptions(C.Structure):   # sgk_stat_options_t
-    _fields_ = [("kernels", C.c_int32), ("reserved", C.c_uint32 * 3)]
+    _fields_ = [("kernels", C.c_int32), ("long_min", C.c_int32), ("reserved", C.c_uint32 * 2)]
+
+
+class LongStatus(C.Structure):    # sgk_long_status_t
+    _fields_ = [("n_long_reads", C.c_uint32), ("n_tiles", C.c_uint32), ("n_true_tiles", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 def _env_int(name, default=0):
@@ -73,11 +78,12 @@ def _env_int(name, default=0):
 #: The options every wrapper of this module (and sigtk_amd.device) passes with its calls.  The library itself keeps no
 #: configuration and reads no environment variable; the development / A-B switches live here, in the bindings:
 #: SGK_EVENT_SEG, SGK_EVENT_LONG_MIN, SGK_EVENT_LEAD, SGK_EVENT_MULTI, SGK_EVENT_MULTI_MAX, SGK_EVENT_TAIL (0 = off),
-#: SGK_LANE_PER_READ (1 / 0 = one read per lane / per wavefront).  Tests set them with event_configure() & co.
+#: SGK_LANE_PER_READ (1 / 0 = one read per lane / per wavefront), SGK_STAT_LONG_MIN (-1 = no long-read path).  Tests
+#: set them with event_configure() & co.
 EVENT_OPTIONS = EventOptions(_env_int("SGK_EVENT_SEG"), _env_int("SGK_EVENT_LONG_MIN"), _env_int("SGK_EVENT_LEAD"),
                              _env_int("SGK_EVENT_MULTI"), _env_int("SGK_EVENT_MULTI_MAX"),
                              {"0": -1, "1": 0}.get(os.environ.get("SGK_EVENT_TAIL", "1"), _env_int("SGK_EVENT_TAIL")))
-STAT_OPTIONS = StatOptions({"1": 1, "0": 2}.get(os.environ.get("SGK_LANE_PER_READ", ""), 0))
+STAT_OPTIONS = StatOptions({"1": 1, "0": 2}.get(os.environ.get("SGK_LANE_PER_READ", ""), 0), _env_int("SGK_STAT_LONG_MIN"))
 
 
 def event_configure(segment_len: int = 0, long_min: int = 0, warmup: int = 0) -> None:
@@ -93,9 +99,10 @@ def event_configure_tail(on: bool = True) -> None:
     EVENT_OPTIONS.tail_split = 0 if on else -1
 
 
-def stat_configure(kernels: int = 0) -> None:
-    """0: chosen per batch, 1: one read per lane (round-1 kernels), 2: one read per wavefront"""
-    STAT_OPTIONS.kernels = int(kernels)
+def stat_configure(kernels: int = 0, long_min: int = 0) -> None:
+    """kernels 0: chosen per batch, 1: one read per lane (round-1 kernels), 2: one read per wavefront; long_min: reads of
+    at least that many samples take the 16-wavefront sums (0 = 262 144, -1 = never)"""
+    STAT_OPTIONS.kernels, STAT_OPTIONS.long_min = int(kernels), int(long_min)
 
 
 def event_plan(n_reads: int, n_samples: int, max_read_len: int, rna: int, opt: "EventOptions" = None) -> EventPlan:
@@ -155,7 +162,7 @@ ABI_SYMBOLS = [
     "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan",
     "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
-    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
     "sgk_stat_host_opt", "sgk_jnn_host_opt", "sgk_prefix_host_opt", "sgk_job_set_options", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
     "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
@@ -223,6 +230,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_prefix.argtypes = [C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     for f in ("sgk_stat", "sgk_stat_pa", "sgk_jnn", "sgk_prefix"):
         getattr(L, f + "_opt").argtypes = getattr(L, f).argtypes + [OS]
+    L.sgk_stat_long_status.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(LongStatus)]
     L.sgk_svbzd_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
     L.sgk_synth_reads.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,

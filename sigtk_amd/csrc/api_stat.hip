@@ -21,9 +21,11 @@ extern "C" {
 
 // 64 bytes of counters + room for the longest-first dispatch order (a smaller workspace, down to 64 bytes -- none for
 // stat / prefix -- is accepted: the kernels then take the reads in batch order)
-size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
-size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
-size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return order_workspace_bytes(n_reads); }
+// ... and the records of the batch's long reads (k_long_chains; without that room long reads run on one wavefront)
+static size_t stat_ws(uint32_t n_reads) { return order_workspace_bytes(n_reads) + long_workspace_bytes(); }
+size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
+size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
+size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
 
 int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream,
                  const sgk_stat_options_t *opt) {
@@ -35,6 +37,7 @@ int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_
     a.kernels = opt ? opt->kernels : 0;
     a.stat = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -54,6 +57,7 @@ int sgk_stat_pa_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, vo
     a.stat = out;
     a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -76,6 +80,7 @@ int sgk_jnn_opt(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_
     a.n_segs = n_segs;
     a.err_count = static_cast<uint32_t *>(ws);
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
@@ -94,12 +99,26 @@ int sgk_prefix_opt(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *ou
     a.kernels = opt ? opt->kernels : 0;
     a.prefix = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
 }
 
 int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
                void *stream) {
     return sgk_prefix_opt(b, rna, pore, out, ws, ws_bytes, stream, nullptr);
+}
+
+int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_long_status_t *out) {
+    if (!out) return SGK_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    const size_t off = order_workspace_bytes(n_reads);
+    if (!ws || ws_bytes < off + long_workspace_bytes()) return SGK_OK;
+    LongHdr h;
+    SGK_HIP_TRY(hipMemcpy(&h, static_cast<const char *>(ws) + off, sizeof h, hipMemcpyDeviceToHost));
+    out->n_long_reads = h.n_long;
+    out->n_tiles = h.n_tiles;
+    out->n_true_tiles = h.n_true;
+    return SGK_OK;
 }
 
 // ---------------------------------------------------------------- host layer
@@ -111,9 +130,10 @@ int sgk_stat_host_opt(const sgk_host_batch_t *hb, sgk_stat_rec_t *out, const sgk
     const size_t nr = hb->n_reads;
     if (nr == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
-    DevBuf d_out;
+    DevBuf d_out, d_ws;
     if ((rc = d_out.alloc(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
-    if ((rc = sgk_stat_opt(&db.view, d_out.as<sgk_stat_rec_t>(), nullptr, 0, nullptr, opt)) != SGK_OK) return rc;
+    if ((rc = d_ws.alloc(stat_ws(hb->n_reads))) != SGK_OK) return rc;
+    if ((rc = sgk_stat_opt(&db.view, d_out.as<sgk_stat_rec_t>(), d_ws.p, stat_ws(hb->n_reads), nullptr, opt)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_stat_rec_t), hipMemcpyDeviceToHost));
     return SGK_OK;
@@ -129,9 +149,11 @@ int sgk_prefix_host_opt(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefi
     const size_t nr = hb->n_reads;
     if (nr == 0) return SGK_OK;
     if (!out) return SGK_ERR_ARG;
-    DevBuf d_out;
+    DevBuf d_out, d_ws;
     if ((rc = d_out.alloc(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
-    if ((rc = sgk_prefix_opt(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), nullptr, 0, nullptr, opt)) != SGK_OK)
+    if ((rc = d_ws.alloc(stat_ws(hb->n_reads))) != SGK_OK) return rc;
+    if ((rc = sgk_prefix_opt(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), d_ws.p, stat_ws(hb->n_reads), nullptr,
+                             opt)) != SGK_OK)
         return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_prefix_rec_t), hipMemcpyDeviceToHost));
@@ -160,10 +182,10 @@ int sgk_jnn_host_opt(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out, 
     if ((rc = d_x.alloc(nslots * 4)) != SGK_OK) return rc;
     if ((rc = d_y.alloc(nslots * 4)) != SGK_OK) return rc;
     if ((rc = d_n.alloc((size_t)nr * 4)) != SGK_OK) return rc;
-    if ((rc = d_ws.alloc(64)) != SGK_OK) return rc;
+    if ((rc = d_ws.alloc(stat_ws(nr))) != SGK_OK) return rc;
     SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     rc = sgk_jnn_opt(&db.view, rna, d_slots.as<uint64_t>(), d_x.as<int32_t>(), d_y.as<int32_t>(), d_n.as<uint32_t>(),
-                     d_ws.p, 64, nullptr, opt);
+                     d_ws.p, stat_ws(nr), nullptr, opt);
     if (rc != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     uint32_t nerr = 0;

@@ -18,8 +18,38 @@ struct StatArgs {
     const uint32_t *order;       // wave-per-read kernels: wave i takes read order[i] (longest reads first), or null
     uint32_t jnn_redo;           // k_jnn: 1 = only the reads k_jnn_wave gave up on (n_segs[r] == JNN_REDO_MARK)
     int kernels;                 // sgk_stat_options_t::kernels: 0 chosen per batch, 1 read per lane, 2 read per wavefront
+    // long reads (k_long_chains): null / 0 when the batch has none or the workspace no room for them
+    struct LongHdr *long_hdr;
+    uint32_t *long_list;         // LC_CAP read indices
+    struct LongSums *longs;      // LC_CAP records, entry i belongs to read long_list[i]
+    uint32_t long_min;           // reads of at least this many samples are long
 };
 constexpr uint32_t JNN_REDO_MARK = 0xffffffffu;
+
+// ---- long reads (round 4): the sequential float sums of a read of long_min samples or more are evaluated by a
+// workgroup of 16 wavefronts BEFORE the wave-per-read kernel runs (k_long_chains); that kernel then finds the sums here
+// and walks the read only for what is cheap per sample (histogram, pA output, automaton, run finder).
+struct LongHdr {
+    uint32_t n_long;     // long reads found (k_long_list; entries beyond LC_CAP have no record)
+    uint32_t n_tiles;    // tiles summarised (per chain)
+    uint32_t n_true;     // ... of which the composition had to evaluate from the true accumulator
+    uint32_t pad[13];
+};
+struct LongSums {
+    uint32_t read;
+    uint32_t valid;      // 1: s1 / s2 are final
+    float s1[2];         // first-stage sums (stat: raw, pA; jnn: clamped raw; prefix: rolling means), signed
+    float s2[2];         // second-stage sums (squared deviations from the first stage's means)
+    uint32_t pad[2];
+};
+static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64, "long-read workspace layout");
+constexpr uint32_t LC_CAP = 1024;             // long reads per batch that get a record (the rest run as before)
+constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
+constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for
+size_t long_workspace_bytes();
+// fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
+// clears the header and lists the long reads
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st);
 
 // workspace layout of stat / jnn / prefix: [0, 64) counters (jnn: overflow count), then the dispatch order of the
 // wave-per-read kernels (n_reads x 4 bytes) and the 2 x 128 words of its counting sort

@@ -67,6 +67,21 @@ __device__ inline Region get_region(int mode, const sgk_batch_t &b, const sgk_pr
     return g;
 }
 
+// the record k_long_chains left for read r (wave-uniform; null: the wave evaluates the read's sums itself)
+__device__ inline const LongSums *find_long(const StatArgs &a, uint32_t r, int64_t len) {
+    if (!a.longs || len < (int64_t)a.long_min) return nullptr;
+    const uint32_t nl = a.long_hdr->n_long, n = nl < LC_CAP ? nl : LC_CAP;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane_id();
+        const unsigned long long hit = __ballot(i < n && a.long_list[i] == r);
+        if (hit) {
+            const LongSums *ls = a.longs + i0 + (uint32_t)(__ffsll((long long)hit) - 1);
+            return ls->valid ? ls : nullptr;
+        }
+    }
+    return nullptr;
+}
+
 __device__ inline float clampf_raw(int16_t v) {  // rm_outlier, src/jnn.c:61-77
     return v > 1200 ? 1200.0f : (v < 0 ? 0.0f : (float)v);
 }
@@ -562,6 +577,9 @@ struct TermDevPa {   // (pA - mean)^2, src/stat.h:36-44
     }
 };
 
+// the signed value of an oriented accumulator (a zero accumulator stands for +0)
+__device__ __forceinline__ float ss_signed(float m, bool negated) { return m == 0.0f ? 0.0f : (negated ? -m : m); }
+
 // one tile of two chains: both walks are issued before either chain's (branching) bookkeeping.  mka / mkb build the
 // chains' term functors from a TermBase<INTERIOR>.
 template <bool NEG, typename MA, typename MB>
@@ -609,6 +627,8 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     WaveRead wr;
     wr.init(a.b, g);
     const float nf = (float)(int)g.len;
+    // a long read's four sums were evaluated by k_long_chains: this wave walks the read for the rest
+    const LongSums *lg = MODE == REG_WHOLE ? find_long(a, r, g.len) : nullptr;
 #ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
     SsCount counts[4] = {};
 #define SS_CNT(i) (&counts[i])
@@ -622,7 +642,7 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     // walk's sign test on every tile and be added term by term)
     float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
     int sraw = 0;
-    {
+    if (PA || !lg) {
         WaveTile cur, nxt;
         if (wr.ntiles > 0) wr.load(cur, 0);
         float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
@@ -655,18 +675,20 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
                     }
                 }
             }
-            ss_tile2<true>(
-                m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
-                [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
-            if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
-            if (m_raw < 0.0f) { m_raw = -m_raw; sraw = ~sraw; }
+            if (!lg) {
+                ss_tile2<true>(
+                    m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
+                    [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
+                if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
+                if (m_raw < 0.0f) { m_raw = -m_raw; sraw = ~sraw; }
+            }
             cur = nxt;
         }
     }
     // (a zero accumulator stands for +0: the reference's sum starts at +0 and x + (-x), +0 + -0 are +0 under
     // round-to-nearest, whichever way the chain was oriented)
-    const float mraw = (m_raw == 0.0f ? 0.0f : (sraw ? -m_raw : m_raw)) / nf;
-    const float mpa = (m_pa == 0.0f ? 0.0f : m_pa * sg) / nf;
+    const float mraw = (lg ? lg->s1[0] : ss_signed(m_raw, sraw != 0)) / nf;
+    const float mpa = (lg ? lg->s1[1] : ss_signed(m_pa, sg < 0.0f)) / nf;
 
     // ---- pass 2: squared deviations, window histogram, pA
     const int64_t k = g.len / 2;
@@ -698,12 +720,14 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
             };
             if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
             else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
-            ss_tile2<false>(
-                q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
-                [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));
+            if (!lg)
+                ss_tile2<false>(
+                    q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
+                    [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));
             cur = nxt;
         }
     }
+    if (lg) { q_raw = lg->s2[0]; q_pa = lg->s2[1]; }
     const float sdraw = sqrtf(q_raw / nf), sdpa = sqrtf(q_pa / nf);
 
     // ---- the order statistics of ranks k (raw median) and, for a negative unit, n-1-k (the pA median's raw value)
@@ -1106,7 +1130,9 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
         const float nf = (float)(int)n;
         float s = 0.0f, q = 0.0f;
-        {
+        const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains
+        if (lg) s = lg->s1[0];
+        else {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1116,7 +1142,8 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
             }
         }
         const float mn = s / nf;
-        {
+        if (lg) q = lg->s2[0];
+        else {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1756,6 +1783,57 @@ __device__ __forceinline__ void roll_tile(const WaveTile &trail, const WaveTile 
     T0 += wave_last_i(incl);
 }
 
+// total of the ADW clamped samples that start at tile-local position lo0 (< SS_TILE) of tile t: the rolling total of
+// the window that starts there (tiles t and t + 1 hold all of it)
+__device__ __forceinline__ int window_total(const WaveRead &wr, int t, int lo0) {
+    const int q0 = lane_id() * SS_SPL;
+    int part = 0;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        WaveTile w;
+        wr.load(w, t + tt);
+        const int lo = lo0 - tt * SS_TILE, hi = lo0 + ADW - tt * SS_TILE;
+#pragma unroll
+        for (int k = 0; k < SS_SPL / 2; ++k) {
+            const s16x2 c = clamp_raw2(w.w[k]);
+            part += (q0 + 2 * k >= lo && q0 + 2 * k < hi) ? (int)c.x : 0;
+            part += (q0 + 2 * k + 1 >= lo && q0 + 2 * k + 1 < hi) ? (int)c.y : 0;
+        }
+    }
+    return wave_last_i(wave_incl_scan_i(part));
+}
+// the trailing and the leading tile of window tile t
+__device__ __forceinline__ void roll_load(const WaveRead &wr, WaveTile &x, WaveTile &y, int t) {
+    const int64_t tile0 = wr.rb + (int64_t)t * SS_TILE;
+    wt_load(x, wr.samples, wr.n_total, tile0);
+    wt_load(y, wr.samples, wr.n_total, tile0 + ADW);
+}
+// one tile of a chain over the terms term(rolling total)
+template <typename TERM>
+__device__ __forceinline__ void roll_chain_tile(float &acc, const WaveRead &wr, int t, const int (&tot)[SS_SPL], TERM term) {
+    const int q0 = lane_id() * SS_SPL;
+    int q_lo, q_hi;
+    float x[SS_SPL];
+    if (t == 0) {  // head, natively
+        wr.range(0, 0, q_lo, q_hi);
+        const int qh = q_lo + wr.head();
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < qh) ? term(tot[e]) : 0.0f;
+        if (qh > q_lo) acc = ss_serial(acc, TermArr{x}, q_lo / SS_SPL, (qh - 1) / SS_SPL);
+    }
+    wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
+    if (wr.interior(t)) {
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) x[e] = term(tot[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
+    }
+    const SsWalk w = ss_walk<false>(acc, TermArr{x});
+    int sk;
+    if (ss_fast<false>(acc, w, TermArr{x}, sk)) acc = ss_finish<false>(acc, TermArr{x}, w, sk);
+}
+
 __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;
@@ -1781,33 +1859,13 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     const int q0 = lane * SS_SPL;
 
     // total of the first window: clamped samples 0 .. 1999 (tile-local positions skip .. skip + 1999 of tiles 0 and 1)
-    int first_total = 0;
-    {
-        int part = 0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            WaveTile w;
-            wr.load(w, t);
-            const int lo = wr.skip - t * SS_TILE, hi = wr.skip + ADW - t * SS_TILE;
-#pragma unroll
-            for (int k = 0; k < SS_SPL / 2; ++k) {
-                const s16x2 c = clamp_raw2(w.w[k]);
-                part += (q0 + 2 * k >= lo && q0 + 2 * k < hi) ? (int)c.x : 0;
-                part += (q0 + 2 * k + 1 >= lo && q0 + 2 * k + 1 < hi) ? (int)c.y : 0;
-            }
-        }
-        first_total = wave_last_i(wave_incl_scan_i(part));
-    }
+    const int first_total = window_total(wr, 0, wr.skip);
 
     // one sweep over the rolling totals: f(t, tot, q_lo, q_hi) per tile; returns early when f says so
     auto sweep = [&](auto f) {
         int T0 = first_total;
         WaveTile tr, ld, trn, ldn;
-        auto load2 = [&](WaveTile &x, WaveTile &y, int t) {
-            const int64_t tile0 = wr.rb + (int64_t)t * SS_TILE;
-            wt_load(x, wr.samples, wr.n_total, tile0);
-            wt_load(y, wr.samples, wr.n_total, tile0 + ADW);
-        };
+        auto load2 = [&](WaveTile &x, WaveTile &y, int t) { roll_load(wr, x, y, t); };
         load2(tr, ld, 0);
         for (int t = 0; t < wr.ntiles; ++t) {
             if (t + 1 < wr.ntiles) load2(trn, ldn, t + 1);
@@ -1818,42 +1876,25 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
             tr = trn; ld = ldn;
         }
     };
-    // one tile of a chain over terms term(tot)
-    auto chain_tile = [&](float &acc, int t, const int (&tot)[SS_SPL], auto term) {
-        int q_lo, q_hi;
-        float x[SS_SPL];
-        if (t == 0) {  // head, natively
-            wr.range(0, 0, q_lo, q_hi);
-            const int qh = q_lo + wr.head();
-#pragma unroll
-            for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < qh) ? term(tot[e]) : 0.0f;
-            if (qh > q_lo) acc = ss_serial(acc, TermArr{x}, q_lo / SS_SPL, (qh - 1) / SS_SPL);
-        }
-        wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
-        if (wr.interior(t)) {
-#pragma unroll
-            for (int e = 0; e < SS_SPL; ++e) x[e] = term(tot[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
-        }
-        const SsWalk w = ss_walk<false>(acc, TermArr{x});
-        int sk;
-        if (ss_fast<false>(acc, w, TermArr{x}, sk)) acc = ss_finish<false>(acc, TermArr{x}, w, sk);
-    };
+    auto chain_tile = [&](float &acc, int t, const int (&tot)[SS_SPL], auto term) { roll_chain_tile(acc, wr, t, tot, term); };
 
     const float mf = (float)(int)m;
+    const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains
     float s = 0.0f;
-    sweep([&](int t, const int (&tot)[SS_SPL]) {
-        chain_tile(s, t, tot, [](int v) { return roll_mean(v); });
-        return false;
-    });
+    if (lg) s = lg->s1[0];
+    else
+        sweep([&](int t, const int (&tot)[SS_SPL]) {
+            chain_tile(s, t, tot, [](int v) { return roll_mean(v); });
+            return false;
+        });
     const float mn = s / mf;
     float q = 0.0f;
-    sweep([&](int t, const int (&tot)[SS_SPL]) {
-        chain_tile(q, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
-        return false;
-    });
+    if (lg) q = lg->s2[0];
+    else
+        sweep([&](int t, const int (&tot)[SS_SPL]) {
+            chain_tile(q, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
+            return false;
+        });
     const float sd = sqrtf(q / mf);
     const float bot = mn - sd * ap.std_scale;
     const int t_lt = roll_threshold(bot, false), t_gt = roll_threshold(bot, true);
@@ -1907,6 +1948,415 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     }
 }
 
+// ---------------------------------------------------------------- long reads: the sequential sums on 16 wavefronts
+// A wave evaluates a sequential float sum at ~1 000 terms per microsecond; a read of 3 000 000 samples keeps its wave
+// busy for milliseconds per sum while the rest of the batch is long done.  k_long_chains gives such a read a workgroup
+// of 16 wavefronts.  What seqsum.h does with the 16 terms of a lane is done here once more with the 1 024 terms of a
+// TILE (tools/proto/seqsum_segments_proto.py is the model):
+//
+//   level 1, all waves, no dependency between them: a wave owns a contiguous run of tiles.  It PREDICTS the accumulator
+//     in front of each tile (the true accumulator at the start of the round + sums of the terms in front, pass A below,
+//     then tile by tile from its own summaries), takes the binade E of the prediction, and summarises the tile for that
+//     binade: T0 / T1, the increment of the accumulator's significand over the tile's 1 024 terms when it enters the
+//     tile even / odd (lanes' surrogate walks, parity maps composed across the lanes, once per entering parity).
+//     8 bytes per tile and chain in LDS.  Tiles the argument does not cover (surrogates left the binade, a negative
+//     term, tile 0 with its native head) are marked instead.
+//   level 2, one wave, 64 tiles per step: the summaries are composed exactly as ss_fast composes lanes -- parity maps
+//     by the segmented xor scan, increments by a sum scan, S + total <= 2^24 certifies that the true sum stayed in the
+//     binade.  A tile whose binade was predicted wrongly (E differs from the true accumulator's), in which the sum
+//     leaves its binade, or that is marked, is evaluated from the TRUE accumulator with the wave kernels' own tile
+//     routine (ss_tile1 / roll_chain_tile): about log2(n / 256) + a few tiles per sum.
+//
+// Nothing is speculative in the result: a wrong prediction costs a tile evaluation, never a wrong bit.  Reads go round
+// by round (LC_TILES tiles per round) so that any length fits the LDS.  The four (stat), two (jnn, prefix) sums of a
+// read land in LongSums; k_stat_wave / k_jnn_wave / k_adaptor_wave pick them up (find_long) and walk the read only
+// for the histogram / pA output, the automaton (already 64 chunks wide), the run finder.
+constexpr int LC_WAVES = 16;
+constexpr int LC_TILES = 2048;  // tiles per round (2 097 152 samples)
+constexpr uint32_t LC_VALID = 0x00800000u;
+
+template <int C>
+struct Ix {
+    static constexpr int v = C;
+};
+struct LcLds {
+    uint2 rec[2][LC_TILES];           // x: T0, y: E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff
+    double seg_tot[LC_WAVES][2];      // pass A: sum of the terms of a wave's tiles
+    float m[2];                       // true accumulators (oriented)
+    uint32_t n_true;
+};
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_last_d(wave_incl_scan_d(v)); }
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_last_i(wave_incl_scan_i(v)); }
+
+// level 1: the summary of one tile for the binade of the predicted accumulator mt; tsum: (about) the sum of its terms
+template <typename TF>
+__device__ __forceinline__ uint2 lc_summary(const TF &tf, double mt, bool force_mark, double &tsum) {
+    const uint32_t mb = ss_bits(ss_uniform((float)mt));
+    const uint32_t ex = (mb >> 23) & 0xffu;
+    const bool ok = !(mb >> 31) && ex >= 27u && ex <= 227u && !force_mark;
+    const uint32_t b0 = ((ok ? ex : 127u) << 23) | 0x400000u, b1 = b0 + 1u;
+    SsWalk w = {ss_float(b0), ss_float(b1), 0u};
+    ss_walk_terms<0, true>(w, tf);
+    const uint32_t c0 = ss_bits(w.a0), c1 = ss_bits(w.a1);
+    const uint32_t bad = (((c0 ^ b0) | (c1 ^ b1)) >> 23) | (w.neg >> 31);
+    if (!ok || __any(bad != 0u)) {
+        float v = 0.0f;
+        ss_native_terms<0>(v, tf.with(ss_opaque_zero()));
+        tsum = wave_sum_d((double)v);
+        return make_uint2(0u, 0u);
+    }
+    const int f0 = (int)(c0 - b0), f1 = (int)(c1 - b1);
+    int T0, T1;
+    if (__any(f0 != f1)) {  // some lane met a tie: the tile's increment depends on the parity it is entered with
+        const int s0 = __builtin_amdgcn_inverse_ballot_w64(ss_parity_in(f0, f1, 0)) ? f1 : f0;
+        const int s1 = __builtin_amdgcn_inverse_ballot_w64(ss_parity_in(f0, f1, 1)) ? f1 : f0;
+        T0 = wave_sum_i(s0);
+        T1 = wave_sum_i(s1);
+    } else T0 = T1 = wave_sum_i(f0);
+    tsum = (double)T0 * (double)ss_float((ex - 23u) << 23);
+    return make_uint2((uint32_t)T0, (ex << 24) | LC_VALID | ((uint32_t)(T1 - T0 + 0x8000) & 0xffffu));
+}
+
+// level 2: the accumulator m taken through tiles [0, nt) of a round (records rec[0 .. nt)); eval(tile, m) evaluates
+// one tile from the true accumulator.  One wave.
+template <typename EVAL>
+__device__ inline float lc_compose(float m, const uint2 *rec, int nt, uint32_t &n_true, EVAL eval) {
+    const int lane = lane_id();
+    for (int g0 = 0; g0 < nt; g0 += 64) {
+        const int gn = nt - g0 < 64 ? nt - g0 : 64;
+        const uint2 rc = lane < gn ? rec[g0 + lane] : make_uint2(0u, 0u);
+        const int t0 = (int)rc.x, t1 = t0 + (int)(rc.y & 0xffffu) - 0x8000;
+        int skip = 0;
+        while (skip < gn) {
+            m = ss_uniform(m);
+            const uint32_t mb = ss_bits(m);
+            const uint32_t ex = (mb >> 23) & 0xffu;
+            const bool live = lane >= skip && lane < gn;
+            // (a record carries a binade in 27 .. 227 or is marked: a negative, tiny, huge or non-finite m matches none)
+            const bool okl = live && !(mb >> 31) && (rc.y & LC_VALID) && (rc.y >> 24) == ex;
+            const unsigned long long badm = __ballot(live && !okl);
+            const int fb = badm ? (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)badm) - 1) : gn;
+            int fail = fb;
+            if (fb > skip) {
+                const int S = (int)((mb & 0x7fffffu) | 0x800000u);
+                const bool in = lane >= skip && lane < fb;
+                const int f0 = in ? t0 : 0, f1 = in ? t1 : 0;  // (other lanes: the identity map)
+                int f = f0;
+                if (__any(f0 != f1)) f = __builtin_amdgcn_inverse_ballot_w64(ss_parity_in(f0, f1, S)) ? f1 : f0;
+                // a tile's increment is below 2^23 + 2^10, 64 of them overflow no int; the comparison is done in 64 bits
+                const long long incl = (long long)wave_incl_scan_i(f);
+                const unsigned long long cm = __ballot(in && (long long)S + incl > (1ll << 24));
+                if (cm) fail = (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+                if (fail > skip) {
+                    const int tot = __builtin_amdgcn_readlane((int)incl, fail - 1);
+                    m = (float)(S + tot) * ss_float((ex - 23u) << 23);
+                }
+            }
+            if (fail >= gn) break;
+            m = eval(g0 + fail, m);
+            ++n_true;
+            skip = fail + 1;
+        }
+    }
+    return m;
+}
+
+// One stage (one or two sums over the same tiles) of a long read.  SRC supplies the tiles:
+//   NCH                      sums per stage
+//   seek(t) / ahead(t, te) / next()   streaming: position at tile t; issue the loads of tile t + 1 (< te); step
+//   terms(t, f)              calls f(Ix<c>, term functor of chain c) for the current tile, c = 0 .. NCH - 1; the functors
+//                            mask what lies outside the region and carry the chain's orientation
+//   eval(c, t, m)            chain c's tile t from the true (oriented) accumulator m
+//   flip(c)                  from now on chain c runs on the negated terms
+// Returns the SIGNED sums in out[].  All 16 waves call it (workgroup barriers inside).
+template <typename SRC>
+__device__ inline void lc_stage(SRC &src, LcLds *L, int ntiles, float (&out)[2]) {
+    constexpr int N = SRC::NCH;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    __syncthreads();  // (the previous stage's readers of L are done)
+    if (threadIdx.x < 2) L->m[threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0) L->n_true = 0u;
+    __syncthreads();
+    for (int R0 = 0; R0 < ntiles; R0 += LC_TILES) {
+        const int R1 = ntiles - R0 < LC_TILES ? ntiles : R0 + LC_TILES;
+        const int per = (R1 - R0 + LC_WAVES - 1) / LC_WAVES;
+        const int ta = R0 + wv * per < R1 ? R0 + wv * per : R1, te = ta + per < R1 ? ta + per : R1;
+        // ---- pass A: the sum of the terms of this wave's tiles (a double per lane; the prediction needs no more)
+        double acc[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc[c] = 0.0;
+        if (ta < te) {
+            src.seek(ta);
+            for (int t = ta; t < te; ++t) {
+                src.ahead(t, te);
+                src.terms(t, [&](auto ix, const auto &tf) {
+                    constexpr int c = decltype(ix)::v;
+                    float v = 0.0f;
+                    ss_native_terms<0>(v, tf);
+                    acc[c] += (double)v;
+                });
+                src.next();
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const double tot = wave_sum_d(acc[c]);
+            if (lane == 0) L->seg_tot[wv][c] = tot;
+        }
+        __syncthreads();
+        // the chain is oriented by the sign of the read's first round (as the wave kernels orient it by the sign of the
+        // accumulator): non-negative terms are what the summaries cover
+        double mt[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double before = 0.0, all = 0.0;
+            for (int w = 0; w < LC_WAVES; ++w) {
+                const double v = L->seg_tot[w][c];
+                before += w < wv ? v : 0.0;
+                all += v;
+            }
+            double sgn = 1.0;
+            if (R0 == 0 && all < 0.0) { src.flip(c); sgn = -1.0; }
+            mt[c] = (double)L->m[c] + sgn * before;
+        }
+        __syncthreads();  // (seg_tot and m are read: the next round's pass A and level 2 may write them)
+        // ---- pass B: the tiles' summaries
+        if (ta < te) {
+            src.seek(ta);
+            for (int t = ta; t < te; ++t) {
+                src.ahead(t, te);
+                src.terms(t, [&](auto ix, const auto &tf) {
+                    constexpr int c = decltype(ix)::v;
+                    double ts;
+                    const uint2 rc = lc_summary(tf, mt[c], t == 0, ts);
+                    if (lane == 0) L->rec[c][t - R0] = rc;
+                    mt[c] += ts;
+                });
+                src.next();
+            }
+        }
+        __syncthreads();
+        // ---- level 2
+        if (wv == 0) {
+            uint32_t n_true = 0u;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const float m = lc_compose(L->m[c], L->rec[c], R1 - R0, n_true, [&](int t, float mm) { return src.eval(c, R0 + t, mm); });
+                if (lane == 0) L->m[c] = m;
+            }
+            if (lane == 0) L->n_true += n_true;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = ss_signed(L->m[c], src.negated(c));
+}
+
+// ---- the tile sources
+struct SrcTiles {  // streaming of the raw tiles of a region
+    WaveRead wr;
+    WaveTile cur, nxt;
+    __device__ __forceinline__ void seek(int t) { wr.load(cur, t); }
+    __device__ __forceinline__ void ahead(int t, int te) { if (t + 1 < te) wr.load(nxt, t + 1); }
+    __device__ __forceinline__ void next() { cur = nxt; }
+    template <typename F>
+    __device__ __forceinline__ void bases(int t, F f) const {  // f(TermBase) for the current tile
+        const int q0 = lane_id() * SS_SPL;
+        int q_lo, q_hi;
+        wr.range(t, 0, q_lo, q_hi);
+        if (wr.interior(t)) f(TermBase<true>{cur, q0, q_lo, q_hi, 0u});
+        else f(TermBase<false>{cur, q0, q_lo, q_hi, 0u});
+    }
+};
+struct SrcStatSums : SrcTiles {  // stat, stage 1: raw and pA (src/stat.h:17-33)
+    static constexpr int NCH = 2;
+    Scale sc;
+    int sraw;   // -1: the raw chain runs negated
+    float sg;   // the pA chain's orientation times the sign of the unit (as in k_stat_wave)
+    __device__ void init(const sgk_batch_t &b, const Region &g, const Scale &s) {
+        wr.init(b, g); sc = s; sraw = 0; sg = s.unit < 0.0f ? -1.0f : 1.0f;
+    }
+    __device__ __forceinline__ void flip(int c) { if (c == 0) sraw = ~sraw; else sg = -sg; }
+    __device__ __forceinline__ bool negated(int c) const { return c == 0 ? sraw != 0 : sg < 0.0f; }
+    template <typename F>
+    __device__ __forceinline__ void terms(int t, F f) const {
+        const Scale so = {sc.offf, sc.unit * sg};
+        bases(t, [&](auto b) {
+            f(Ix<0>{}, TermRaw<decltype(b)::interior>{b, sraw});
+            f(Ix<1>{}, TermPa<decltype(b)::interior>{b, so});
+        });
+    }
+    __device__ __attribute__((noinline)) float eval(int c, int t, float m) const {
+        WaveTile x;
+        wr.load(x, t);
+        const Scale so = {sc.offf, sc.unit * sg};
+        if (c == 0) ss_tile1<true>(m, wr, x, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; });
+        else ss_tile1<true>(m, wr, x, t, [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; });
+        return m;
+    }
+};
+struct SrcStatDevs : SrcTiles {  // stat, stage 2: squared deviations (src/stat.h:36-54)
+    static constexpr int NCH = 2;
+    Scale sc;
+    float mraw, mpa;
+    __device__ __forceinline__ void flip(int) {}
+    __device__ __forceinline__ bool negated(int) const { return false; }
+    template <typename F>
+    __device__ __forceinline__ void terms(int t, F f) const {
+        bases(t, [&](auto b) {
+            f(Ix<0>{}, TermDevRaw<decltype(b)::interior>{b, mraw});
+            f(Ix<1>{}, TermDevPa<decltype(b)::interior>{b, sc, mpa});
+        });
+    }
+    __device__ __attribute__((noinline)) float eval(int c, int t, float m) const {
+        WaveTile x;
+        wr.load(x, t);
+        if (c == 0) ss_tile1<false>(m, wr, x, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; });
+        else ss_tile1<false>(m, wr, x, t, [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; });
+        return m;
+    }
+};
+template <bool DEV>
+struct SrcClamp : SrcTiles {  // jnn: rm_outlier(raw), then its squared deviations (src/jnn.c:195-199)
+    static constexpr int NCH = 1;
+    float mean;
+    __device__ __forceinline__ void flip(int) {}
+    __device__ __forceinline__ bool negated(int) const { return false; }
+    template <typename B>
+    __device__ __forceinline__ auto term(B b) const {
+        if constexpr (DEV) return TermDevClamp<B::interior>{b, mean};
+        else return TermClamp<B::interior>{b};
+    }
+    template <typename F>
+    __device__ __forceinline__ void terms(int t, F f) const {
+        bases(t, [&](auto b) { f(Ix<0>{}, term(b)); });
+    }
+    __device__ __attribute__((noinline)) float eval(int, int t, float m) const {
+        WaveTile x;
+        wr.load(x, t);
+        ss_tile1<false>(m, wr, x, t, [&](auto b) { return term(b); });
+        return m;
+    }
+};
+template <bool DEV>
+struct SrcRoll {  // jnnv2: the rolling means of ADW clamped samples, then their squared deviations (src/jnn.c:106-124)
+    static constexpr int NCH = 1;
+    WaveRead wr;  // region: the windows' first samples
+    float mean;
+    int T0;
+    WaveTile tr, ld, trn, ldn;
+    __device__ __forceinline__ void flip(int) {}
+    __device__ __forceinline__ bool negated(int) const { return false; }
+    __device__ __forceinline__ float term(int v) const {
+        if constexpr (DEV) { const float d = roll_mean(v) - mean; return d * d; }
+        else return roll_mean(v);
+    }
+    __device__ __forceinline__ void seek(int t) {
+        T0 = window_total(wr, t, t == 0 ? wr.skip : 0);
+        roll_load(wr, tr, ld, t);
+    }
+    __device__ __forceinline__ void ahead(int t, int te) { if (t + 1 < te) roll_load(wr, trn, ldn, t + 1); }
+    __device__ __forceinline__ void next() { tr = trn; ld = ldn; }
+    __device__ __forceinline__ void totals(const WaveTile &a, const WaveTile &b, int t, int &T, int (&tot)[SS_SPL]) const {
+        if (t == 0 && wr.skip > 0) roll_tile<true>(a, b, wr.skip, T, tot);
+        else roll_tile<false>(a, b, 0, T, tot);
+    }
+    template <typename F>
+    __device__ __forceinline__ void terms(int t, F f) {
+        int tot[SS_SPL];
+        totals(tr, ld, t, T0, tot);
+        const int q0 = lane_id() * SS_SPL;
+        int q_lo, q_hi;
+        wr.range(t, 0, q_lo, q_hi);
+        float x[SS_SPL];
+#pragma unroll
+        for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
+        f(Ix<0>{}, TermArr{x});
+    }
+    __device__ __attribute__((noinline)) float eval(int, int t, float m) const {
+        int T = window_total(wr, t, t == 0 ? wr.skip : 0);
+        WaveTile a, b;
+        roll_load(wr, a, b, t);
+        int tot[SS_SPL];
+        totals(a, b, t, T, tot);
+        roll_chain_tile(m, wr, t, tot, [&](int v) { return term(v); });
+        return m;
+    }
+};
+
+enum { LC_STAT = 0, LC_JNN = 1, LC_ADAPT = 2 };
+// lists the reads of long_min samples or more (any order)
+__global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.b.n_reads || a.b.lengths[r] < a.long_min) return;
+    const uint32_t i = atomicAdd(&a.long_hdr->n_long, 1u);
+    if (i < LC_CAP) {
+        a.long_list[i] = r;
+        a.longs[i].read = r;
+        a.longs[i].valid = 0u;
+    }
+}
+template <int KIND>
+__global__ __launch_bounds__(LC_WAVES * 64) void k_long_chains(StatArgs a, float std_scale) {
+    __shared__ LcLds L;
+    const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
+    for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const uint32_t r = a.long_list[i];
+        const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+        float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+        uint32_t tiles = 0u, n_true = 0u;
+        if (KIND == LC_STAT) {
+            const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+            const float nf = (float)(int)g.len;
+            SrcStatSums src1;
+            src1.init(a.b, g, sc);
+            lc_stage(src1, &L, src1.wr.ntiles, s1);
+            n_true += L.n_true;
+            SrcStatDevs src2;
+            src2.wr = src1.wr; src2.sc = sc; src2.mraw = s1[0] / nf; src2.mpa = s1[1] / nf;
+            lc_stage(src2, &L, src2.wr.ntiles, s2);
+            n_true += L.n_true;
+            tiles = 4u * (uint32_t)src1.wr.ntiles;
+        } else if (KIND == LC_JNN) {
+            if (std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums)
+                const float nf = (float)(int)g.len;
+                SrcClamp<false> src1;
+                src1.wr.init(a.b, g); src1.mean = 0.0f;
+                lc_stage(src1, &L, src1.wr.ntiles, s1);
+                n_true += L.n_true;
+                SrcClamp<true> src2;
+                src2.wr = src1.wr; src2.mean = s1[0] / nf;
+                lc_stage(src2, &L, src2.wr.ntiles, s2);
+                n_true += L.n_true;
+                tiles = 2u * (uint32_t)src1.wr.ntiles;
+            }
+        } else {
+            if (g.len > ADW) {
+                const int64_t m = g.len - ADW;
+                const float mf = (float)(int)m;
+                SrcRoll<false> src1;
+                src1.wr.init(a.b, Region{g.start, m}); src1.mean = 0.0f;
+                lc_stage(src1, &L, src1.wr.ntiles, s1);
+                n_true += L.n_true;
+                SrcRoll<true> src2;
+                src2.wr = src1.wr; src2.mean = s1[0] / mf;
+                lc_stage(src2, &L, src2.wr.ntiles, s2);
+                n_true += L.n_true;
+                tiles = 2u * (uint32_t)src1.wr.ntiles;
+            }
+        }
+        if (threadIdx.x == 0) {
+            LongSums *o = a.longs + i;
+            o->s1[0] = s1[0]; o->s1[1] = s1[1];
+            o->s2[0] = s2[0]; o->s2[1] = s2[1];
+            o->valid = 1u;
+            atomicAdd(&a.long_hdr->n_tiles, tiles);
+            atomicAdd(&a.long_hdr->n_true, n_true);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- dispatch order of the wave-per-read kernels
 // A wave-per-read kernel cannot finish before its longest read has: reads are handed to the waves longest first
 // (workgroups start in index order), by a counting sort of the read lengths into 128 buckets (4 per octave).
@@ -1946,6 +2396,35 @@ int launch_order(const uint32_t *lengths, uint32_t nr, uint32_t *order, uint32_t
     hipLaunchKernelGGL(k_order_fill, dim3((nr + 255) / 256), dim3(256), 0, st, lengths, nr, hist, order);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
+}
+size_t long_workspace_bytes() { return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums)); }
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st) {
+    a.long_hdr = nullptr;
+    a.long_list = nullptr;
+    a.longs = nullptr;
+    a.long_min = 0u;
+    const uint32_t lm = opt_long_min <= 0 ? LC_LONG_MIN
+                                          : ((uint32_t)opt_long_min < LC_LONG_MIN_FLOOR ? LC_LONG_MIN_FLOOR : (uint32_t)opt_long_min);
+    const size_t off = order_workspace_bytes(a.b.n_reads);
+    if (!ws || ws_bytes < off + long_workspace_bytes() || (reinterpret_cast<uintptr_t>(ws) & 3u)) return SGK_OK;
+    char *base = static_cast<char *>(ws) + off;
+    if (opt_long_min < 0 || a.b.max_read_len < lm) {  // no long read in this call: sgk_stat_long_status says so
+        SGK_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
+        return SGK_OK;
+    }
+    a.long_hdr = reinterpret_cast<LongHdr *>(base);
+    a.long_list = reinterpret_cast<uint32_t *>(base + sizeof(LongHdr));
+    a.longs = reinterpret_cast<LongSums *>(base + sizeof(LongHdr) + (size_t)LC_CAP * 4);
+    a.long_min = lm;
+    SGK_HIP_TRY(hipMemsetAsync(a.long_hdr, 0, sizeof(LongHdr), st));
+    hipLaunchKernelGGL(k_long_list, dim3((a.b.n_reads + 255) / 256), dim3(256), 0, st, a);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+// workgroups of k_long_chains: one per long read the batch can hold, at most one per CU
+static uint32_t long_grid(const StatArgs &a) {
+    const uint64_t most = a.b.n_samples / a.long_min;
+    return most < 1 ? 1u : (most > 256 ? 256u : (uint32_t)most);
 }
 int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
     a.order = nullptr;
@@ -1992,6 +2471,10 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         SGK_HIP_TRY(hipGetLastError());
         return SGK_OK;
     }
+    if (a.longs) {
+        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+        SGK_HIP_TRY(hipGetLastError());
+    }
     if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
     else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
     SGK_HIP_TRY(hipGetLastError());
@@ -2007,7 +2490,13 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
     if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
-        SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, a, p);
+        if (a.longs && p.std_scale > 0.0f) {
+            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WAVES * 64, a, p.std_scale);
+            SGK_HIP_TRY(hipGetLastError());
+        }
+        StatArgs aw = a;
+        if (!(p.std_scale > 0.0f)) aw.longs = nullptr;
+        SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, aw, p);
         SGK_HIP_TRY(hipGetLastError());
         StatArgs redo = a;
         redo.jnn_redo = 1u;  // the reads the wave kernel gave up on (none, usually: its wavefronts return at once)
@@ -2021,7 +2510,13 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
-    else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
+    else {
+        if (a.longs) {
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+            SGK_HIP_TRY(hipGetLastError());
+        }
+        SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
+    }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -2045,7 +2540,13 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t gw = (nr + 63) / 64;
     const bool lanes = lane_per_read(a);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
-    else SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
+    else {
+        if (a.longs) {
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+            SGK_HIP_TRY(hipGetLastError());
+        }
+        SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
+    }
     SGK_HIP_TRY(hipGetLastError());
     if (lanes) {
         SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);

@@ -169,6 +169,17 @@ def _workspace(b: "DeviceReads", size_fn_name: str) -> torch.Tensor:
     return cache[size_fn_name]
 
 
+def long_status(b: "DeviceReads", tool: str = "stat", ws: Optional[torch.Tensor] = None) -> "api.LongStatus":
+    """sgk_stat_long_status of the workspace the last stat / prefix call on this batch used (jnn: pass arena.ws);
+    synchronises"""
+    if ws is None:
+        ws = _workspace(b, "sgk_%s_workspace_bytes" % tool)
+    torch.cuda.synchronize()
+    st = api.LongStatus()
+    api.check(api.load_library().sgk_stat_long_status(_ptr(ws), ws.numel(), b.n_reads, C.byref(st)), "sgk_stat_long_status")
+    return st
+
+
 def stat(b: DeviceReads) -> torch.Tensor:
     """sgk_stat -> uint8 tensor holding n_reads sgk_stat_rec_t (view it with api.STAT_DTYPE)."""
     L = api.load_library()

@@ -1,0 +1,119 @@
+"""GPU parity: long reads in stat / jnn / prefix (k_long_chains: the sequential float sums of a long read on 16
+wavefronts, composed from per-tile summaries) against the oracle, bit for bit, and against the one-wave path."""
+import numpy as np
+import pytest
+
+from test_gpu_stat import _check_jnn, _check_prefix, _check_stat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def long_min(gpu):
+    """sets sgk_stat_options_t::long_min for the test's calls and restores the default afterwards"""
+    def set_(v):
+        gpu.stat_configure(2, v)
+    yield set_
+    gpu.stat_configure(0, 0)
+
+
+def _hostile(gpu, lens, seed):
+    """synthetic reads + the shapes the summaries do not cover or cover with ties: signed ADC codes (negative terms
+    and a negative running sum), a constant read (every addition of the raw chain rounds the same way: the predicted
+    binades run ahead of the true ones), an all-zero read, a read of +-32767 alternating, a negative range"""
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=seed, kind=0)
+    reads = [r.copy() for r in reads]
+    rs = np.random.RandomState(seed)
+    rng = rng.copy()
+    if len(reads) > 1:
+        reads[1] = rs.randint(-2000, 2000, size=reads[1].size).astype(np.int16)
+    if len(reads) > 2:
+        reads[2][:] = 517
+    if len(reads) > 3:
+        reads[3][:] = 0
+    if len(reads) > 4:
+        reads[4][::2] = 32767
+        reads[4][1::2] = -32767
+    if len(reads) > 5:
+        rng[5] = -rng[5]
+    if len(reads) > 6:
+        reads[6] = (-np.abs(reads[6].astype(np.int32)) - 3).astype(np.int16)   # every term negative
+    return reads, dig, off, rng
+
+
+def test_read_of_3000001_samples_all_three_subtools(gpu, oracle, long_min):
+    """VERDICT r03 task 6: a 3 000 001-sample read next to ordinary ones, stat / jnn / prefix against the oracle"""
+    lens = [3000001, 100000, 5000, 262144, 262143]
+    for kind in (0, 1):
+        reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=41 + kind, kind=kind)
+        long_min(0)
+        st = gpu.stat(reads, dig, off, rng)
+        _check_stat(oracle, reads, dig, off, rng, st)
+        for rna in (0, 1):
+            _check_jnn(oracle, reads, rna, gpu.jnn(reads, dig, off, rng, rna))
+        for pore in (0, 2):
+            _check_prefix(oracle, reads, dig, off, rng, kind, pore, gpu.prefix(reads, dig, off, rng, kind, pore))
+        long_min(-1)   # the one-wave path gives the same records
+        st1 = gpu.stat(reads, dig, off, rng)
+        assert st.tobytes() == st1.tobytes()
+
+
+@pytest.mark.parametrize("threshold", [8192, 20000])
+def test_many_long_reads_of_every_shape(gpu, oracle, long_min, threshold):
+    """a low threshold makes every read above it long: ragged lengths around tile and round boundaries, hostile
+    contents; two rounds (more than 2 097 152 samples) in one read"""
+    lens = [8192, 8193, 16384, 16385, 20000, 20001, 33333, 65535, 65536, 100000, 131071, 250000, 1024 * 2048 + 5000,
+            9000, 12000, 8191, 100, 0, 1]
+    reads, dig, off, rng = _hostile(gpu, lens, 7)
+    long_min(threshold)
+    _check_stat(oracle, reads, dig, off, rng, gpu.stat(reads, dig, off, rng))
+    for rna in (0, 1):
+        _check_jnn(oracle, reads, rna, gpu.jnn(reads, dig, off, rng, rna))
+    for pore in (0, 2):
+        _check_prefix(oracle, reads, dig, off, rng, 0, pore, gpu.prefix(reads, dig, off, rng, 0, pore))
+    reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=9, kind=1)
+    for pore in (0, 2):
+        _check_prefix(oracle, reads, dig, off, rng, 1, pore, gpu.prefix(reads, dig, off, rng, 1, pore))
+
+
+def test_long_path_composes_most_tiles_and_equals_the_one_wave_path(gpu):
+    """device API: the fused stat + pA records and the pA output are identical with and without the long path; the
+    status says how many tile sums were composed from summaries (all but the binade crossings and the first tile)"""
+    import torch
+    from sigtk_amd import device
+    lens = np.asarray([1500000, 300000, 100000, 700001, 4000], dtype=np.int64)
+    dev = torch.device("cuda", 0)
+    b = device.synth_reads(len(lens), 0, seed=5, kind=0, device=dev, lengths=lens)
+    gpu.stat_configure(2, 0)
+    try:
+        rec, pa = device.stat_pa(b)
+        st = device.long_status(b, "stat")
+        rec, pa = rec.cpu().numpy().copy(), pa.cpu().numpy().copy()
+        pre = device.prefix(b, 0, 0).cpu().numpy().copy()
+        sp = device.long_status(b, "prefix")
+        arena = device.SegArena(b)
+        device.jnn(b, arena, 0)
+        sj = device.long_status(b, ws=arena.ws)
+        segs = (arena.n_segs.cpu().numpy().copy(), arena.x.cpu().numpy().copy(), arena.y.cpu().numpy().copy())
+        gpu.stat_configure(2, -1)
+        rec1, pa1 = device.stat_pa(b)
+        assert device.long_status(b, "stat").n_long_reads == 0
+        pre1 = device.prefix(b, 0, 0).cpu().numpy()
+        arena1 = device.SegArena(b)
+        device.jnn(b, arena1, 0)
+    finally:
+        gpu.stat_configure(0, 0)
+    assert rec.tobytes() == rec1.cpu().numpy().tobytes()
+    assert pa.tobytes() == pa1.cpu().numpy().tobytes()
+    assert pre.tobytes() == pre1.tobytes()
+    n1 = arena1.n_segs.cpu().numpy()
+    assert (segs[0] == n1).all()
+    x1, y1, slots = arena1.x.cpu().numpy(), arena1.y.cpu().numpy(), arena1.slots_host
+    for r in range(len(lens)):
+        s0, n = int(slots[r]), int(n1[r])
+        assert (segs[1][s0:s0 + n] == x1[s0:s0 + n]).all() and (segs[2][s0:s0 + n] == y1[s0:s0 + n]).all()
+    for s, chains in ((st, 4), (sp, 2), (sj, 2)):
+        assert s.n_long_reads == 3
+        tiles = sum((int(n) + 1023 + 7) // 1024 for n in lens[[0, 1, 3]])
+        assert chains * (tiles - 12) <= s.n_tiles <= chains * (tiles + 3)
+        assert 0 < s.n_true_tiles <= s.n_tiles // 20, (s.n_tiles, s.n_true_tiles)
