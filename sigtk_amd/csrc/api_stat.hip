@@ -22,10 +22,12 @@ extern "C" {
 // 64 bytes of counters + room for the longest-first dispatch order (a smaller workspace, down to 64 bytes -- none for
 // stat / prefix -- is accepted: the kernels then take the reads in batch order)
 // ... and the records of the batch's long reads (k_long_chains; without that room long reads run on one wavefront)
-static size_t stat_ws(uint32_t n_reads) { return order_workspace_bytes(n_reads) + long_workspace_bytes(); }
-size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
-size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
-size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t, uint32_t) { return stat_ws(n_reads); }
+static size_t stat_ws(uint32_t n_reads, uint64_t n_samples, uint32_t max_len) {
+    return order_workspace_bytes(n_reads) + long_workspace_bytes(n_samples, max_len);
+}
+size_t sgk_stat_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_len) { return stat_ws(n_reads, n_samples, max_len); }
+size_t sgk_jnn_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_len) { return stat_ws(n_reads, n_samples, max_len); }
+size_t sgk_prefix_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_len) { return stat_ws(n_reads, n_samples, max_len); }
 
 int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_bytes, void *stream,
                  const sgk_stat_options_t *opt) {
@@ -112,7 +114,7 @@ int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_
     if (!out) return SGK_ERR_ARG;
     memset(out, 0, sizeof *out);
     const size_t off = order_workspace_bytes(n_reads);
-    if (!ws || ws_bytes < off + long_workspace_bytes()) return SGK_OK;
+    if (!ws || ws_bytes < off + long_workspace_bytes(0, 0)) return SGK_OK;
     LongHdr h;
     SGK_HIP_TRY(hipMemcpy(&h, static_cast<const char *>(ws) + off, sizeof h, hipMemcpyDeviceToHost));
     out->n_long_reads = h.n_long;
@@ -132,8 +134,8 @@ int sgk_stat_host_opt(const sgk_host_batch_t *hb, sgk_stat_rec_t *out, const sgk
     if (!out) return SGK_ERR_ARG;
     DevBuf d_out, d_ws;
     if ((rc = d_out.alloc(nr * sizeof(sgk_stat_rec_t))) != SGK_OK) return rc;
-    if ((rc = d_ws.alloc(stat_ws(hb->n_reads))) != SGK_OK) return rc;
-    if ((rc = sgk_stat_opt(&db.view, d_out.as<sgk_stat_rec_t>(), d_ws.p, stat_ws(hb->n_reads), nullptr, opt)) != SGK_OK) return rc;
+    if ((rc = d_ws.alloc(stat_ws(hb->n_reads, db.view.n_samples, db.view.max_read_len))) != SGK_OK) return rc;
+    if ((rc = sgk_stat_opt(&db.view, d_out.as<sgk_stat_rec_t>(), d_ws.p, stat_ws(hb->n_reads, db.view.n_samples, db.view.max_read_len), nullptr, opt)) != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     SGK_HIP_TRY(hipMemcpy(out, d_out.p, nr * sizeof(sgk_stat_rec_t), hipMemcpyDeviceToHost));
     return SGK_OK;
@@ -151,8 +153,8 @@ int sgk_prefix_host_opt(const sgk_host_batch_t *hb, int rna, int pore, sgk_prefi
     if (!out) return SGK_ERR_ARG;
     DevBuf d_out, d_ws;
     if ((rc = d_out.alloc(nr * sizeof(sgk_prefix_rec_t))) != SGK_OK) return rc;
-    if ((rc = d_ws.alloc(stat_ws(hb->n_reads))) != SGK_OK) return rc;
-    if ((rc = sgk_prefix_opt(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), d_ws.p, stat_ws(hb->n_reads), nullptr,
+    if ((rc = d_ws.alloc(stat_ws(hb->n_reads, db.view.n_samples, db.view.max_read_len))) != SGK_OK) return rc;
+    if ((rc = sgk_prefix_opt(&db.view, rna, pore, d_out.as<sgk_prefix_rec_t>(), d_ws.p, stat_ws(hb->n_reads, db.view.n_samples, db.view.max_read_len), nullptr,
                              opt)) != SGK_OK)
         return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
@@ -182,10 +184,10 @@ int sgk_jnn_host_opt(const sgk_host_batch_t *hb, int rna, sgk_segs_host_t *out, 
     if ((rc = d_x.alloc(nslots * 4)) != SGK_OK) return rc;
     if ((rc = d_y.alloc(nslots * 4)) != SGK_OK) return rc;
     if ((rc = d_n.alloc((size_t)nr * 4)) != SGK_OK) return rc;
-    if ((rc = d_ws.alloc(stat_ws(nr))) != SGK_OK) return rc;
+    if ((rc = d_ws.alloc(stat_ws(nr, db.view.n_samples, db.view.max_read_len))) != SGK_OK) return rc;
     SGK_HIP_TRY(hipMemcpy(d_slots.p, slots.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     rc = sgk_jnn_opt(&db.view, rna, d_slots.as<uint64_t>(), d_x.as<int32_t>(), d_y.as<int32_t>(), d_n.as<uint32_t>(),
-                     d_ws.p, stat_ws(nr), nullptr, opt);
+                     d_ws.p, stat_ws(nr, db.view.n_samples, db.view.max_read_len), nullptr, opt);
     if (rc != SGK_OK) return rc;
     SGK_HIP_TRY(hipDeviceSynchronize());
     uint32_t nerr = 0;

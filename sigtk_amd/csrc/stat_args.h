@@ -22,31 +22,47 @@ struct StatArgs {
     struct LongHdr *long_hdr;
     uint32_t *long_list;         // LC_CAP read indices
     struct LongSums *longs;      // LC_CAP records, entry i belongs to read long_list[i]
+    struct LongWork *long_work;  // LC_CAP blocks the workgroups of a long read meet in
+    unsigned long long *long_pool;  // tile records: [0, long_pool_tiles) of the first sum, then of the second
+    uint32_t long_pool_tiles;
     uint32_t long_min;           // reads of at least this many samples are long
 };
 constexpr uint32_t JNN_REDO_MARK = 0xffffffffu;
 
-// ---- long reads (round 4): the sequential float sums of a read of long_min samples or more are evaluated by a
-// workgroup of 16 wavefronts BEFORE the wave-per-read kernel runs (k_long_chains); that kernel then finds the sums here
-// and walks the read only for what is cheap per sample (histogram, pA output, automaton, run finder).
+// ---- long reads (round 4): the sequential float sums of a read of long_min samples or more are evaluated by
+// LC_PARTS workgroups of four wavefronts BEFORE the wave-per-read kernel runs (k_long_chains); that kernel then finds the
+// sums here and walks the read only for what is cheap per sample (histogram, pA output, automaton, run finder).
+constexpr int LC_PARTS = 16;                  // workgroups per long read
+constexpr int LC_WG_WAVES = 4;
+constexpr int LC_WAVES = LC_PARTS * LC_WG_WAVES;
+static_assert(LC_WAVES == 64, "lc_stage reads one wave's total per lane");
 struct LongHdr {
     uint32_t n_long;     // long reads found (k_long_list; entries beyond LC_CAP have no record)
-    uint32_t n_tiles;    // tiles summarised (per chain)
+    uint32_t n_tiles;    // tile sums summarised
     uint32_t n_true;     // ... of which the composition had to evaluate from the true accumulator
-    uint32_t pad[13];
+    uint32_t pool_used;  // tile records handed out
+    uint32_t pad[12];
 };
 struct LongSums {
     uint32_t read;
     uint32_t valid;      // 1: s1 / s2 are final
     float s1[2];         // first-stage sums (stat: raw, pA; jnn: clamped raw; prefix: rolling means), signed
     float s2[2];         // second-stage sums (squared deviations from the first stage's means)
-    uint32_t pad[2];
+    uint32_t rec_off;    // the read's tile records in the pool (0xffffffff: none, the read runs on one wave)
+    uint32_t pad;
 };
-static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64, "long-read workspace layout");
+struct LongWork {        // what the workgroups of one long read exchange (agent-scope atomics only)
+    uint32_t arrive;     // barrier counter
+    uint32_t n_true;
+    float m[2];          // the sums' accumulators after level 2 (oriented)
+    unsigned long long seg_tot[LC_WAVES][2];  // pass A: sum of the terms of a wave's tiles (a double's bits)
+};
+static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64 && sizeof(LongWork) == 16 + 16 * LC_WAVES, "long-read workspace layout");
 constexpr uint32_t LC_CAP = 1024;             // long reads per batch that get a record (the rest run as before)
+constexpr uint32_t LC_POOL_TILES = 1u << 20;  // tile records per sum (2^30 samples of long reads; 16 MB)
 constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
 constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for
-size_t long_workspace_bytes();
+size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
 // clears the header and lists the long reads
 int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st);

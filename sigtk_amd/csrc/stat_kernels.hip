@@ -1948,49 +1948,72 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     }
 }
 
-// ---------------------------------------------------------------- long reads: the sequential sums on 16 wavefronts
+// ---------------------------------------------------------------- long reads: the sequential sums on 64 wavefronts
 // A wave evaluates a sequential float sum at ~1 000 terms per microsecond; a read of 3 000 000 samples keeps its wave
-// busy for milliseconds per sum while the rest of the batch is long done.  k_long_chains gives such a read a workgroup
-// of 16 wavefronts.  What seqsum.h does with the 16 terms of a lane is done here once more with the 1 024 terms of a
-// TILE (tools/proto/seqsum_segments_proto.py is the model):
+// busy for milliseconds per sum while the rest of the batch is long done.  k_long_chains gives such a read LC_PARTS
+// workgroups of four wavefronts (on LC_PARTS compute units: the sums are bound by vector-instruction issue, one compute
+// unit's four SIMDs would not do).  What seqsum.h does with the 16 terms of a lane is done here once more with the 1 024
+// terms of a TILE (tools/proto/seqsum_segments_proto.py is the model):
 //
 //   level 1, all waves, no dependency between them: a wave owns a contiguous run of tiles.  It PREDICTS the accumulator
-//     in front of each tile (the true accumulator at the start of the round + sums of the terms in front, pass A below,
-//     then tile by tile from its own summaries), takes the binade E of the prediction, and summarises the tile for that
-//     binade: T0 / T1, the increment of the accumulator's significand over the tile's 1 024 terms when it enters the
-//     tile even / odd (lanes' surrogate walks, parity maps composed across the lanes, once per entering parity).
-//     8 bytes per tile and chain in LDS.  Tiles the argument does not cover (surrogates left the binade, a negative
-//     term, tile 0 with its native head) are marked instead.
-//   level 2, one wave, 64 tiles per step: the summaries are composed exactly as ss_fast composes lanes -- parity maps
-//     by the segmented xor scan, increments by a sum scan, S + total <= 2^24 certifies that the true sum stayed in the
-//     binade.  A tile whose binade was predicted wrongly (E differs from the true accumulator's), in which the sum
+//     in front of each tile (sums of the terms in front of its run, pass A below, then tile by tile from its own
+//     summaries), takes the binade E of the prediction, and summarises the tile for that binade: T0 / T1, the
+//     increment of the accumulator's significand over the tile's 1 024 terms when it enters the tile even / odd (lanes'
+//     surrogate walks, parity maps composed across the lanes, once per entering parity).  8 bytes per tile and sum in
+//     the workspace.  Tiles the argument does not cover (surrogates left the binade, a negative term, tile 0 with its
+//     native head) are marked instead.
+//   level 2, one wave per sum, 64 tiles per step: the summaries are composed exactly as ss_fast composes lanes -- parity
+//     maps by the segmented xor scan, increments by a sum scan, S + total <= 2^24 certifies that the true sum stayed in
+//     the binade.  A tile whose binade was predicted wrongly (E differs from the true accumulator's), in which the sum
 //     leaves its binade, or that is marked, is evaluated from the TRUE accumulator with the wave kernels' own tile
 //     routine (ss_tile1 / roll_chain_tile): about log2(n / 256) + a few tiles per sum.
 //
-// Nothing is speculative in the result: a wrong prediction costs a tile evaluation, never a wrong bit.  Reads go round
-// by round (LC_TILES tiles per round) so that any length fits the LDS.  The four (stat), two (jnn, prefix) sums of a
-// read land in LongSums; k_stat_wave / k_jnn_wave / k_adaptor_wave pick them up (find_long) and walk the read only
-// for the histogram / pA output, the automaton (already 64 chunks wide), the run finder.
-constexpr int LC_WAVES = 16;
-constexpr int LC_TILES = 2048;  // tiles per round (2 097 152 samples)
+// Nothing is speculative in the result: a wrong prediction costs a tile evaluation, never a wrong bit.  The workgroups
+// of a read meet at barriers on a counter in the workspace (three per stage); everything they exchange is written and
+// read with agent-scope atomics (the L2s of the eight XCDs are not coherent for ordinary accesses).  A read's workgroups
+// are neighbours in the grid and the grid is small enough to be resident at once, so nobody waits for a workgroup that
+// cannot start.  The four (stat), two (jnn, prefix) sums of a read land in LongSums; k_stat_wave / k_jnn_wave /
+// k_adaptor_wave pick them up (find_long) and walk the read only for the histogram / pA output, the automaton (already
+// 64 chunks wide), the run finder.
 constexpr uint32_t LC_VALID = 0x00800000u;
 
 template <int C>
 struct Ix {
     static constexpr int v = C;
 };
-struct LcLds {
-    uint2 rec[2][LC_TILES];           // x: T0, y: E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff
-    double seg_tot[LC_WAVES][2];      // pass A: sum of the terms of a wave's tiles
-    float m[2];                       // true accumulators (oriented)
-    uint32_t n_true;
-};
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_last_d(wave_incl_scan_d(v)); }
 __device__ __forceinline__ int wave_sum_i(int v) { return wave_last_i(wave_incl_scan_i(v)); }
+__device__ __forceinline__ uint32_t lc_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long lc_ld(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lc_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lc_st(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct LcCtx {
+    LongWork *w;
+    unsigned long long *rec[2];  // tile records of the two sums: T0 | (E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff) << 32
+    uint32_t phase;              // barriers passed
+    int part;                    // this workgroup's index among the read's LC_PARTS
+};
+// all workgroups of the read; what they wrote with lc_st before is readable with lc_ld behind it
+__device__ inline void lc_barrier(LcCtx &cx) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++cx.phase;
+    if (threadIdx.x == 0) {
+        atomicAdd(&cx.w->arrive, 1u);
+        const uint32_t target = cx.phase * (uint32_t)LC_PARTS;
+        while (lc_ld(&cx.w->arrive) < target) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
 
 // level 1: the summary of one tile for the binade of the predicted accumulator mt; tsum: (about) the sum of its terms
 template <typename TF>
-__device__ __forceinline__ uint2 lc_summary(const TF &tf, double mt, bool force_mark, double &tsum) {
+__device__ __forceinline__ unsigned long long lc_summary(const TF &tf, double mt, bool force_mark, double &tsum) {
     const uint32_t mb = ss_bits(ss_uniform((float)mt));
     const uint32_t ex = (mb >> 23) & 0xffu;
     const bool ok = !(mb >> 31) && ex >= 27u && ex <= 227u && !force_mark;
@@ -2003,7 +2026,7 @@ __device__ __forceinline__ uint2 lc_summary(const TF &tf, double mt, bool force_
         float v = 0.0f;
         ss_native_terms<0>(v, tf.with(ss_opaque_zero()));
         tsum = wave_sum_d((double)v);
-        return make_uint2(0u, 0u);
+        return 0ull;
     }
     const int f0 = (int)(c0 - b0), f1 = (int)(c1 - b1);
     int T0, T1;
@@ -2014,18 +2037,20 @@ __device__ __forceinline__ uint2 lc_summary(const TF &tf, double mt, bool force_
         T1 = wave_sum_i(s1);
     } else T0 = T1 = wave_sum_i(f0);
     tsum = (double)T0 * (double)ss_float((ex - 23u) << 23);
-    return make_uint2((uint32_t)T0, (ex << 24) | LC_VALID | ((uint32_t)(T1 - T0 + 0x8000) & 0xffffu));
+    const uint32_t hi = (ex << 24) | LC_VALID | ((uint32_t)(T1 - T0 + 0x8000) & 0xffffu);
+    return ((unsigned long long)hi << 32) | (uint32_t)T0;
 }
 
-// level 2: the accumulator m taken through tiles [0, nt) of a round (records rec[0 .. nt)); eval(tile, m) evaluates
-// one tile from the true accumulator.  One wave.
+// level 2: the accumulator m taken through tiles [0, nt) (records rec[0 .. nt)); eval(tile, m) evaluates one tile from
+// the true accumulator.  One wave.
 template <typename EVAL>
-__device__ inline float lc_compose(float m, const uint2 *rec, int nt, uint32_t &n_true, EVAL eval) {
+__device__ inline float lc_compose(float m, const unsigned long long *rec, int nt, uint32_t &n_true, EVAL eval) {
     const int lane = lane_id();
     for (int g0 = 0; g0 < nt; g0 += 64) {
         const int gn = nt - g0 < 64 ? nt - g0 : 64;
-        const uint2 rc = lane < gn ? rec[g0 + lane] : make_uint2(0u, 0u);
-        const int t0 = (int)rc.x, t1 = t0 + (int)(rc.y & 0xffffu) - 0x8000;
+        const unsigned long long rc = lane < gn ? lc_ld(rec + g0 + lane) : 0ull;
+        const uint32_t rhi = (uint32_t)(rc >> 32);
+        const int t0 = (int)(uint32_t)rc, t1 = t0 + (int)(rhi & 0xffffu) - 0x8000;
         int skip = 0;
         while (skip < gn) {
             m = ss_uniform(m);
@@ -2033,7 +2058,7 @@ __device__ inline float lc_compose(float m, const uint2 *rec, int nt, uint32_t &
             const uint32_t ex = (mb >> 23) & 0xffu;
             const bool live = lane >= skip && lane < gn;
             // (a record carries a binade in 27 .. 227 or is marked: a negative, tiny, huge or non-finite m matches none)
-            const bool okl = live && !(mb >> 31) && (rc.y & LC_VALID) && (rc.y >> 24) == ex;
+            const bool okl = live && !(mb >> 31) && (rhi & LC_VALID) && (rhi >> 24) == ex;
             const unsigned long long badm = __ballot(live && !okl);
             const int fb = badm ? (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)badm) - 1) : gn;
             int fail = fb;
@@ -2064,92 +2089,80 @@ __device__ inline float lc_compose(float m, const uint2 *rec, int nt, uint32_t &
 // One stage (one or two sums over the same tiles) of a long read.  SRC supplies the tiles:
 //   NCH                      sums per stage
 //   seek(t) / ahead(t, te) / next()   streaming: position at tile t; issue the loads of tile t + 1 (< te); step
-//   terms(t, f)              calls f(Ix<c>, term functor of chain c) for the current tile, c = 0 .. NCH - 1; the functors
-//                            mask what lies outside the region and carry the chain's orientation
-//   eval(c, t, m)            chain c's tile t from the true (oriented) accumulator m
-//   flip(c)                  from now on chain c runs on the negated terms
-// Returns the SIGNED sums in out[].  All 16 waves call it (workgroup barriers inside).
+//   terms(t, f)              calls f(Ix<c>, term functor of sum c) for the current tile, c = 0 .. NCH - 1; the functors
+//                            mask what lies outside the region and carry the sum's orientation
+//   eval(c, t, m)            sum c's tile t from the true (oriented) accumulator m
+//   flip(c) / negated(c)     from now on sum c runs on the negated terms / does it?
+// Returns the SIGNED sums in out[].  Every wave of the read's LC_PARTS workgroups calls it (barriers inside).
 template <typename SRC>
-__device__ inline void lc_stage(SRC &src, LcLds *L, int ntiles, float (&out)[2]) {
+__device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2], uint32_t &n_true_out) {
     constexpr int N = SRC::NCH;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    __syncthreads();  // (the previous stage's readers of L are done)
-    if (threadIdx.x < 2) L->m[threadIdx.x] = 0.0f;
-    if (threadIdx.x == 0) L->n_true = 0u;
-    __syncthreads();
-    for (int R0 = 0; R0 < ntiles; R0 += LC_TILES) {
-        const int R1 = ntiles - R0 < LC_TILES ? ntiles : R0 + LC_TILES;
-        const int per = (R1 - R0 + LC_WAVES - 1) / LC_WAVES;
-        const int ta = R0 + wv * per < R1 ? R0 + wv * per : R1, te = ta + per < R1 ? ta + per : R1;
-        // ---- pass A: the sum of the terms of this wave's tiles (a double per lane; the prediction needs no more)
-        double acc[N];
+    const int gw = cx.part * LC_WG_WAVES + wv;  // this wave among the read's LC_WAVES
+    const int per = (ntiles + LC_WAVES - 1) / LC_WAVES;
+    const int ta = gw * per < ntiles ? gw * per : ntiles, te = ta + per < ntiles ? ta + per : ntiles;
+    // ---- pass A: the sum of the terms of this wave's tiles (a double per lane; the prediction needs no more)
+    double acc[N];
 #pragma unroll
-        for (int c = 0; c < N; ++c) acc[c] = 0.0;
-        if (ta < te) {
-            src.seek(ta);
-            for (int t = ta; t < te; ++t) {
-                src.ahead(t, te);
-                src.terms(t, [&](auto ix, const auto &tf) {
-                    constexpr int c = decltype(ix)::v;
-                    float v = 0.0f;
-                    ss_native_terms<0>(v, tf);
-                    acc[c] += (double)v;
-                });
-                src.next();
-            }
+    for (int c = 0; c < N; ++c) acc[c] = 0.0;
+    if (ta < te) {
+        src.seek(ta);
+        for (int t = ta; t < te; ++t) {
+            src.ahead(t, te);
+            src.terms(t, [&](auto ix, const auto &tf) {
+                constexpr int c = decltype(ix)::v;
+                float v = 0.0f;
+                ss_native_terms<0>(v, tf);
+                acc[c] += (double)v;
+            });
+            src.next();
         }
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-            const double tot = wave_sum_d(acc[c]);
-            if (lane == 0) L->seg_tot[wv][c] = tot;
-        }
-        __syncthreads();
-        // the chain is oriented by the sign of the read's first round (as the wave kernels orient it by the sign of the
-        // accumulator): non-negative terms are what the summaries cover
-        double mt[N];
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-            double before = 0.0, all = 0.0;
-            for (int w = 0; w < LC_WAVES; ++w) {
-                const double v = L->seg_tot[w][c];
-                before += w < wv ? v : 0.0;
-                all += v;
-            }
-            double sgn = 1.0;
-            if (R0 == 0 && all < 0.0) { src.flip(c); sgn = -1.0; }
-            mt[c] = (double)L->m[c] + sgn * before;
-        }
-        __syncthreads();  // (seg_tot and m are read: the next round's pass A and level 2 may write them)
-        // ---- pass B: the tiles' summaries
-        if (ta < te) {
-            src.seek(ta);
-            for (int t = ta; t < te; ++t) {
-                src.ahead(t, te);
-                src.terms(t, [&](auto ix, const auto &tf) {
-                    constexpr int c = decltype(ix)::v;
-                    double ts;
-                    const uint2 rc = lc_summary(tf, mt[c], t == 0, ts);
-                    if (lane == 0) L->rec[c][t - R0] = rc;
-                    mt[c] += ts;
-                });
-                src.next();
-            }
-        }
-        __syncthreads();
-        // ---- level 2
-        if (wv == 0) {
-            uint32_t n_true = 0u;
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const float m = lc_compose(L->m[c], L->rec[c], R1 - R0, n_true, [&](int t, float mm) { return src.eval(c, R0 + t, mm); });
-                if (lane == 0) L->m[c] = m;
-            }
-            if (lane == 0) L->n_true += n_true;
-        }
-        __syncthreads();
     }
 #pragma unroll
-    for (int c = 0; c < N; ++c) out[c] = ss_signed(L->m[c], src.negated(c));
+    for (int c = 0; c < N; ++c) {
+        const double tot = wave_sum_d(acc[c]);
+        if (lane == 0) lc_st(&cx.w->seg_tot[gw][c], (unsigned long long)__double_as_longlong(tot));
+    }
+    lc_barrier(cx);
+    // the sum is oriented by the sign of the read's total (as the wave kernels orient it by the sign of the
+    // accumulator): non-negative terms are what the summaries cover
+    double mt[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const double v = __longlong_as_double((long long)lc_ld(&cx.w->seg_tot[lane][c]));  // (LC_WAVES == 64 lanes)
+        const double before = wave_sum_d(lane < gw ? v : 0.0), all = wave_sum_d(v);
+        if (all < 0.0) { src.flip(c); mt[c] = -before; }
+        else mt[c] = before;
+    }
+    // ---- pass B: the tiles' summaries
+    if (ta < te) {
+        src.seek(ta);
+        for (int t = ta; t < te; ++t) {
+            src.ahead(t, te);
+            src.terms(t, [&](auto ix, const auto &tf) {
+                constexpr int c = decltype(ix)::v;
+                double ts;
+                const unsigned long long rc = lc_summary(tf, mt[c], t == 0, ts);
+                if (lane == 0) lc_st(cx.rec[c] + t, rc);
+                mt[c] += ts;
+            });
+            src.next();
+        }
+    }
+    lc_barrier(cx);
+    // ---- level 2: wave c of the read's first workgroup composes sum c
+    if (cx.part == 0 && wv < N) {
+        uint32_t n_true = 0u;
+        const float m = lc_compose(0.0f, cx.rec[wv], ntiles, n_true, [&](int t, float mm) { return src.eval(wv, t, mm); });
+        if (lane == 0) {
+            lc_st(reinterpret_cast<uint32_t *>(&cx.w->m[wv]), ss_bits(m));
+            atomicAdd(&cx.w->n_true, n_true);
+        }
+    }
+    lc_barrier(cx);
+#pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = ss_signed(ss_float(lc_ld(reinterpret_cast<const uint32_t *>(&cx.w->m[c]))), src.negated(c));
+    n_true_out = lc_ld(&cx.w->n_true);
 }
 
 // ---- the tile sources
@@ -2285,24 +2298,39 @@ struct SrcRoll {  // jnnv2: the rolling means of ADW clamped samples, then their
 };
 
 enum { LC_STAT = 0, LC_JNN = 1, LC_ADAPT = 2 };
-// lists the reads of long_min samples or more (any order)
+// lists the reads of long_min samples or more (any order) and gives each its tile records
 __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.b.n_reads || a.b.lengths[r] < a.long_min) return;
+    if (r >= a.b.n_reads) return;
+    const uint32_t len = a.b.lengths[r];
+    if (len < a.long_min) return;
     const uint32_t i = atomicAdd(&a.long_hdr->n_long, 1u);
-    if (i < LC_CAP) {
-        a.long_list[i] = r;
-        a.longs[i].read = r;
-        a.longs[i].valid = 0u;
-    }
+    if (i >= LC_CAP) return;
+    const uint32_t need = (len + 7u) / SS_TILE + 2u;  // tiles of the read from an 8-sample boundary in front of it
+    const uint32_t off = atomicAdd(&a.long_hdr->pool_used, need);
+    a.long_list[i] = r;
+    LongSums *o = a.longs + i;
+    o->read = r;
+    o->valid = 0u;
+    o->rec_off = off + need <= a.long_pool_tiles ? off : 0xffffffffu;  // (no room: the read runs on one wave as before)
+    a.long_work[i].arrive = 0u;
+    a.long_work[i].n_true = 0u;
 }
 template <int KIND>
-__global__ __launch_bounds__(LC_WAVES * 64) void k_long_chains(StatArgs a, float std_scale) {
-    __shared__ LcLds L;
+__global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, float std_scale) {
     const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
-    for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+    const uint32_t groups = gridDim.x / LC_PARTS;
+    for (uint32_t i = blockIdx.x / LC_PARTS; i < n_long; i += groups) {
+        LongSums *o = a.longs + i;
+        if (o->rec_off == 0xffffffffu) continue;
         const uint32_t r = a.long_list[i];
         const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+        LcCtx cx;
+        cx.w = a.long_work + i;
+        cx.rec[0] = a.long_pool + o->rec_off;
+        cx.rec[1] = a.long_pool + a.long_pool_tiles + o->rec_off;
+        cx.phase = 0u;
+        cx.part = (int)(blockIdx.x % LC_PARTS);
         float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
         uint32_t tiles = 0u, n_true = 0u;
         if (KIND == LC_STAT) {
@@ -2310,24 +2338,20 @@ __global__ __launch_bounds__(LC_WAVES * 64) void k_long_chains(StatArgs a, float
             const float nf = (float)(int)g.len;
             SrcStatSums src1;
             src1.init(a.b, g, sc);
-            lc_stage(src1, &L, src1.wr.ntiles, s1);
-            n_true += L.n_true;
+            lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
             SrcStatDevs src2;
             src2.wr = src1.wr; src2.sc = sc; src2.mraw = s1[0] / nf; src2.mpa = s1[1] / nf;
-            lc_stage(src2, &L, src2.wr.ntiles, s2);
-            n_true += L.n_true;
+            lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
             tiles = 4u * (uint32_t)src1.wr.ntiles;
         } else if (KIND == LC_JNN) {
             if (std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums)
                 const float nf = (float)(int)g.len;
                 SrcClamp<false> src1;
                 src1.wr.init(a.b, g); src1.mean = 0.0f;
-                lc_stage(src1, &L, src1.wr.ntiles, s1);
-                n_true += L.n_true;
+                lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
                 SrcClamp<true> src2;
                 src2.wr = src1.wr; src2.mean = s1[0] / nf;
-                lc_stage(src2, &L, src2.wr.ntiles, s2);
-                n_true += L.n_true;
+                lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
             }
         } else {
@@ -2336,24 +2360,20 @@ __global__ __launch_bounds__(LC_WAVES * 64) void k_long_chains(StatArgs a, float
                 const float mf = (float)(int)m;
                 SrcRoll<false> src1;
                 src1.wr.init(a.b, Region{g.start, m}); src1.mean = 0.0f;
-                lc_stage(src1, &L, src1.wr.ntiles, s1);
-                n_true += L.n_true;
+                lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
                 SrcRoll<true> src2;
                 src2.wr = src1.wr; src2.mean = s1[0] / mf;
-                lc_stage(src2, &L, src2.wr.ntiles, s2);
-                n_true += L.n_true;
+                lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
             }
         }
-        if (threadIdx.x == 0) {
-            LongSums *o = a.longs + i;
+        if (cx.part == 0 && threadIdx.x == 0) {
             o->s1[0] = s1[0]; o->s1[1] = s1[1];
             o->s2[0] = s2[0]; o->s2[1] = s2[1];
             o->valid = 1u;
             atomicAdd(&a.long_hdr->n_tiles, tiles);
             atomicAdd(&a.long_hdr->n_true, n_true);
         }
-        __syncthreads();
     }
 }
 
@@ -2397,34 +2417,55 @@ int launch_order(const uint32_t *lengths, uint32_t nr, uint32_t *order, uint32_t
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
-size_t long_workspace_bytes() { return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums)); }
+// the tile records: 8 bytes per tile and sum for the long reads of the batch, at most LC_POOL_TILES tiles
+static uint32_t long_pool_tiles(uint64_t n_samples, uint32_t max_read_len) {
+    if (max_read_len < LC_LONG_MIN_FLOOR) return 0u;
+    const uint64_t most = n_samples / SS_TILE + 2ull * (n_samples / LC_LONG_MIN_FLOOR < LC_CAP ? n_samples / LC_LONG_MIN_FLOOR : LC_CAP) + 2ull;
+    return (uint32_t)(most < LC_POOL_TILES ? most : LC_POOL_TILES);
+}
+size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len) {
+    return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork)) +
+           (size_t)long_pool_tiles(n_samples, max_read_len) * 16;
+}
 int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st) {
     a.long_hdr = nullptr;
     a.long_list = nullptr;
     a.longs = nullptr;
+    a.long_work = nullptr;
+    a.long_pool = nullptr;
+    a.long_pool_tiles = 0u;
     a.long_min = 0u;
     const uint32_t lm = opt_long_min <= 0 ? LC_LONG_MIN
                                           : ((uint32_t)opt_long_min < LC_LONG_MIN_FLOOR ? LC_LONG_MIN_FLOOR : (uint32_t)opt_long_min);
     const size_t off = order_workspace_bytes(a.b.n_reads);
-    if (!ws || ws_bytes < off + long_workspace_bytes() || (reinterpret_cast<uintptr_t>(ws) & 3u)) return SGK_OK;
+    if (!ws || ws_bytes < off + long_workspace_bytes(0, 0) || (reinterpret_cast<uintptr_t>(ws) & 7u)) return SGK_OK;
     char *base = static_cast<char *>(ws) + off;
-    if (opt_long_min < 0 || a.b.max_read_len < lm) {  // no long read in this call: sgk_stat_long_status says so
-        SGK_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
+    const uint32_t pool = long_pool_tiles(a.b.n_samples, a.b.max_read_len);
+    if (opt_long_min < 0 || a.b.max_read_len < lm || pool == 0u || ws_bytes < off + long_workspace_bytes(a.b.n_samples, a.b.max_read_len)) {
+        SGK_HIP_TRY(hipMemsetAsync(base, 0, 16, st));  // no long read in this call: sgk_stat_long_status says so
         return SGK_OK;
     }
     a.long_hdr = reinterpret_cast<LongHdr *>(base);
-    a.long_list = reinterpret_cast<uint32_t *>(base + sizeof(LongHdr));
-    a.longs = reinterpret_cast<LongSums *>(base + sizeof(LongHdr) + (size_t)LC_CAP * 4);
+    base += sizeof(LongHdr);
+    a.longs = reinterpret_cast<LongSums *>(base);
+    base += (size_t)LC_CAP * sizeof(LongSums);
+    a.long_work = reinterpret_cast<LongWork *>(base);
+    base += (size_t)LC_CAP * sizeof(LongWork);
+    a.long_pool = reinterpret_cast<unsigned long long *>(base);
+    base += (size_t)pool * 16;
+    a.long_list = reinterpret_cast<uint32_t *>(base);
+    a.long_pool_tiles = pool;
     a.long_min = lm;
     SGK_HIP_TRY(hipMemsetAsync(a.long_hdr, 0, sizeof(LongHdr), st));
     hipLaunchKernelGGL(k_long_list, dim3((a.b.n_reads + 255) / 256), dim3(256), 0, st, a);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
-// workgroups of k_long_chains: one per long read the batch can hold, at most one per CU
+// workgroups of k_long_chains: LC_PARTS per long read the batch can hold, all resident at once (at most 64 reads at a
+// time: 1 024 workgroups of 256 threads; further long reads follow in the same workgroups)
 static uint32_t long_grid(const StatArgs &a) {
     const uint64_t most = a.b.n_samples / a.long_min;
-    return most < 1 ? 1u : (most > 256 ? 256u : (uint32_t)most);
+    return (uint32_t)(most < 1 ? 1 : (most > 64 ? 64 : most)) * LC_PARTS;
 }
 int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
     a.order = nullptr;
@@ -2472,7 +2513,7 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         return SGK_OK;
     }
     if (a.longs) {
-        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
         SGK_HIP_TRY(hipGetLastError());
     }
     if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
@@ -2491,7 +2532,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
         if (a.longs && p.std_scale > 0.0f) {
-            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WAVES * 64, a, p.std_scale);
+            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WG_WAVES * 64, a, p.std_scale);
             SGK_HIP_TRY(hipGetLastError());
         }
         StatArgs aw = a;
@@ -2512,7 +2553,7 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
@@ -2542,7 +2583,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WAVES * 64, a, 0.0f);
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--ragged", type=float, default=0.0, help="sigma of log-normal read lengths with mean --read-len "
                     "(0: all reads --read-len samples)")
     ap.add_argument("--sorted", type=int, default=0, help="1: ragged reads laid out longest first")
+    ap.add_argument("--one-long", type=int, default=0, help="N > 0: the batch's middle read has N samples (the others "
+                    "keep their length): what a single very long read costs the batch")
     args = ap.parse_args()
     import torch
     from sigtk_amd import api, device
@@ -36,13 +38,19 @@ def main():
         lens = np.clip(lens, 2500, 16 * args.read_len).astype(np.int64)
         if args.sorted:
             lens = np.sort(lens)[::-1].copy()
+    if args.one_long > 0:
+        import numpy as np
+        if lens is None:
+            lens = np.full(args.reads, args.read_len, dtype=np.int64)
+        lens[args.reads // 2] = args.one_long
     b = device.synth_reads(args.reads, args.read_len, seed=2, kind=args.rna, device=dev, lengths=lens)
     S, R = b.total_samples, b.n_reads
     pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=dev)
     segs = device.SegArena(b)
 
-    def run(name, fn, alg_bytes):
+    def run(name, fn, alg_bytes, long_ws=None):
         fn(); torch.cuda.synchronize()
+        ls = device.long_status(b, ws=long_ws) if long_ws is not None else None
         L.sgk_profile_reset(); L.sgk_profile_enable(1)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -55,11 +63,16 @@ def main():
         print(json.dumps({"subtool": name, "reads": R, "samples": S, "ms": round(dt * 1e3, 3),
                           "samples_per_s": round(S / dt, 1), "reads_per_s": round(R / dt, 1),
                           "algorithmic_GBps": round(alg_bytes / dt / 1e9, 1),
-                          "hbm_frac": round(alg_bytes / dt / 1e9 / 8000.0, 4), "kernels_ms": prof}), flush=True)
+                          "hbm_frac": round(alg_bytes / dt / 1e9 / 8000.0, 4), "kernels_ms": prof,
+                          "longest_read": int(b.max_read_len), "stat_long_min": int(api.STAT_OPTIONS.long_min),
+                          "long_reads": None if ls is None else {"reads": ls.n_long_reads, "tile_sums": ls.n_tiles,
+                                                                 "evaluated_from_true_accumulator": ls.n_true_tiles}}),
+              flush=True)
 
     run("pa", lambda: device.pa(b, pa_out), 6 * S)
-    run("stat", lambda: device.stat(b), 2 * S + 32 * R)
-    run("stat+pa", lambda: device.stat_pa(b, pa_out), 6 * S + 32 * R)   # BASELINE config 4 (fused)
+    run("stat", lambda: device.stat(b), 2 * S + 32 * R, device._workspace(b, "sgk_stat_workspace_bytes"))
+    run("stat+pa", lambda: device.stat_pa(b, pa_out), 6 * S + 32 * R,   # BASELINE config 4 (fused)
+        device._workspace(b, "sgk_stat_workspace_bytes"))
     if args.pipeline:
         # BASELINE config 5: pa -> event -> stat over the same resident batch (pA is not materialised for the
         # event / stat kernels: they scale on the fly; the fused stat+pa pass writes it once)
@@ -71,8 +84,8 @@ def main():
             device.stat_pa(b, pa_out)
             device.event(b, arena, args.rna)
         run("pa->event->stat", pipe, 2 * S + 16 * E + 72 * R)
-    run("jnn", lambda: device.jnn(b, segs, args.rna), 2 * S)
-    run("prefix", lambda: device.prefix(b, args.rna, 0), 2 * S + 48 * R)
+    run("jnn", lambda: device.jnn(b, segs, args.rna), 2 * S, segs.ws)
+    run("prefix", lambda: device.prefix(b, args.rna, 0), 2 * S + 48 * R, device._workspace(b, "sgk_prefix_workspace_bytes"))
 
 
 if __name__ == "__main__":
