@@ -24,6 +24,7 @@ struct StatArgs {
     struct LongSums *longs;      // LC_CAP records, entry i belongs to read long_list[i]
     struct LongWork *long_work;  // LC_CAP blocks the workgroups of a long read meet in
     unsigned long long *long_pool;  // tile records: [0, long_pool_tiles) of the first sum, then of the second
+    uint32_t *long_hist;         // stat: LC_CAP window histograms of LC_HIST_BINS bins
     uint32_t long_pool_tiles;
     uint32_t long_min;           // reads of at least this many samples are long
 };
@@ -58,7 +59,8 @@ struct LongWork {        // what the workgroups of one long read exchange (agent
     unsigned long long seg_tot[LC_WAVES][2];  // pass A: sum of the terms of a wave's tiles (a double's bits)
 };
 static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64 && sizeof(LongWork) == 16 + 16 * LC_WAVES, "long-read workspace layout");
-constexpr uint32_t LC_CAP = 1024;             // long reads per batch that get a record (the rest run as before)
+constexpr uint32_t LC_CAP = 512;              // long reads per batch that get a record (the rest run as before)
+constexpr uint32_t LC_HIST_BINS = 2048;       // stat's window histogram (WH_BINS)
 constexpr uint32_t LC_POOL_TILES = 1u << 20;  // tile records per sum (2^30 samples of long reads; 16 MB)
 constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
 constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for

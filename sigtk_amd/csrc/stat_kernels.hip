@@ -445,6 +445,7 @@ __device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
 // are flagged (`reserved`) and taken by k_median.  Ragged batches cost what their samples cost: a wave is busy for the
 // length of ITS read, not for the longest read among 64 neighbours as in the lane-per-read kernels above.
 constexpr int WH_BINS = 2048;
+static_assert(WH_BINS == (int)LC_HIST_BINS, "the long reads' histograms in the workspace");
 constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_POLYA = 2u;
 
 struct WaveTile {
@@ -611,128 +612,60 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
         mb = ss_finish<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), wb, skb, cb);
 }
 
-#ifndef SGK_STAT_WAVES
-#define SGK_STAT_WAVES 4  // waves per SIMD the register allocation aims at (5: spills, measured slower)
-#endif
-template <int MODE, bool PA>
-__global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
-    __shared__ uint32_t hist_all[4][WH_BINS];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
-    if (widx >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
-    const uint32_t r = a.order ? a.order[widx] : widx;
-    uint32_t *hist = hist_all[wv];
-    const Region g = get_region(MODE, a.b, a.prefix, r);
-    const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
-    WaveRead wr;
-    wr.init(a.b, g);
-    const float nf = (float)(int)g.len;
-    // a long read's four sums were evaluated by k_long_chains: this wave walks the read for the rest
-    const LongSums *lg = MODE == REG_WHOLE ? find_long(a, r, g.len) : nullptr;
-#ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
-    SsCount counts[4] = {};
-#define SS_CNT(i) (&counts[i])
-#else
-#define SS_CNT(i) nullptr
-#endif
-
-    // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative); fused stat + pa: the pA of
-    // every sample is written here, under the lighter arithmetic of the two passes
-    // (both chains: a read whose running raw sum is negative -- signed ADC codes -- would otherwise fail the fast
-    // walk's sign test on every tile and be added term by term)
-    float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
-    int sraw = 0;
-    if (PA || !lg) {
-        WaveTile cur, nxt;
-        if (wr.ntiles > 0) wr.load(cur, 0);
-        float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
-        for (int t = 0; t < wr.ntiles; ++t) {
-            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
-            int q_lo, q_hi;
-            wr.range(t, 0, q_lo, q_hi);
-            const bool pa_interior = q_lo == 0 && q_hi == SS_TILE;
-            const Scale so = {sc.offf, sc.unit * sg};
-            if (PA) {
-                // pA of every sample, written as whole cache lines: the tile is read once more as 4 x 256 samples with
-                // 8 bytes per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the chains' layout,
-                // 64 bytes per lane, would make every store instruction touch 32 lines partially)
+// pA of every sample of tile t, written as whole cache lines: the tile is read once more as 4 x 256 samples with 8 bytes
+// per lane (L2 hits) so that a store instruction covers 1 KB contiguously (the sums' layout, 64 bytes per lane, would make
+// every store instruction touch 32 lines partially).  pa_dst: the pA array at the region's 8-sample base (wr.rb).
+__device__ __forceinline__ void pa_write_tile(const WaveRead &wr, int t, const Scale &sc, float *pa_dst) {
+    const int lane = lane_id();
+    int q_lo, q_hi;
+    wr.range(t, 0, q_lo, q_hi);
+    const bool pa_interior = q_lo == 0 && q_hi == SS_TILE;
 #pragma unroll 1
-                for (int sub = 0; sub < SS_TILE / 256; ++sub) {
-                    const int qs = sub * 256 + lane * 4;
-                    int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
-                    const int64_t last = wr.n_total - 4;
-                    pp = pp < last ? pp : last;
-                    const uint2 rw = *reinterpret_cast<const uint2 *>(wr.samples + pp);
-                    const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
-                                                 to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
-                    float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
-                    if (pa_interior) *reinterpret_cast<float4 *>(dst) = o;
-                    else {
-                        if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
-                        if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
-                        if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
-                        if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
-                    }
-                }
-            }
-            if (!lg) {
-                ss_tile2<true>(
-                    m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
-                    [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
-                if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
-                if (m_raw < 0.0f) { m_raw = -m_raw; sraw = ~sraw; }
-            }
-            cur = nxt;
+    for (int sub = 0; sub < SS_TILE / 256; ++sub) {
+        const int qs = sub * 256 + lane * 4;
+        int64_t pp = wr.rb + (int64_t)t * SS_TILE + qs;
+        const int64_t last = wr.n_total - 4;
+        pp = pp < last ? pp : last;
+        const uint2 rw = *reinterpret_cast<const uint2 *>(wr.samples + pp);
+        const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
+                                     to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
+        float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
+        if (pa_interior) *reinterpret_cast<float4 *>(dst) = o;
+        else {
+            if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
+            if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
+            if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
+            if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
         }
     }
-    // (a zero accumulator stands for +0: the reference's sum starts at +0 and x + (-x), +0 + -0 are +0 under
-    // round-to-nearest, whichever way the chain was oriented)
-    const float mraw = (lg ? lg->s1[0] : ss_signed(m_raw, sraw != 0)) / nf;
-    const float mpa = (lg ? lg->s1[1] : ss_signed(m_pa, sg < 0.0f)) / nf;
-
-    // ---- pass 2: squared deviations, window histogram, pA
+}
+// the histogram window of a read: WH_BINS raw values around its mean
+__device__ __forceinline__ int hist_window_lo(float mraw) {
+    const int c = (mraw == mraw) ? (int)fminf(fmaxf(mraw, -32768.0f), 32767.0f) : 0;
+    const int lo = c - WH_BINS / 2;
+    return lo < -32768 ? -32768 : (lo > 32768 - WH_BINS ? 32768 - WH_BINS : lo);
+}
+// this lane's 16 samples of a tile into the window histogram (LDS)
+template <bool INTERIOR>
+__device__ __forceinline__ void hist_tile(const WaveTile &cur, int q_lo, int q_hi, int lo, uint32_t *hist) {
+    auto each = [&]<int E>(int16_t v, bool valid) {
+        if (valid) {
+            int b = (int)v - lo;
+            b = b < 0 ? 0 : (b > WH_BINS - 1 ? WH_BINS - 1 : b);
+            atomicAdd(&hist[b], 1u);
+        }
+    };
+    wt_each_<0, INTERIOR>(cur, lane_id() * SS_SPL, q_lo, q_hi, each);
+}
+// The end of stat for one region, by one wave: the order statistics of ranks k (raw median) and, for a negative unit,
+// n-1-k (the pA median's raw value) from the window histogram `hist` (LDS, complete and visible to this wave), and the
+// record.  A median outside the window leaves the read flagged for k_median.
+template <int MODE>
+__device__ inline void stat_finish(const StatArgs &a, uint32_t r, const Region &g, const Scale &sc, int lo, const uint32_t *hist,
+                                   float mraw, float mpa, float sdraw, float sdpa) {
+    const int lane = lane_id();
     const int64_t k = g.len / 2;
     const bool mirrored = sc.unit < 0.0f && g.len - 1 - k != k;  // pA order is the reverse of the raw order
-    int c = (mraw == mraw) ? (int)fminf(fmaxf(mraw, -32768.0f), 32767.0f) : 0;
-    int lo = c - WH_BINS / 2;
-    lo = lo < -32768 ? -32768 : (lo > 32768 - WH_BINS ? 32768 - WH_BINS : lo);
-#pragma unroll
-    for (int i = 0; i < WH_BINS / 64; ++i) hist[i * 64 + lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float q_raw = 0.0f, q_pa = 0.0f;
-    {
-        WaveTile cur, nxt;
-        if (wr.ntiles > 0) wr.load(cur, 0);
-        for (int t = 0; t < wr.ntiles; ++t) {
-            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
-            int q_lo, q_hi;
-            wr.range(t, 0, q_lo, q_hi);
-            const bool interior = wr.interior(t);
-            const int q0 = lane * SS_SPL;
-            // histogram of the raw values; pA of every sample
-            auto each = [&]<int E>(int16_t v, bool valid) {
-                if (valid) {
-                    int b = (int)v - lo;
-                    b = b < 0 ? 0 : (b > WH_BINS - 1 ? WH_BINS - 1 : b);
-                    atomicAdd(&hist[b], 1u);
-                }
-            };
-            if (interior) wt_each_<0, true>(cur, q0, q_lo, q_hi, each);
-            else wt_each_<0, false>(cur, q0, q_lo, q_hi, each);
-            if (!lg)
-                ss_tile2<false>(
-                    q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
-                    [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));
-            cur = nxt;
-        }
-    }
-    if (lg) { q_raw = lg->s2[0]; q_pa = lg->s2[1]; }
-    const float sdraw = sqrtf(q_raw / nf), sdpa = sqrtf(q_pa / nf);
-
-    // ---- the order statistics of ranks k (raw median) and, for a negative unit, n-1-k (the pA median's raw value)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     constexpr int PER = WH_BINS / 64;
     uint32_t cnt[PER], lsum = 0u;
 #pragma unroll
@@ -754,12 +687,6 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
         const unsigned long long own = __ballot(rank >= excl && rank < incl);
         found[w] = own ? __builtin_amdgcn_readlane(bin, __builtin_amdgcn_readfirstlane(__ffsll((long long)own) - 1)) : 0;
     }
-#ifdef SGK_SS_COUNT
-    if (lane == 0 && r == 0)
-        for (int i = 0; i < 4; ++i)
-            printf("chain %d: tiles %u generic %u walks %u crossings %u composes %u serial %u\n", i, counts[i].tiles,
-                   counts[i].generic, counts[i].walks, counts[i].crossings, counts[i].composes, counts[i].serial);
-#endif
     const bool trusted = g.len > 0 && found[0] > 0 && found[0] < WH_BINS - 1 && found[1] > 0 && found[1] < WH_BINS - 1;
     if (lane == 0) {
         const int med = lo + found[0];
@@ -784,6 +711,93 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
             if (pending) a.prefix[r].reserved |= FLAG_MEDIAN_POLYA;
         }
     }
+}
+
+#ifndef SGK_STAT_WAVES
+#define SGK_STAT_WAVES 4  // waves per SIMD the register allocation aims at (5: spills, measured slower)
+#endif
+template <int MODE, bool PA>
+__global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
+    __shared__ uint32_t hist_all[4][WH_BINS];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
+    if (widx >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
+    const uint32_t r = a.order ? a.order[widx] : widx;
+    uint32_t *hist = hist_all[wv];
+    const Region g = get_region(MODE, a.b, a.prefix, r);
+    const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
+    WaveRead wr;
+    wr.init(a.b, g);
+    const float nf = (float)(int)g.len;
+    // a long read's record (and pA) is k_long_chains' work
+    if (MODE == REG_WHOLE && find_long(a, r, g.len)) return;
+#ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
+    SsCount counts[4] = {};
+#define SS_CNT(i) (&counts[i])
+#else
+#define SS_CNT(i) nullptr
+#endif
+
+    // ---- pass 1: sum of raw, sum of pA (oriented so that the running sum is non-negative); fused stat + pa: the pA of
+    // every sample is written here, under the lighter arithmetic of the two passes
+    // (both chains: a read whose running raw sum is negative -- signed ADC codes -- would otherwise fail the fast
+    // walk's sign test on every tile and be added term by term)
+    float m_raw = 0.0f, m_pa = 0.0f, sg = sc.unit < 0.0f ? -1.0f : 1.0f;
+    int sraw = 0;
+    {
+        WaveTile cur, nxt;
+        if (wr.ntiles > 0) wr.load(cur, 0);
+        float *pa_dst = PA ? a.pa_out + wr.rb : nullptr;
+        for (int t = 0; t < wr.ntiles; ++t) {
+            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+            const Scale so = {sc.offf, sc.unit * sg};
+            if (PA) pa_write_tile(wr, t, sc, pa_dst);
+            ss_tile2<true>(
+                m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
+                [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
+            if (m_pa < 0.0f) { m_pa = -m_pa; sg = -sg; }
+            if (m_raw < 0.0f) { m_raw = -m_raw; sraw = ~sraw; }
+            cur = nxt;
+        }
+    }
+    // (a zero accumulator stands for +0: the reference's sum starts at +0 and x + (-x), +0 + -0 are +0 under
+    // round-to-nearest, whichever way the chain was oriented)
+    const float mraw = ss_signed(m_raw, sraw != 0) / nf;
+    const float mpa = ss_signed(m_pa, sg < 0.0f) / nf;
+
+    // ---- pass 2: squared deviations, window histogram
+    const int lo = hist_window_lo(mraw);
+#pragma unroll
+    for (int i = 0; i < WH_BINS / 64; ++i) hist[i * 64 + lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float q_raw = 0.0f, q_pa = 0.0f;
+    {
+        WaveTile cur, nxt;
+        if (wr.ntiles > 0) wr.load(cur, 0);
+        for (int t = 0; t < wr.ntiles; ++t) {
+            if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
+            int q_lo, q_hi;
+            wr.range(t, 0, q_lo, q_hi);
+            if (wr.interior(t)) hist_tile<true>(cur, q_lo, q_hi, lo, hist);
+            else hist_tile<false>(cur, q_lo, q_hi, lo, hist);
+            ss_tile2<false>(
+                q_raw, q_pa, wr, cur, t, [&](auto b) { return TermDevRaw<decltype(b)::interior>{b, mraw}; },
+                [&](auto b) { return TermDevPa<decltype(b)::interior>{b, sc, mpa}; }, SS_CNT(2), SS_CNT(3));
+            cur = nxt;
+        }
+    }
+    const float sdraw = sqrtf(q_raw / nf), sdpa = sqrtf(q_pa / nf);
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#ifdef SGK_SS_COUNT
+    if (lane == 0 && r == 0)
+        for (int i = 0; i < 4; ++i)
+            printf("chain %d: tiles %u generic %u walks %u crossings %u composes %u serial %u\n", i, counts[i].tiles,
+                   counts[i].generic, counts[i].walks, counts[i].crossings, counts[i].composes, counts[i].serial);
+#endif
+    stat_finish<MODE>(a, r, g, sc, lo, hist, mraw, mpa, sdraw, sdpa);
 }
 
 // ---------------------------------------------------------------- jnn_core automaton (src/jnn.c:190-278)
@@ -2093,6 +2107,8 @@ __device__ inline float lc_compose(float m, const unsigned long long *rec, int n
 //                            mask what lies outside the region and carry the sum's orientation
 //   eval(c, t, m)            sum c's tile t from the true (oriented) accumulator m
 //   flip(c) / negated(c)     from now on sum c runs on the negated terms / does it?
+//   pass_a(t) / pass_b(t) / end_b()   what else the subtool does with the current tile in either pass, and once per
+//                            workgroup behind pass B (stat: pA output; window histogram)
 // Returns the SIGNED sums in out[].  Every wave of the read's LC_PARTS workgroups calls it (barriers inside).
 template <typename SRC>
 __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2], uint32_t &n_true_out) {
@@ -2115,6 +2131,7 @@ __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2]
                 ss_native_terms<0>(v, tf);
                 acc[c] += (double)v;
             });
+            src.pass_a(t);
             src.next();
         }
     }
@@ -2146,9 +2163,11 @@ __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2]
                 if (lane == 0) lc_st(cx.rec[c] + t, rc);
                 mt[c] += ts;
             });
+            src.pass_b(t);
             src.next();
         }
     }
+    src.end_b();
     lc_barrier(cx);
     // ---- level 2: wave c of the read's first workgroup composes sum c
     if (cx.part == 0 && wv < N) {
@@ -2172,6 +2191,9 @@ struct SrcTiles {  // streaming of the raw tiles of a region
     __device__ __forceinline__ void seek(int t) { wr.load(cur, t); }
     __device__ __forceinline__ void ahead(int t, int te) { if (t + 1 < te) wr.load(nxt, t + 1); }
     __device__ __forceinline__ void next() { cur = nxt; }
+    __device__ __forceinline__ void pass_a(int) {}
+    __device__ __forceinline__ void pass_b(int) {}
+    __device__ __forceinline__ void end_b() {}
     template <typename F>
     __device__ __forceinline__ void bases(int t, F f) const {  // f(TermBase) for the current tile
         const int q0 = lane_id() * SS_SPL;
@@ -2186,9 +2208,12 @@ struct SrcStatSums : SrcTiles {  // stat, stage 1: raw and pA (src/stat.h:17-33)
     Scale sc;
     int sraw;   // -1: the raw chain runs negated
     float sg;   // the pA chain's orientation times the sign of the unit (as in k_stat_wave)
-    __device__ void init(const sgk_batch_t &b, const Region &g, const Scale &s) {
+    float *pa_dst;  // fused stat + pa: the pA array at the region's base (or null)
+    __device__ void init(const sgk_batch_t &b, const Region &g, const Scale &s, float *pa_out) {
         wr.init(b, g); sc = s; sraw = 0; sg = s.unit < 0.0f ? -1.0f : 1.0f;
+        pa_dst = pa_out ? pa_out + wr.rb : nullptr;
     }
+    __device__ __forceinline__ void pass_a(int t) { if (pa_dst) pa_write_tile(wr, t, sc, pa_dst); }
     __device__ __forceinline__ void flip(int c) { if (c == 0) sraw = ~sraw; else sg = -sg; }
     __device__ __forceinline__ bool negated(int c) const { return c == 0 ? sraw != 0 : sg < 0.0f; }
     template <typename F>
@@ -2212,6 +2237,22 @@ struct SrcStatDevs : SrcTiles {  // stat, stage 2: squared deviations (src/stat.
     static constexpr int NCH = 2;
     Scale sc;
     float mraw, mpa;
+    int lo;            // window histogram: first raw value
+    uint32_t *hist;    // this workgroup's (LDS, zeroed)
+    uint32_t *ghist;   // the read's (workspace, zeroed): the workgroups add theirs
+    __device__ __forceinline__ void pass_b(int t) {
+        int q_lo, q_hi;
+        wr.range(t, 0, q_lo, q_hi);
+        if (wr.interior(t)) hist_tile<true>(cur, q_lo, q_hi, lo, hist);
+        else hist_tile<false>(cur, q_lo, q_hi, lo, hist);
+    }
+    __device__ __forceinline__ void end_b() {
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < WH_BINS; i += LC_WG_WAVES * 64) {
+            const uint32_t h = hist[i];
+            if (h) atomicAdd(&ghist[i], h);
+        }
+    }
     __device__ __forceinline__ void flip(int) {}
     __device__ __forceinline__ bool negated(int) const { return false; }
     template <typename F>
@@ -2270,6 +2311,9 @@ struct SrcRoll {  // jnnv2: the rolling means of ADW clamped samples, then their
     }
     __device__ __forceinline__ void ahead(int t, int te) { if (t + 1 < te) roll_load(wr, trn, ldn, t + 1); }
     __device__ __forceinline__ void next() { tr = trn; ld = ldn; }
+    __device__ __forceinline__ void pass_a(int) {}
+    __device__ __forceinline__ void pass_b(int) {}
+    __device__ __forceinline__ void end_b() {}
     __device__ __forceinline__ void totals(const WaveTile &a, const WaveTile &b, int t, int &T, int (&tot)[SS_SPL]) const {
         if (t == 0 && wr.skip > 0) roll_tile<true>(a, b, wr.skip, T, tot);
         else roll_tile<false>(a, b, 0, T, tot);
@@ -2318,6 +2362,7 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
 }
 template <int KIND>
 __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, float std_scale) {
+    __shared__ uint32_t hist[KIND == LC_STAT ? WH_BINS : 1];
     const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
     const uint32_t groups = gridDim.x / LC_PARTS;
     for (uint32_t i = blockIdx.x / LC_PARTS; i < n_long; i += groups) {
@@ -2336,13 +2381,26 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, fl
         if (KIND == LC_STAT) {
             const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
             const float nf = (float)(int)g.len;
+            uint32_t *ghist = a.long_hist + (size_t)i * WH_BINS;
+            for (int b = (int)threadIdx.x; b < WH_BINS / LC_PARTS; b += LC_WG_WAVES * 64) lc_st(&ghist[cx.part * (WH_BINS / LC_PARTS) + b], 0u);
+            for (int b = (int)threadIdx.x; b < WH_BINS; b += LC_WG_WAVES * 64) hist[b] = 0u;
             SrcStatSums src1;
-            src1.init(a.b, g, sc);
+            src1.init(a.b, g, sc, a.pa_out);
             lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
             SrcStatDevs src2;
             src2.wr = src1.wr; src2.sc = sc; src2.mraw = s1[0] / nf; src2.mpa = s1[1] / nf;
+            src2.lo = hist_window_lo(src2.mraw); src2.hist = hist; src2.ghist = ghist;
             lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
             tiles = 4u * (uint32_t)src1.wr.ntiles;
+            // the record: the read's histogram through this workgroup's LDS (everybody is behind the stage's last barrier)
+            if (cx.part == 0 && threadIdx.x < 64) {
+                constexpr int PER = WH_BINS / 64;
+                const int lane = lane_id();
+#pragma unroll
+                for (int b = 0; b < PER; ++b) hist[lane * PER + b] = lc_ld(&ghist[lane * PER + b]);
+                stat_finish<REG_WHOLE>(a, r, g, sc, src2.lo, hist, src2.mraw, src2.mpa, sqrtf(s2[0] / nf), sqrtf(s2[1] / nf));
+            }
+            __syncthreads();
         } else if (KIND == LC_JNN) {
             if (std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums)
                 const float nf = (float)(int)g.len;
@@ -2424,7 +2482,7 @@ static uint32_t long_pool_tiles(uint64_t n_samples, uint32_t max_read_len) {
     return (uint32_t)(most < LC_POOL_TILES ? most : LC_POOL_TILES);
 }
 size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len) {
-    return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork)) +
+    return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork) + LC_HIST_BINS * 4) +
            (size_t)long_pool_tiles(n_samples, max_read_len) * 16;
 }
 int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st) {
@@ -2433,6 +2491,7 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, h
     a.longs = nullptr;
     a.long_work = nullptr;
     a.long_pool = nullptr;
+    a.long_hist = nullptr;
     a.long_pool_tiles = 0u;
     a.long_min = 0u;
     const uint32_t lm = opt_long_min <= 0 ? LC_LONG_MIN
@@ -2453,6 +2512,8 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, h
     base += (size_t)LC_CAP * sizeof(LongWork);
     a.long_pool = reinterpret_cast<unsigned long long *>(base);
     base += (size_t)pool * 16;
+    a.long_hist = reinterpret_cast<uint32_t *>(base);
+    base += (size_t)LC_CAP * LC_HIST_BINS * 4;
     a.long_list = reinterpret_cast<uint32_t *>(base);
     a.long_pool_tiles = pool;
     a.long_min = lm;
