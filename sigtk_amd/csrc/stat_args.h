@@ -46,7 +46,7 @@ struct LongHdr {
 };
 struct LongSums {
     uint32_t read;
-    uint32_t valid;      // 1: s1 / s2 are final
+    uint32_t valid;      // 1: s1 / s2 are final; 2: and k_long_chains wrote the subtool's whole output for this read (stat, jnn)
     float s1[2];         // first-stage sums (stat: raw, pA; jnn: clamped raw; prefix: rolling means), signed
     float s2[2];         // second-stage sums (squared deviations from the first stage's means)
     uint32_t rec_off;    // the read's tile records in the pool (0xffffffff: none, the read runs on one wave)

@@ -67,6 +67,15 @@ __device__ inline Region get_region(int mode, const sgk_batch_t &b, const sgk_pr
     return g;
 }
 
+// what the workgroups of a long read exchange is written and read with agent-scope atomics
+__device__ __forceinline__ uint32_t lc_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long lc_ld(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lc_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lc_st(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // the record k_long_chains left for read r (wave-uniform; null: the wave evaluates the read's sums itself)
 __device__ inline const LongSums *find_long(const StatArgs &a, uint32_t r, int64_t len) {
     if (!a.longs || len < (int64_t)a.long_min) return nullptr;
@@ -730,7 +739,10 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     wr.init(a.b, g);
     const float nf = (float)(int)g.len;
     // a long read's record (and pA) is k_long_chains' work
-    if (MODE == REG_WHOLE && find_long(a, r, g.len)) return;
+    if (MODE == REG_WHOLE) {
+        const LongSums *lg = find_long(a, r, g.len);
+        if (lg && lg->valid == 2u) return;
+    }
 #ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
     SsCount counts[4] = {};
 #define SS_CNT(i) (&counts[i])
@@ -996,20 +1008,28 @@ constexpr int JW_BLOCK = 32;  // samples a lane takes per step of the chunked pa
 // The chunked pass of jnn_core shared by k_jnn_wave and k_polya_wave: in <=> lo_r < raw < hi_r; `candidate(x, y, c)`
 // is called, per lane in sample order, for every segment that ended after c >= keep_min samples.
 __device__ __forceinline__ int jnn_chunk_lanes(int64_t nq) { return nq >= 512 ? (nq / 256 >= 64 ? 64 : (int)(nq / 256)) : 1; }
+// (C chunks in all; this wave's lane l takes chunk gchunk0 + l: one wave per read has C <= 64 and gchunk0 = 0, the waves
+// of a long read share its C = 64 x waves chunks)
+// ... and of a long read on LC_WAVES waves: chunks of at least 512 samples, at most 64 per wave
+__device__ __forceinline__ int jnn_long_chunks(int64_t nq) {
+    const int64_t c = nq / 512;
+    const int lanes = jnn_chunk_lanes(nq);
+    return c > 64 * LC_WAVES ? 64 * LC_WAVES : (c > lanes ? (int)c : lanes);
+}
 template <typename CAND>
 __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi_r, int lo_r, int error, int keep_min,
-                                           CAND &candidate) {
+                                           CAND &candidate, int C, int gchunk0) {
     const int lane = lane_id();
     const int E1 = error + 1;
     // ---- chunks in q space (q = sample index + wr.skip; chunk bounds are multiples of 8 -> 16-byte aligned loads)
     const int64_t nq = wr.skip + n;
-    const int C = jnn_chunk_lanes(nq);
     const int64_t K = ((nq + C - 1) / C + 7) & ~(int64_t)7;
     const int LEAD = (E1 + 7) & ~7;
-    const bool active = lane < C;
-    const int64_t cs = (int64_t)lane * K, ce = cs + K;            // nominal chunk of this lane
-    int64_t qb = lane == 0 ? 0 : cs - LEAD;                      // where this lane starts reading
-    int runm = (lane == 0) ? -1 : 0, srchm = (active && lane != 0) ? -1 : 0;  // -1 / 0 lane masks
+    const int gc = gchunk0 + lane;
+    const bool active = gc < C;
+    const int64_t cs = (int64_t)gc * K, ce = cs + K;             // nominal chunk of this lane
+    int64_t qb = gc == 0 ? 0 : cs - LEAD;                        // where this lane starts reading
+    int runm = (gc == 0) ? -1 : 0, srchm = (active && gc != 0) ? -1 : 0;  // -1 / 0 lane masks
     int opn = 0, err = 0, run = 0, start = 0, oc = 0;
     // A block of 32 samples as bit masks (bit e: sample e is in / out of range; samples outside the read are neither).
     // The automaton goes from EVENT to event -- a segment opens at the next set bit of `inm`; it ends at the
@@ -1127,6 +1147,127 @@ __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi
 
 }
 
+// integer form of jnn_core's range test for thresholds top / bot (JnnAuto::init above), on the UNCLAMPED sample:
+// lo_i < clamp(v) < hi_i  <=>  lo_r < v < hi_r; keep_min: the shortest segment that can matter
+struct JnnThr {
+    int hi_r, lo_r, keep_min;
+};
+__device__ __forceinline__ JnnThr jnn_thresholds(float top, float bot, const JnnP &p) {
+    const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
+    const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
+    JnnThr t;
+    t.hi_r = hi_i <= 0 ? -40000 : (hi_i > 1200 ? 40000 : hi_i);
+    t.lo_r = lo_i >= 1200 ? 40000 : (lo_i < 0 ? -40000 : lo_i);
+    const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
+    t.keep_min = first_min_i < p.window ? first_min_i : p.window;
+    return t;
+}
+
+// The merge of the kept segments (src/jnn.c:246-258), 64 chunks per round, in chunk order.  A chunk's kept segments are
+// [its first candidate, if that is strong or the first candidate of the read] + its staged strong ones; a kept segment
+// opens a new merged segment iff its start is seg_dist or more behind the previous kept segment's end.  Between rounds
+// the carry holds the last kept segment (its end is written once the next kept segment turns out to open a new merged
+// one, or by jnn_merge_flush) and the number of merged segments so far.
+struct JnnCarry {
+    bool has, seen, overflow;  // a kept segment so far; a candidate so far; some slot range was too small
+    int y;                     // end of the last kept segment
+    uint32_t idx;              // merged segments opened so far
+};
+template <bool AGENT>
+__device__ __forceinline__ int jnn_ld(const int32_t *p) {
+    if constexpr (AGENT) return (int)lc_ld(reinterpret_cast<const uint32_t *>(p));
+    else return *p;
+}
+template <bool AGENT>  // AGENT: the staged segments were written by other workgroups (agent-scope atomics)
+__device__ inline void jnn_merge_round(JnnCarry &cy, int has_first, int fx, int fy, int fstrong, uint32_t cnt, uint32_t cap_l,
+                                       const int32_t *stage_x, const int32_t *stage_y, int seg_dist, int32_t *out_x,
+                                       int32_t *out_y, uint32_t half) {
+    const int lane = lane_id();
+    const unsigned long long hasf = __ballot(has_first != 0);
+    const int firstlane = (!cy.seen && hasf) ? __ffsll((long long)hasf) - 1 : -1;
+    const bool keep_first = has_first && (fstrong || lane == firstlane);
+    bool overflow = cnt > cap_l;
+    if (cnt > cap_l) cnt = cap_l;
+    const uint32_t kcnt = cnt + (keep_first ? 1u : 0u);
+    // y of the last kept segment of the nearest lane in front that has one (or the carry's)
+    int last_y_own = 0;
+    if (kcnt) last_y_own = cnt ? jnn_ld<AGENT>(stage_y + cnt - 1) : fy;
+    const unsigned long long nonempty = __ballot(kcnt != 0u);
+    const unsigned long long before = nonempty & ((1ull << lane) - 1ull);
+    const int src_prev = before ? 63 - __clzll((long long)before) : 0;
+    int prev_y_in = __shfl(last_y_own, src_prev, 64);
+    bool has_prev = before != 0ull;
+    if (!has_prev) { prev_y_in = cy.y; has_prev = cy.has; }
+    auto entry = [&](uint32_t k, int &x, int &y) {
+        if (keep_first) {
+            if (k == 0) { x = fx; y = fy; return; }
+            --k;
+        }
+        x = jnn_ld<AGENT>(stage_x + k); y = jnn_ld<AGENT>(stage_y + k);
+    };
+    // pass 1: how many merged segments start in this lane; is this lane's first kept segment one of them?
+    uint32_t nnew = 0u;
+    bool first_is_new = false;
+    {
+        int py = prev_y_in;
+        bool hp = has_prev;
+        for (uint32_t k = 0; k < kcnt; ++k) {
+            int x, y;
+            entry(k, x, y);
+            const bool nw = !hp || !(x - py < seg_dist);
+            if (k == 0) first_is_new = nw;
+            nnew += nw ? 1u : 0u;
+            py = y; hp = true;
+        }
+    }
+    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)nnew), base = cy.idx + incl - nnew;
+    const uint32_t total = (uint32_t)wave_last_i((int)incl);
+    // the end of the last kept segment in front of this round, if this round's first kept segment opens a new merged one
+    const int firstne = nonempty ? __ffsll((long long)nonempty) - 1 : -1;
+    if (cy.has && lane == firstne && first_is_new && cy.idx - 1u < half) out_y[cy.idx - 1u] = cy.y;
+    // is the kept segment behind this lane's last one the start of a new merged segment?  (the round's last kept
+    // segment: decided by the next round or the flush)
+    const unsigned long long after = lane == 63 ? 0ull : (nonempty & ~((2ull << lane) - 1ull));
+    const int src_next = after ? __ffsll((long long)after) - 1 : 0;
+    const bool next_new = __shfl(first_is_new ? 1 : 0, src_next, 64) != 0 && after != 0ull;
+    // pass 2: x of every segment that starts a merged one, y of every segment that ends one
+    {
+        int py = prev_y_in;
+        bool hp = has_prev;
+        uint32_t idx = base;  // merged segments started so far (in front of and inside this lane)
+        int x = 0, y = 0;
+        if (kcnt) entry(0, x, y);
+        for (uint32_t k = 0; k < kcnt; ++k) {
+            const bool nw = !hp || !(x - py < seg_dist);
+            if (nw) {
+                if (idx < half) out_x[idx] = x; else overflow = true;
+                ++idx;
+            }
+            int xn = 0, yn = 0;
+            bool ends;
+            if (k + 1 < kcnt) {
+                entry(k + 1, xn, yn);
+                ends = !(xn - y < seg_dist);
+            } else ends = next_new;
+            if (ends && idx - 1 < half) out_y[idx - 1] = y;
+            py = y; hp = true;
+            x = xn; y = yn;
+        }
+    }
+    if (nonempty) {
+        cy.y = __builtin_amdgcn_readlane(last_y_own, 63 - __clzll((long long)nonempty));
+        cy.has = true;
+    }
+    cy.idx += total;
+    cy.seen = cy.seen || hasf != 0ull;
+    cy.overflow = cy.overflow || __any(overflow);
+}
+// the end of the read's last kept segment; returns the number of merged segments (JNN_REDO_MARK: the slots did not do)
+__device__ inline uint32_t jnn_merge_flush(const JnnCarry &cy, int32_t *out_y, uint32_t half) {
+    if (cy.has && lane_id() == 0 && cy.idx - 1u < half) out_y[cy.idx - 1u] = cy.y;
+    return (cy.overflow || cy.idx > half) ? JNN_REDO_MARK : cy.idx;
+}
+
 __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;
@@ -1144,7 +1285,9 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
         const float nf = (float)(int)n;
         float s = 0.0f, q = 0.0f;
-        const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains
+        // a long read: k_long_chains evaluated its two sums (valid 1) or ran the whole of jnn (valid 2)
+        const LongSums *lg = find_long(a, r, n);
+        if (lg && lg->valid == 2u) return;
         if (lg) s = lg->s1[0];
         else {
             WaveTile cur, nxt;
@@ -1170,27 +1313,18 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
         top = mn + band;
         bot = mn - band;
     }
-    // integer form of the tests (JnnAuto::init above): in <=> lo_i < iv < hi_i for the clamped integer sample iv
-    const int hi_i = (top != top) ? -0x40000000 : (top > 4000.0f ? 4000 : (top < -4.0f ? -4 : (int)ceilf(top)));
-    const int lo_i = (bot != bot) ? 0x40000000 : (bot > 4000.0f ? 4000 : (bot < -4.0f ? -4 : (int)floorf(bot)));
-    // the same test on the UNCLAMPED sample: lo_i < clamp(v) < hi_i  <=>  lo_r < v < hi_r
-    const int hi_r = hi_i <= 0 ? -40000 : (hi_i > 1200 ? 40000 : hi_i);
-    const int lo_r = lo_i >= 1200 ? 40000 : (lo_i < 0 ? -40000 : lo_i);
-    const int first_min_i = (int)ceilf((float)p.window * p.stall_len);  // (float)c >= window * stall_len
-    const int keep_min = first_min_i < p.window ? first_min_i : p.window;
+    const JnnThr th = jnn_thresholds(top, bot, p);
 
     // ---- the automaton, in chunks between sync points (jnn_chunks); kept segments are staged in the upper half of the
     // read's slots (a part per lane), the merged segments go to the lower half
     const int64_t nq = wr.skip + n;
     const int C = jnn_chunk_lanes(nq);
-    // slots: kept segments are staged in the upper half, the merged segments go to the lower half
     const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
     const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
     int32_t *stage_x = a.seg_x + slot0 + half + (uint64_t)lane * capL, *stage_y = a.seg_y + slot0 + half + (uint64_t)lane * capL;
 
     int fx = 0, fy = 0, fstrong = 0, has_first = 0;
     uint32_t cnt = 0u;
-    bool overflow = false;
 
     // a segment that ended with c >= keep_min samples: the lane's first one is kept in registers (whether it is kept
     // depends on the lanes in front), later ones only matter if c >= window
@@ -1202,83 +1336,18 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
         if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
         else if (strong) {
             if (cnt < capL) { stage_x[cnt] = sx; stage_y[cnt] = sy; }
-            else overflow = true;
-            ++cnt;
+            ++cnt;  // (more than capL: jnn_merge_round reports the overflow)
         }
     };
-    jnn_chunks(wr, n, hi_r, lo_r, p.error, keep_min, candidate);
+    jnn_chunks(wr, n, th.hi_r, th.lo_r, p.error, th.keep_min, candidate, C, 0);
 
-    // ---- the kept segments in order: [a lane's first candidate, if it is strong or the first of the read] + its staged ones
-    const unsigned long long hasf = __ballot(has_first != 0);
-    const int firstlane = hasf ? __ffsll((long long)hasf) - 1 : -1;
-    const bool keep_first = has_first && (fstrong || lane == firstlane);
-    if (cnt > capL) cnt = capL;
-    const uint32_t kcnt = cnt + (keep_first ? 1u : 0u);
-    // y of the last kept segment of the nearest lane in front that has one
-    int last_y_own = 0;
-    if (kcnt) last_y_own = cnt ? stage_y[cnt - 1] : fy;
-    const unsigned long long nonempty = __ballot(kcnt != 0u);
-    const unsigned long long before = nonempty & ((1ull << lane) - 1ull);
-    const int src_prev = before ? 63 - __clzll((long long)before) : 0;
-    const int prev_y_in = __shfl(last_y_own, src_prev, 64);
-    const bool has_prev = before != 0ull;
-    auto entry = [&](uint32_t k, int &x, int &y) {
-        if (keep_first) {
-            if (k == 0) { x = fx; y = fy; return; }
-            --k;
-        }
-        x = stage_x[k]; y = stage_y[k];
-    };
-    // pass 1: how many merged segments start in this lane; is this lane's first kept segment one of them?
-    uint32_t nnew = 0u;
-    bool first_is_new = false;
-    {
-        int py = prev_y_in;
-        bool hp = has_prev;
-        for (uint32_t k = 0; k < kcnt; ++k) {
-            int x, y;
-            entry(k, x, y);
-            const bool nw = !hp || !(x - py < p.seg_dist);
-            if (k == 0) first_is_new = nw;
-            nnew += nw ? 1u : 0u;
-            py = y; hp = true;
-        }
-    }
-    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)nnew), base = incl - nnew;
-    const uint32_t total = (uint32_t)wave_last_i((int)incl);
-    // is the kept segment behind this lane's last one the start of a new merged segment (or absent)?
-    const unsigned long long after = lane == 63 ? 0ull : (nonempty & ~((2ull << lane) - 1ull));
-    const int src_next = after ? __ffsll((long long)after) - 1 : 0;
-    const bool next_new = __shfl(first_is_new ? 1 : 0, src_next, 64) != 0 || after == 0ull;
-    // pass 2: x of every segment that starts a merged one, y of every segment that ends one
-    {
-        int32_t *out_x = a.seg_x + slot0, *out_y = a.seg_y + slot0;
-        int py = prev_y_in;
-        bool hp = has_prev;
-        uint32_t idx = base;  // merged segments started so far (in front of and inside this lane)
-        int x = 0, y = 0;
-        if (kcnt) entry(0, x, y);
-        for (uint32_t k = 0; k < kcnt; ++k) {
-            const bool nw = !hp || !(x - py < p.seg_dist);
-            if (nw) {
-                if (idx < half) out_x[idx] = x; else overflow = true;
-                ++idx;
-            }
-            int xn = 0, yn = 0;
-            bool ends;
-            if (k + 1 < kcnt) {
-                entry(k + 1, xn, yn);
-                ends = !(xn - y < p.seg_dist);
-            } else ends = next_new;
-            if (ends && idx - 1 < half) out_y[idx - 1] = y;
-            py = y; hp = true;
-            x = xn; y = yn;
-        }
-    }
     // A lane's staging part is sized for chunks that end where they should; a read with too few sync points (a lane ran
     // on through many chunks and kept more segments than its part holds) is handed to the lane-per-read kernel instead
-    const bool giveup = __any(overflow) || total > half;
-    if (lane == 0) a.n_segs[r] = giveup ? JNN_REDO_MARK : total;
+    JnnCarry cy = {false, false, false, 0, 0u};
+    jnn_merge_round<false>(cy, has_first, fx, fy, fstrong, cnt, capL, stage_x, stage_y, p.seg_dist, a.seg_x + slot0,
+                           a.seg_y + slot0, half);
+    const uint32_t total = jnn_merge_flush(cy, a.seg_y + slot0, half);
+    if (lane == 0) a.n_segs[r] = total;
 }
 
 // ---------------------------------------------------------------- find_polya, one WAVE per read
@@ -1997,14 +2066,6 @@ struct Ix {
 };
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_last_d(wave_incl_scan_d(v)); }
 __device__ __forceinline__ int wave_sum_i(int v) { return wave_last_i(wave_incl_scan_i(v)); }
-__device__ __forceinline__ uint32_t lc_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long lc_ld(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void lc_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lc_st(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 struct LcCtx {
     LongWork *w;
     unsigned long long *rec[2];  // tile records of the two sums: T0 | (E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff) << 32
@@ -2361,7 +2422,7 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     a.long_work[i].n_true = 0u;
 }
 template <int KIND>
-__global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, float std_scale) {
+__global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, JnnP p) {
     __shared__ uint32_t hist[KIND == LC_STAT ? WH_BINS : 1];
     const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
     const uint32_t groups = gridDim.x / LC_PARTS;
@@ -2377,7 +2438,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, fl
         cx.phase = 0u;
         cx.part = (int)(blockIdx.x % LC_PARTS);
         float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
-        uint32_t tiles = 0u, n_true = 0u;
+        uint32_t tiles = 0u, n_true = 0u, done = 1u;  // done: 1 the sums, 2 the subtool's whole output for this read
         if (KIND == LC_STAT) {
             const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
             const float nf = (float)(int)g.len;
@@ -2401,8 +2462,9 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, fl
                 stat_finish<REG_WHOLE>(a, r, g, sc, src2.lo, hist, src2.mraw, src2.mpa, sqrtf(s2[0] / nf), sqrtf(s2[1] / nf));
             }
             __syncthreads();
+            done = 2u;
         } else if (KIND == LC_JNN) {
-            if (std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums)
+            if (p.std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums, launch_jnn does not come here)
                 const float nf = (float)(int)g.len;
                 SrcClamp<false> src1;
                 src1.wr.init(a.b, g); src1.mean = 0.0f;
@@ -2411,6 +2473,56 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, fl
                 src2.wr = src1.wr; src2.mean = s1[0] / nf;
                 lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
+                // ---- the automaton on all waves: 64 chunks per wave (jnn_chunks), every chunk stages its first
+                // candidate and its strong segments in its part of the upper half of the read's slots; one wave merges
+                // them, 64 chunks per round
+                const float mn = s1[0] / nf, band = sqrtf(s2[0] / nf) * p.std_scale;
+                const JnnThr th = jnn_thresholds(mn + band, mn - band, p);
+                const WaveRead &wr = src1.wr;
+                const int C = jnn_long_chunks(wr.skip + g.len);
+                const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
+                const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
+                if (capL >= 4u) {  // (else: k_jnn_wave runs the automaton with the sums from here)
+                    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+                    const int gw = cx.part * LC_WG_WAVES + wv;
+                    int32_t *up_x = a.seg_x + slot0 + half, *up_y = a.seg_y + slot0 + half;
+                    if (gw * 64 < C) {
+                        const int gc = gw * 64 + lane;
+                        uint32_t *sx_ = reinterpret_cast<uint32_t *>(up_x + (uint64_t)(gc < C ? gc : 0) * capL);
+                        uint32_t *sy_ = reinterpret_cast<uint32_t *>(up_y + (uint64_t)(gc < C ? gc : 0) * capL);
+                        int fx = 0, fy = 0, fstrong = 0, has_first = 0;
+                        uint32_t cnt = 0u;
+                        auto candidate = [&](int sx, int sy, int c) {
+                            const int strong = c >= p.window ? 1 : 0;
+                            if (!has_first) { has_first = 1; fx = sx; fy = sy; fstrong = strong; }
+                            else if (strong) {
+                                if (cnt < capL - 2u) { lc_st(sx_ + 2 + cnt, (uint32_t)sx); lc_st(sy_ + 2 + cnt, (uint32_t)sy); }
+                                ++cnt;
+                            }
+                        };
+                        jnn_chunks(wr, g.len, th.hi_r, th.lo_r, p.error, th.keep_min, candidate, C, gw * 64);
+                        if (gc < C) {  // the chunk's header: its first candidate, how many strong segments follow
+                            lc_st(sx_, (uint32_t)fx); lc_st(sx_ + 1, (uint32_t)fy);
+                            lc_st(sy_, (uint32_t)(has_first | (fstrong << 1))); lc_st(sy_ + 1, cnt);
+                        }
+                    }
+                    lc_barrier(cx);
+                    if (cx.part == 0 && wv == 0) {
+                        JnnCarry cy = {false, false, false, 0, 0u};
+                        for (int j = 0; j < C; j += 64) {
+                            const int gc = j + lane;
+                            const int32_t *sx_ = up_x + (uint64_t)(gc < C ? gc : 0) * capL, *sy_ = up_y + (uint64_t)(gc < C ? gc : 0) * capL;
+                            int fx = 0, fy = 0, fl = 0;
+                            uint32_t cnt = 0u;
+                            if (gc < C) { fx = jnn_ld<true>(sx_); fy = jnn_ld<true>(sx_ + 1); fl = jnn_ld<true>(sy_); cnt = (uint32_t)jnn_ld<true>(sy_ + 1); }
+                            jnn_merge_round<true>(cy, fl & 1, fx, fy, (fl >> 1) & 1, cnt, capL - 2u, sx_ + 2, sy_ + 2, p.seg_dist,
+                                                  a.seg_x + slot0, a.seg_y + slot0, half);
+                        }
+                        const uint32_t total = jnn_merge_flush(cy, a.seg_y + slot0, half);
+                        if (lane == 0) a.n_segs[r] = total;  // (JNN_REDO_MARK: the lane-per-read kernel takes the read)
+                    }
+                    done = 2u;
+                }
             }
         } else {
             if (g.len > ADW) {
@@ -2428,7 +2540,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, fl
         if (cx.part == 0 && threadIdx.x == 0) {
             o->s1[0] = s1[0]; o->s1[1] = s1[1];
             o->s2[0] = s2[0]; o->s2[1] = s2[1];
-            o->valid = 1u;
+            o->valid = done;
             atomicAdd(&a.long_hdr->n_tiles, tiles);
             atomicAdd(&a.long_hdr->n_true, n_true);
         }
@@ -2574,7 +2686,7 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         return SGK_OK;
     }
     if (a.longs) {
-        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
+        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
         SGK_HIP_TRY(hipGetLastError());
     }
     if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
@@ -2593,7 +2705,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
         if (a.longs && p.std_scale > 0.0f) {
-            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WG_WAVES * 64, a, p.std_scale);
+            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WG_WAVES * 64, a, p);
             SGK_HIP_TRY(hipGetLastError());
         }
         StatArgs aw = a;
@@ -2614,7 +2726,7 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
@@ -2644,7 +2756,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, 0.0f);
+            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
