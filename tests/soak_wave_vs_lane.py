@@ -28,7 +28,7 @@ def main():
     api.load_library()
     rs = np.random.RandomState(a.seed)
     t_end = time.time() + a.minutes * 60
-    stats = {"batches": 0, "reads": 0, "samples": 0, "mismatches": []}
+    stats = {"batches": 0, "reads": 0, "samples": 0, "long_min": {}, "reads_at_or_above_long_min": 0, "mismatches": []}
 
     def fail(msg):
         stats["mismatches"].append(msg)
@@ -56,9 +56,18 @@ def main():
             elif u < 0.85: reads[r] = rs.randint(-2000, 2000, size=n).astype(np.int16)
         rna = int(rs.randint(0, 2)); pore = int(rs.choice([0, 2]))
         tag = "batch %d (seed %d kind %d rna %d pore %d, %d reads)" % (stats["batches"], seed, kind, rna, pore, nr)
+        if rs.rand() < 0.3:   # a few much longer reads: several rounds of the chunk merge, thousands of tiles
+            for r in rs.randint(0, nr, size=3):
+                lens[r] = int(rs.randint(300000, 1500000))
+                reads[r] = api.synth_reads_host(1, [lens[r]], int(rs.randint(0, 1 << 30)), kind)[0][0]
         out = {}
+        # the wave kernels' long-read path (k_long_chains: sums from tile summaries, histogram, automaton on 64 waves):
+        # a low threshold sends hundreds of reads per batch through it, the default only the longest
+        long_min = int(rs.choice([0, 8192, 8192, 20000, 60000, -1]))
+        stats["long_min"][str(long_min)] = stats["long_min"].get(str(long_min), 0) + 1
+        stats["reads_at_or_above_long_min"] += sum(1 for n in lens if long_min >= 0 and n >= (long_min or 262144))
         for mode in ("wave", "lane"):
-            api.stat_configure(1 if mode == "lane" else 2)
+            api.stat_configure(1 if mode == "lane" else 2, long_min)
             job = api.Job(0)
             job.stage(reads, dig, off, rng, None)
             job.launch(api.TOOL_STAT); st = job.wait()["stat"].copy()
@@ -66,7 +75,7 @@ def main():
             job.launch(api.TOOL_PREFIX, rna=rna, pore=pore); pf = job.wait()["prefix"].copy()
             out[mode] = (st, sg, pf)
             job.close()
-        api.stat_configure(0)
+        api.stat_configure(0, 0)
         w, l = out["wave"], out["lane"]
         for r in range(nr):
             if w[0][r].tobytes() != l[0][r].tobytes():
