@@ -249,9 +249,12 @@ int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *ou
  * 1 one read per lane, 2 one read per wavefront.  Results do not depend on it (the tests compare the two bit for bit). */
 typedef struct sgk_stat_options {
     int32_t kernels;
-    int32_t long_min;   /* reads of at least this many samples get a workgroup of 16 wavefronts for their sequential
-                         * float sums before the wave-per-read kernel runs: 0 = 262 144, -1 = never, else >= 8 192.
-                         * Needs the workspace sgk_*_workspace_bytes asks for (with less, such reads run on one wave). */
+    int32_t long_min;   /* reads of at least this many samples get 16 workgroups (64 wavefronts) of their own before
+                         * the wave-per-read kernel runs (sequential float sums composed from tile summaries, stat's
+                         * histogram and pA output, jnn's automaton): 0 = chosen per batch, max(262 144, n_samples / 2048)
+                         * -- the reads one wavefront would still be busy with when the rest of the batch is done;
+                         * -1 = never; else the threshold (>= 8 192).  Results do not depend on it.  Needs the workspace
+                         * sgk_*_workspace_bytes asks for (with less, such reads run on one wavefront). */
     uint32_t reserved[2];
 } sgk_stat_options_t;
 int sgk_stat_opt(const sgk_batch_t *batch, sgk_stat_rec_t *out, void *workspace, size_t workspace_bytes, void *stream,

@@ -25,16 +25,17 @@ __global__ __launch_bounds__(256) void k_pa(const int16_t *samples, const uint64
                                             const uint32_t *lengths, const double *dig,
                                             const double *off, const double *rng, uint32_t n_reads,
                                             uint32_t slabs_per_read, float *out) {
+    // slabs_per_read comes from the batch's MEAN read length (launch_pa): a read longer than that many slabs is
+    // finished by its workgroups in further rounds, so that one very long read does not make the grid n_reads x its slabs
     const uint64_t total = (uint64_t)n_reads * slabs_per_read;
     for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
-        const uint32_t r = (uint32_t)(w / slabs_per_read);
-        const uint32_t slab = (uint32_t)(w % slabs_per_read);
-        const uint64_t o0 = offsets[r];
-        const uint64_t n = lengths[r];
-        const uint64_t b = (uint64_t)slab * PA_SLAB;
-        if (b >= n) continue;
+      const uint32_t r = (uint32_t)(w / slabs_per_read);
+      const uint64_t o0 = offsets[r];
+      const uint64_t n = lengths[r];
+      const Scale sc = make_scale(dig[r], off[r], rng[r]);
+      for (uint64_t slab = w % slabs_per_read; slab * PA_SLAB < n; slab += slabs_per_read) {
+        const uint64_t b = slab * PA_SLAB;
         const uint64_t e = (b + PA_SLAB < n) ? b + PA_SLAB : n;
-        const Scale sc = make_scale(dig[r], off[r], rng[r]);
         const int16_t *src = samples + o0;
         float *dst = out + o0;
         const bool vec = ((reinterpret_cast<uintptr_t>(src + b) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + b) & 15u) == 0);
@@ -68,13 +69,16 @@ __global__ __launch_bounds__(256) void k_pa(const int16_t *samples, const uint64
         } else {
             for (uint64_t p = b + threadIdx.x; p < e; p += 256) dst[p] = to_pa(src[p], sc);
         }
+      }
     }
 }
 
 int launch_pa(const sgk_batch_t *b, float *out, hipStream_t st) {
-    if (b->n_reads == 0) return SGK_OK;
-    const uint32_t spr = (b->max_read_len + PA_SLAB - 1) / PA_SLAB;
-    if (spr == 0) return SGK_OK;
+    if (b->n_reads == 0 || b->max_read_len == 0) return SGK_OK;
+    // workgroups per read: what a read of 1.25 x the mean length needs, at most what the longest needs
+    const uint64_t mean = b->n_samples / b->n_reads;
+    const uint64_t want = (mean + mean / 4 + PA_SLAB - 1) / PA_SLAB + 1, most = (b->max_read_len + PA_SLAB - 1) / PA_SLAB;
+    const uint32_t spr = (uint32_t)(want < most ? want : most);
     const uint64_t blocks = (uint64_t)b->n_reads * spr;
     const uint32_t grid = blocks < SLAB_GRID_MAX ? (uint32_t)blocks : SLAB_GRID_MAX;
     {

@@ -2606,8 +2606,15 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, h
     a.long_hist = nullptr;
     a.long_pool_tiles = 0u;
     a.long_min = 0u;
-    const uint32_t lm = opt_long_min <= 0 ? LC_LONG_MIN
-                                          : ((uint32_t)opt_long_min < LC_LONG_MIN_FLOOR ? LC_LONG_MIN_FLOOR : (uint32_t)opt_long_min);
+    // By default a read is long when one wavefront would still be busy with it after the rest of the batch is done:
+    // a wave takes 2 - 4 ns per sample, the full GPU ~1.3 ps, and the batch's longest reads are dispatched first, so a
+    // read of more than n_samples / 2048 samples decides when the kernel ends (and one of less than 262 144 samples
+    // costs less than the long path's barriers).  Measured on 20 000 log-normal reads (1 081 of 262 144 samples or
+    // more): with all of those on the long path stat takes 6.8 ms instead of 3.9 -- the wave kernels balance them.
+    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : a.b.n_samples / 2048;
+    if (opt_long_min <= 0 && lm64 < LC_LONG_MIN) lm64 = LC_LONG_MIN;
+    if (lm64 < LC_LONG_MIN_FLOOR) lm64 = LC_LONG_MIN_FLOOR;
+    const uint32_t lm = lm64 > 0xffffffffull ? 0xffffffffu : (uint32_t)lm64;
     const size_t off = order_workspace_bytes(a.b.n_reads);
     if (!ws || ws_bytes < off + long_workspace_bytes(0, 0) || (reinterpret_cast<uintptr_t>(ws) & 7u)) return SGK_OK;
     char *base = static_cast<char *>(ws) + off;
