@@ -44,6 +44,7 @@
 #include <utility>
 
 #include "event_args.h"
+#include "side_stream.h"
 #include "stat_args.h"
 #include "sgk_common.h"
 #include "tstat_math.h"
@@ -2151,20 +2152,14 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 // k_event's last waves leave empty -- 5.1 vs 3.8 ms on config 2: its kernels start late and slowly.)
 // A small pool per device and kind, handed out round-robin; a stream's mutex is held while one launch enqueues its
 // fork .. join on it (the events are the stream's), never across launches of other streams or devices.
-struct SideStream {
-    std::mutex mu;
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
-};
 constexpr int SIDE_POOL = 4;
-static SideStream g_side[64][2][SIDE_POOL];
-static std::atomic<unsigned> g_side_next[64][2];
+static SideStream g_side[64][3][SIDE_POOL];
+static std::atomic<unsigned> g_side_next[64][3];
 // returns a locked side stream (unlock with x->mu.unlock()), or null
-static SideStream *side_acquire(bool low_priority) {
+SideStream *side_acquire(int priority) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    const int kind = low_priority ? 1 : 0;
+    const int kind = priority < 0 ? 1 : (priority > 0 ? 2 : 0);
     SideStream &x = g_side[dev][kind][g_side_next[dev][kind].fetch_add(1u) % SIDE_POOL];
     x.mu.lock();
     if (!x.s && !x.tried) {
@@ -2173,8 +2168,8 @@ static SideStream *side_acquire(bool low_priority) {
         hipEvent_t f = nullptr, j = nullptr;
         int lo = 0, hi = 0;
         hipError_t e;
-        if (low_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo);   // (lo: the numerically greatest = lowest)
+        if (priority != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority < 0 ? lo : hi);   // (lo: the numerically greatest = lowest)
         else
             e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         if (e == hipSuccess) {
@@ -2193,35 +2188,6 @@ static SideStream *side_acquire(bool low_priority) {
     }
     return &x;
 }
-// One fork .. join on a side stream: joins on every exit path (an error return in between must not leave the caller's
-// stream unordered behind work that still writes the workspace).
-struct SideFork {
-    SideStream *x = nullptr;
-    hipStream_t main = nullptr;
-    bool open(bool low_priority, hipStream_t st) {
-        // (a stream that is being captured into a graph keeps everything in itself: the library's events and streams are
-        // not part of the caller's capture)
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-        x = side_acquire(low_priority);
-        if (!x) return false;
-        main = st;
-        if (hipEventRecord(x->fork, st) == hipSuccess && hipStreamWaitEvent(x->s, x->fork, 0) == hipSuccess) return true;
-        x->mu.unlock();
-        x = nullptr;
-        return false;
-    }
-    hipStream_t stream() const { return x ? x->s : main; }
-    void join() {
-        if (!x) return;
-        const bool ok = hipEventRecord(x->join, x->s) == hipSuccess && hipStreamWaitEvent(main, x->join, 0) == hipSuccess;
-        if (!ok) (void)hipStreamSynchronize(x->s);
-        x->mu.unlock();
-        x = nullptr;
-    }
-    ~SideFork() { join(); }
-};
-
 template <typename T>
 static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStream_t st) {
     if (a.n_reads == 0) return SGK_OK;
@@ -2244,7 +2210,7 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
     const bool tail_only = ao.max_segs && ao.split_seg && !ao.has_long;
     SideFork multi_side;
     hipStream_t st_multi = st;
-    if (ao.multi_lanes && !all_short && multi_side.open(false, st)) st_multi = multi_side.stream();
+    if (ao.multi_lanes && !all_short && multi_side.open(0, st)) st_multi = multi_side.stream();
     if (ao.multi_lanes) {
         ProfScope ps("k_event_multi", st_multi);
         const uint32_t per_wave = 64u / ao.multi_lanes;

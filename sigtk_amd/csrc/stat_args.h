@@ -49,7 +49,7 @@ struct LongSums {
     uint32_t valid;      // 1: s1 / s2 are final; 2: and k_long_chains wrote the subtool's whole output for this read (stat, jnn)
     float s1[2];         // first-stage sums (stat: raw, pA; jnn: clamped raw; prefix: rolling means), signed
     float s2[2];         // second-stage sums (squared deviations from the first stage's means)
-    uint32_t rec_off;    // the read's tile records in the pool (0xffffffff: none, the read runs on one wave)
+    uint32_t rec_off;    // the read's tile records in the pool (LC_NO_REC: none, the read runs on one wave)
     uint32_t pad;
 };
 struct LongWork {        // what the workgroups of one long read exchange (agent-scope atomics only)
@@ -60,6 +60,7 @@ struct LongWork {        // what the workgroups of one long read exchange (agent
 };
 static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64 && sizeof(LongWork) == 16 + 16 * LC_WAVES, "long-read workspace layout");
 constexpr uint32_t LC_CAP = 512;              // long reads per batch that get a record (the rest run as before)
+constexpr uint32_t LC_NO_REC = 0xffffffffu;     // LongSums::rec_off of a long read without tile records
 constexpr uint32_t LC_HIST_BINS = 2048;       // stat's window histogram (WH_BINS)
 constexpr uint32_t LC_POOL_TILES = 1u << 20;  // tile records per sum (2^30 samples of long reads; 16 MB)
 constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min

@@ -25,6 +25,7 @@
 #include "row_stream.h"
 #include "seqsum.h"
 #include "sgk_common.h"
+#include "side_stream.h"
 #include "stat_args.h"
 #include "tstat_math.h"
 
@@ -76,7 +77,10 @@ __device__ __forceinline__ void lc_st(uint32_t *p, uint32_t v) { __hip_atomic_st
 __device__ __forceinline__ void lc_st(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the record k_long_chains left for read r (wave-uniform; null: the wave evaluates the read's sums itself)
+// The record of read r if k_long_list listed it (wave-uniform; null: an ordinary read).  k_long_chains may run BESIDE the
+// kernel that asks (stat, jnn: side stream), so who does a read is decided by what k_long_list wrote -- LongSums::rec_off,
+// final before either kernel starts -- and never by LongSums::valid, which k_long_chains sets when it is done (prefix'
+// k_adaptor_wave, launched behind it, reads the sums under valid).
 __device__ inline const LongSums *find_long(const StatArgs &a, uint32_t r, int64_t len) {
     if (!a.longs || len < (int64_t)a.long_min) return nullptr;
     const uint32_t nl = a.long_hdr->n_long, n = nl < LC_CAP ? nl : LC_CAP;
@@ -84,8 +88,7 @@ __device__ inline const LongSums *find_long(const StatArgs &a, uint32_t r, int64
         const uint32_t i = i0 + (uint32_t)lane_id();
         const unsigned long long hit = __ballot(i < n && a.long_list[i] == r);
         if (hit) {
-            const LongSums *ls = a.longs + i0 + (uint32_t)(__ffsll((long long)hit) - 1);
-            return ls->valid ? ls : nullptr;
+            return a.longs + i0 + (uint32_t)(__ffsll((long long)hit) - 1);
         }
     }
     return nullptr;
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     // a long read's record (and pA) is k_long_chains' work
     if (MODE == REG_WHOLE) {
         const LongSums *lg = find_long(a, r, g.len);
-        if (lg && lg->valid == 2u) return;
+        if (lg && lg->rec_off != LC_NO_REC) return;
     }
 #ifdef SGK_SS_COUNT  // development: what the four chains of read 0 had to do
     SsCount counts[4] = {};
@@ -1016,6 +1019,11 @@ __device__ __forceinline__ int jnn_long_chunks(int64_t nq) {
     const int lanes = jnn_chunk_lanes(nq);
     return c > 64 * LC_WAVES ? 64 * LC_WAVES : (c > lanes ? (int)c : lanes);
 }
+// slots per chunk of a long read's staging area (the upper half of its slots); below 4 the read stays with k_jnn_wave
+__device__ __forceinline__ uint32_t jnn_long_cap(const StatArgs &a, uint32_t r, int64_t nq) {
+    const uint64_t cap = a.seg_slots[r + 1] - a.seg_slots[r];
+    return (uint32_t)((cap - cap / 2) / (uint32_t)jnn_long_chunks(nq));
+}
 template <typename CAND>
 __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi_r, int lo_r, int error, int keep_min,
                                            CAND &candidate, int C, int gchunk0) {
@@ -1285,11 +1293,10 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     if (p.std_scale > 0.0f) {  // src/jnn.c:195-199
         const float nf = (float)(int)n;
         float s = 0.0f, q = 0.0f;
-        // a long read: k_long_chains evaluated its two sums (valid 1) or ran the whole of jnn (valid 2)
+        // a long read is k_long_chains' (sums, automaton and merge) if its slots have room for 4 096 chunks' headers
         const LongSums *lg = find_long(a, r, n);
-        if (lg && lg->valid == 2u) return;
-        if (lg) s = lg->s1[0];
-        else {
+        if (lg && lg->rec_off != LC_NO_REC && jnn_long_cap(a, r, wr.skip + n) >= 4u) return;
+        {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1299,8 +1306,7 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
             }
         }
         const float mn = s / nf;
-        if (lg) q = lg->s2[0];
-        else {
+        {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1962,7 +1968,8 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     auto chain_tile = [&](float &acc, int t, const int (&tot)[SS_SPL], auto term) { roll_chain_tile(acc, wr, t, tot, term); };
 
     const float mf = (float)(int)m;
-    const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains
+    const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains (launched in front)
+    if (lg && !lg->valid) lg = nullptr;
     float s = 0.0f;
     if (lg) s = lg->s1[0];
     else
@@ -2417,7 +2424,7 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     LongSums *o = a.longs + i;
     o->read = r;
     o->valid = 0u;
-    o->rec_off = off + need <= a.long_pool_tiles ? off : 0xffffffffu;  // (no room: the read runs on one wave as before)
+    o->rec_off = off + need <= a.long_pool_tiles ? off : LC_NO_REC;  // (no room: the read runs on one wave as before)
     a.long_work[i].arrive = 0u;
     a.long_work[i].n_true = 0u;
 }
@@ -2428,7 +2435,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
     const uint32_t groups = gridDim.x / LC_PARTS;
     for (uint32_t i = blockIdx.x / LC_PARTS; i < n_long; i += groups) {
         LongSums *o = a.longs + i;
-        if (o->rec_off == 0xffffffffu) continue;
+        if (o->rec_off == LC_NO_REC) continue;
         const uint32_t r = a.long_list[i];
         const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
         LcCtx cx;
@@ -2464,7 +2471,8 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
             __syncthreads();
             done = 2u;
         } else if (KIND == LC_JNN) {
-            if (p.std_scale > 0.0f) {  // (fixed thresholds otherwise: no sums, launch_jnn does not come here)
+            // (fixed thresholds: launch_jnn does not come here; slots too small for the chunks: k_jnn_wave keeps the read)
+            if (p.std_scale > 0.0f && jnn_long_cap(a, r, (g.start & 7) + g.len) >= 4u) {
                 const float nf = (float)(int)g.len;
                 SrcClamp<false> src1;
                 src1.wr.init(a.b, g); src1.mean = 0.0f;
@@ -2482,7 +2490,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                 const int C = jnn_long_chunks(wr.skip + g.len);
                 const uint64_t slot0 = a.seg_slots[r], cap = a.seg_slots[r + 1] - slot0;
                 const uint32_t half = (uint32_t)(cap / 2), capL = (uint32_t)((cap - half) / (uint32_t)C);
-                if (capL >= 4u) {  // (else: k_jnn_wave runs the automaton with the sums from here)
+                {
                     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
                     const int gw = cx.part * LC_WG_WAVES + wv;
                     int32_t *up_x = a.seg_x + slot0 + half, *up_y = a.seg_y + slot0 + half;
@@ -2692,13 +2700,21 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         SGK_HIP_TRY(hipGetLastError());
         return SGK_OK;
     }
+    // the long reads' workgroups run beside the wave kernel (which skips those reads) when a side stream is to be had
+    SideFork side;
     if (a.longs) {
-        SGK_LAUNCH("k_long_chains_stat", (k_long_chains<LC_STAT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
+        const bool forked = side.open(0, st);
+        hipStream_t ls = forked ? side.stream() : st;
+        {
+            ProfScope ps_("k_long_chains_stat", ls);
+            hipLaunchKernelGGL((k_long_chains<LC_STAT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{});
+        }
         SGK_HIP_TRY(hipGetLastError());
     }
     if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
     else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
     SGK_HIP_TRY(hipGetLastError());
+    side.join();
     SGK_LAUNCH("k_median_flagged", (k_median<REG_WHOLE, false, true>), nr, 256, a);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
@@ -2711,14 +2727,21 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
     if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
+        SideFork side;
         if (a.longs && p.std_scale > 0.0f) {
-            SGK_LAUNCH("k_long_chains_jnn", (k_long_chains<LC_JNN>), long_grid(a), LC_WG_WAVES * 64, a, p);
+            const bool forked = side.open(0, st);
+            hipStream_t ls = forked ? side.stream() : st;
+            {
+                ProfScope ps_("k_long_chains_jnn", ls);
+                hipLaunchKernelGGL((k_long_chains<LC_JNN>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, p);
+            }
             SGK_HIP_TRY(hipGetLastError());
         }
         StatArgs aw = a;
         if (!(p.std_scale > 0.0f)) aw.longs = nullptr;
         SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, aw, p);
         SGK_HIP_TRY(hipGetLastError());
+        side.join();
         StatArgs redo = a;
         redo.jnn_redo = 1u;  // the reads the wave kernel gave up on (none, usually: its wavefronts return at once)
         SGK_LAUNCH("k_jnn_redo", k_jnn, (nr + 63) / 64, 64, redo, p);
