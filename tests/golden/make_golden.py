@@ -30,6 +30,11 @@ SYNTH = {  # name -> (n_reads, read_len, seed, kind, experiment_type, sequencing
     "synth_ragged": (12, [200, 201, 250, 333, 1000, 2000, 2001, 2048, 4096, 4097, 9999, 30000], 404, 0,
                      "genomic_dna", "sqk-lsk109"),
 }
+# reads the long-read path of stat / jnn / prefix takes (k_long_chains) and event's segments: `event -c` as a hash
+SYNTH_LONG = {
+    "synth_long": (3, [700000, 5000, 300000], 505, 0, "genomic_dna", "sqk-lsk109"),
+    "synth_long_rna": (2, [400000, 30000], 606, 1, "rna", "sqk-rna002"),
+}
 PA_READS = ["00011a60-dd92-4aad-be1d-59a33545ab1d", "0448591b-036c-4cc7-a702-6c542ccc07de",
             "03880e3d-b79d-4bd8-aab4-15724f1331af"]
 
@@ -89,7 +94,15 @@ def main():
             save(name + ".prefix_stat.tsv", ref(tmp, "prefix", "--print-stat", f))
             save(name + ".ent.tsv", ref(tmp, "ent", f))
             manifest[name + ".event.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", f)).hexdigest()
+        for name, spec in SYNTH_LONG.items():
+            f = os.path.join(tmp, name + ".blow5")
+            write_synth_blow5(f, spec)
+            save(name + ".stat.tsv", ref(tmp, "stat", f))
+            save(name + ".jnn.tsv", ref(tmp, "jnn", f))
+            save(name + ".prefix_stat.tsv", ref(tmp, "prefix", "--print-stat", f))
+            manifest[name + ".event_c.tsv.sha256"] = hashlib.sha256(ref(tmp, "event", "-c", f)).hexdigest()
     manifest["_synth_specs"] = {k: list(v) for k, v in SYNTH.items()}
+    manifest["_synth_long_specs"] = {k: list(v) for k, v in SYNTH_LONG.items()}
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("wrote %d golden files" % (len(manifest) - 1))

@@ -38,7 +38,7 @@ def gold(name):
 def synth_files(tmp_path_factory):
     d = tmp_path_factory.mktemp("synth")
     files = {}
-    for name, spec in MANIFEST["_synth_specs"].items():
+    for name, spec in list(MANIFEST["_synth_specs"].items()) + list(MANIFEST["_synth_long_specs"].items()):
         n, ln, seed, kind, exp, kit = spec
         reads, dig, off, rng = api.synth_reads_host(n, ln, seed, kind)
         recs = [blow5.Read("synth-%08d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i])
@@ -179,3 +179,15 @@ def test_synthetic_outputs(cli, synth_files, name):
     assert out(cli, "ent", f) == gold(name + ".ent.tsv")
     assert out(cli, "ent", "--no-header", "--batch-samples", "50000", f) == gold(name + ".ent.tsv").split(b"\n", 1)[1]
     assert hashlib.sha256(out(cli, "event", f)).hexdigest() == MANIFEST[name + ".event.tsv.sha256"]
+
+
+@pytest.mark.parametrize("name", list(MANIFEST["_synth_long_specs"]))
+def test_synthetic_long_reads(cli, synth_files, name):
+    """reads of 300 000 - 700 000 samples through the CLI (its batches put them on k_long_chains for stat / jnn / prefix
+    and on event's segments); the goldens are the real reference's output (tests/golden/make_golden.py)"""
+    f = synth_files[name]
+    assert out(cli, "stat", f) == gold(name + ".stat.tsv")
+    assert out(cli, "jnn", f) == gold(name + ".jnn.tsv")
+    assert out(cli, "prefix", "--print-stat", f) == gold(name + ".prefix_stat.tsv")
+    assert hashlib.sha256(out(cli, "event", "-c", f)).hexdigest() == MANIFEST[name + ".event_c.tsv.sha256"]
+
