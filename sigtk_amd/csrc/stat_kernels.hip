@@ -1923,79 +1923,44 @@ __device__ __forceinline__ void roll_chain_tile(float &acc, const WaveRead &wr, 
     if (ss_fast<false>(acc, w, TermArr{x}, sk)) acc = ss_finish<false>(acc, TermArr{x}, w, sk);
 }
 
-__global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t widx = blockIdx.x * 4 + wv;
-    if (widx >= a.b.n_reads) return;
-    const uint32_t r = a.order ? a.order[widx] : widx;
-    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
-    const int64_t n = g.len;
-    sgk_prefix_rec_t *o = a.prefix + r;
-    if (lane == 0) {
-        o->n = (uint32_t)n;
-        o->reserved = 0;
-        o->polya_x = -1; o->polya_y = -1;
-        o->adapt_mean = 0.0f; o->adapt_std = 0.0f; o->adapt_median = 0.0f;
-        o->polya_mean = 0.0f; o->polya_std = 0.0f; o->polya_median = 0.0f;
+// one sweep over the rolling totals of the windows of wr: f(t, tot) per tile; stops when f returns true
+template <typename F>
+__device__ __forceinline__ void roll_sweep(const WaveRead &wr, int first_total, F f) {
+    int T0 = first_total;
+    WaveTile tr, ld, trn, ldn;
+    roll_load(wr, tr, ld, 0);
+    for (int t = 0; t < wr.ntiles; ++t) {
+        if (t + 1 < wr.ntiles) roll_load(wr, trn, ldn, t + 1);
+        int tot[SS_SPL];
+        if (t == 0 && wr.skip > 0) roll_tile<true>(tr, ld, wr.skip, T0, tot);
+        else roll_tile<false>(tr, ld, 0, T0, tot);
+        if (f(t, tot)) break;
+        tr = trn; ld = ldn;
     }
-    if (n <= ADW) {  // "Not enough data to trim", src/jnn.c:173-177
-        if (lane == 0) { o->adapt_x = -1; o->adapt_y = -1; }
-        return;
-    }
-    const int64_t m = n - ADW;  // number of rolling means
-    WaveRead wr;
-    wr.init(a.b, Region{g.start, m});
-    const int q0 = lane * SS_SPL;
-
-    // total of the first window: clamped samples 0 .. 1999 (tile-local positions skip .. skip + 1999 of tiles 0 and 1)
-    const int first_total = window_total(wr, 0, wr.skip);
-
-    // one sweep over the rolling totals: f(t, tot, q_lo, q_hi) per tile; returns early when f says so
-    auto sweep = [&](auto f) {
-        int T0 = first_total;
-        WaveTile tr, ld, trn, ldn;
-        auto load2 = [&](WaveTile &x, WaveTile &y, int t) { roll_load(wr, x, y, t); };
-        load2(tr, ld, 0);
-        for (int t = 0; t < wr.ntiles; ++t) {
-            if (t + 1 < wr.ntiles) load2(trn, ldn, t + 1);
-            int tot[SS_SPL];
-            if (t == 0 && wr.skip > 0) roll_tile<true>(tr, ld, wr.skip, T0, tot);
-            else roll_tile<false>(tr, ld, 0, T0, tot);
-            if (f(t, tot)) break;
-            tr = trn; ld = ldn;
-        }
-    };
-    auto chain_tile = [&](float &acc, int t, const int (&tot)[SS_SPL], auto term) { roll_chain_tile(acc, wr, t, tot, term); };
-
-    const float mf = (float)(int)m;
-    const LongSums *lg = find_long(a, r, n);  // a long read's two sums were evaluated by k_long_chains (launched in front)
-    if (lg && !lg->valid) lg = nullptr;
-    float s = 0.0f;
-    if (lg) s = lg->s1[0];
-    else
-        sweep([&](int t, const int (&tot)[SS_SPL]) {
-            chain_tile(s, t, tot, [](int v) { return roll_mean(v); });
-            return false;
-        });
+}
+// what find_adaptor leaves in a read's record before anything is found (lane 0)
+__device__ __forceinline__ void adaptor_init_rec(sgk_prefix_rec_t *o, int64_t n) {
+    o->n = (uint32_t)n;
+    o->reserved = 0;
+    o->polya_x = -1; o->polya_y = -1;
+    o->adapt_mean = 0.0f; o->adapt_std = 0.0f; o->adapt_median = 0.0f;
+    o->polya_mean = 0.0f; o->polya_std = 0.0f; o->polya_median = 0.0f;
+}
+// jnnv2's thresholds from the two sums over the m rolling means (src/jnn.c:106-124) and its run finder (RunFinder above,
+// src/jnn.c:126-167) from flip to flip, by one wave; writes adapt_x / adapt_y
+__device__ inline void adaptor_find(const WaveRead &wr, int first_total, float s, float q, float mf, const AdaptP &ap,
+                                    sgk_prefix_rec_t *o) {
+    const int lane = lane_id(), q0 = lane * SS_SPL;
     const float mn = s / mf;
-    float q = 0.0f;
-    if (lg) q = lg->s2[0];
-    else
-        sweep([&](int t, const int (&tot)[SS_SPL]) {
-            chain_tile(q, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
-            return false;
-        });
     const float sd = sqrtf(q / mf);
     const float bot = mn - sd * ap.std_scale;
     const int t_lt = roll_threshold(bot, false), t_gt = roll_threshold(bot, true);
-
-    // the run finder (RunFinder above, src/jnn.c:126-167) from flip to flip
     int in_run = 0, start = 0, end = 0, nseg = 0, last_x = 0, last_y = 0, ans_x = 0, ans_y = 0, found = 0;
     auto settle = [&]() {
         const int len = last_y - last_x;
         if (!found && !(len > ap.hi_thresh) && !(len < ap.lo_thresh)) { found = 1; ans_x = last_x; ans_y = last_y; }
     };
-    sweep([&](int t, const int (&tot)[SS_SPL]) {
+    roll_sweep(wr, first_total, [&](int t, const int (&tot)[SS_SPL]) {
         int q_lo, q_hi;
         wr.range(t, 0, q_lo, q_hi);
         uint32_t bm = 0u, am = 0u;
@@ -2036,6 +2001,43 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
         if (found) { o->adapt_x = ans_x + ADW / 2 - 1; o->adapt_y = ans_y + ADW / 2 - 1; }
         else { o->adapt_x = 0; o->adapt_y = 0; }
     }
+}
+
+__global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t widx = blockIdx.x * 4 + wv;
+    if (widx >= a.b.n_reads) return;
+    const uint32_t r = a.order ? a.order[widx] : widx;
+    const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
+    const int64_t n = g.len;
+    // a long read is k_long_chains' (which runs beside this kernel): its sums, thresholds, run finder and record
+    const LongSums *lg = find_long(a, r, n);
+    if (lg && lg->rec_off != LC_NO_REC) return;
+    sgk_prefix_rec_t *o = a.prefix + r;
+    if (lane == 0) adaptor_init_rec(o, n);
+    if (n <= ADW) {  // "Not enough data to trim", src/jnn.c:173-177
+        if (lane == 0) { o->adapt_x = -1; o->adapt_y = -1; }
+        return;
+    }
+    const int64_t m = n - ADW;  // number of rolling means
+    WaveRead wr;
+    wr.init(a.b, Region{g.start, m});
+
+    // total of the first window: clamped samples 0 .. 1999 (tile-local positions skip .. skip + 1999 of tiles 0 and 1)
+    const int first_total = window_total(wr, 0, wr.skip);
+    const float mf = (float)(int)m;
+    float s = 0.0f;
+    roll_sweep(wr, first_total, [&](int t, const int (&tot)[SS_SPL]) {
+        roll_chain_tile(s, wr, t, tot, [](int v) { return roll_mean(v); });
+        return false;
+    });
+    const float mn = s / mf;
+    float q = 0.0f;
+    roll_sweep(wr, first_total, [&](int t, const int (&tot)[SS_SPL]) {
+        roll_chain_tile(q, wr, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
+        return false;
+    });
+    adaptor_find(wr, first_total, s, q, mf, ap, o);
 }
 
 // ---------------------------------------------------------------- long reads: the sequential sums on 64 wavefronts
@@ -2429,7 +2431,7 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     a.long_work[i].n_true = 0u;
 }
 template <int KIND>
-__global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, JnnP p) {
+__global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, JnnP p, AdaptP ap) {
     __shared__ uint32_t hist[KIND == LC_STAT ? WH_BINS : 1];
     const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
     const uint32_t groups = gridDim.x / LC_PARTS;
@@ -2533,7 +2535,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                 }
             }
         } else {
-            if (g.len > ADW) {
+            if (g.len > ADW) {  // (always: long_min is far above the window)
                 const int64_t m = g.len - ADW;
                 const float mf = (float)(int)m;
                 SrcRoll<false> src1;
@@ -2543,6 +2545,13 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                 src2.wr = src1.wr; src2.mean = s1[0] / mf;
                 lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
+                // thresholds, run finder (it stops at the first adaptor candidate) and the record: one wave
+                if (cx.part == 0 && threadIdx.x < 64) {
+                    sgk_prefix_rec_t *rec = a.prefix + r;
+                    if (threadIdx.x == 0) adaptor_init_rec(rec, g.len);
+                    adaptor_find(src1.wr, window_total(src1.wr, 0, src1.wr.skip), s1[0], s2[0], mf, ap, rec);
+                }
+                done = 2u;
             }
         }
         if (cx.part == 0 && threadIdx.x == 0) {
@@ -2707,7 +2716,7 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         hipStream_t ls = forked ? side.stream() : st;
         {
             ProfScope ps_("k_long_chains_stat", ls);
-            hipLaunchKernelGGL((k_long_chains<LC_STAT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{});
+            hipLaunchKernelGGL((k_long_chains<LC_STAT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{}, AdaptP{});
         }
         SGK_HIP_TRY(hipGetLastError());
     }
@@ -2733,7 +2742,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
             hipStream_t ls = forked ? side.stream() : st;
             {
                 ProfScope ps_("k_long_chains_jnn", ls);
-                hipLaunchKernelGGL((k_long_chains<LC_JNN>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, p);
+                hipLaunchKernelGGL((k_long_chains<LC_JNN>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, p, AdaptP{});
             }
             SGK_HIP_TRY(hipGetLastError());
         }
@@ -2755,8 +2764,14 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
+        SideFork side;
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
+            const bool forked = side.open(0, st);
+            hipStream_t ls = forked ? side.stream() : st;
+            {
+                ProfScope ps_("k_long_chains_adapt", ls);
+                hipLaunchKernelGGL((k_long_chains<LC_ADAPT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{}, p);
+            }
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
@@ -2785,8 +2800,15 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const bool lanes = lane_per_read(a);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
+        SideFork side;  // (joins at the end of this block: the kernels behind read every read's adapt_x / adapt_y)
         if (a.longs) {
-            SGK_LAUNCH("k_long_chains_adapt", (k_long_chains<LC_ADAPT>), long_grid(a), LC_WG_WAVES * 64, a, JnnP{});
+            const bool forked = side.open(0, st);
+            hipStream_t ls = forked ? side.stream() : st;
+            {
+                ProfScope ps_("k_long_chains_adapt", ls);
+                hipLaunchKernelGGL((k_long_chains<LC_ADAPT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{},
+                                   adaptor_preset(pore));
+            }
             SGK_HIP_TRY(hipGetLastError());
         }
         SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
