@@ -39,7 +39,7 @@ int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_
     a.kernels = opt ? opt->kernels : 0;
     a.stat = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -59,7 +59,7 @@ int sgk_stat_pa_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, vo
     a.stat = out;
     a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -82,7 +82,7 @@ int sgk_jnn_opt(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_
     a.n_segs = n_segs;
     a.err_count = static_cast<uint32_t *>(ws);
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 3072u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
@@ -101,7 +101,7 @@ int sgk_prefix_opt(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *ou
     a.kernels = opt ? opt->kernels : 0;
     a.prefix = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
 }
 

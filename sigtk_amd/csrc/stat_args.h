@@ -67,8 +67,8 @@ constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
 constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for
 size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
-// clears the header and lists the long reads
-int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st);
+// clears the header and lists the long reads; auto_div: long_min = max(262 144, n_samples / auto_div) when the option is 0
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st);
 
 // workspace layout of stat / jnn / prefix: [0, 64) counters (jnn: overflow count), then the dispatch order of the
 // wave-per-read kernels (n_reads x 4 bytes) and the 2 x 128 words of its counting sort

@@ -2433,6 +2433,10 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
 template <int KIND>
 __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, JnnP p, AdaptP ap) {
     __shared__ uint32_t hist[KIND == LC_STAT ? WH_BINS : 1];
+#ifndef SGK_LC_NOPRIO
+    // these waves are the batch's critical path and share their SIMDs with the wave kernel's: they issue first
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t nl = a.long_hdr->n_long, n_long = nl < LC_CAP ? nl : LC_CAP;
     const uint32_t groups = gridDim.x / LC_PARTS;
     for (uint32_t i = blockIdx.x / LC_PARTS; i < n_long; i += groups) {
@@ -2614,7 +2618,7 @@ size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len) {
     return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork) + LC_HIST_BINS * 4) +
            (size_t)long_pool_tiles(n_samples, max_read_len) * 16;
 }
-int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, hipStream_t st) {
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st) {
     a.long_hdr = nullptr;
     a.long_list = nullptr;
     a.longs = nullptr;
@@ -2625,10 +2629,11 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, h
     a.long_min = 0u;
     // By default a read is long when one wavefront would still be busy with it after the rest of the batch is done:
     // a wave takes 2 - 4 ns per sample, the full GPU ~1.3 ps, and the batch's longest reads are dispatched first, so a
-    // read of more than n_samples / 2048 samples decides when the kernel ends (and one of less than 262 144 samples
-    // costs less than the long path's barriers).  Measured on 20 000 log-normal reads (1 081 of 262 144 samples or
-    // more): with all of those on the long path stat takes 6.8 ms instead of 3.9 -- the wave kernels balance them.
-    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : a.b.n_samples / 2048;
+    // read of more than n_samples / 2048 samples (jnn, whose wave is slower on a long read: / 3072) decides when the
+    // kernel ends (and one of less than 262 144 samples costs less than the long path's barriers).  Measured on 20 000
+    // log-normal reads (1 081 of 262 144 samples or more): with all of those on the long path stat takes 6.8 ms
+    // instead of 3.9 -- the wave kernels balance them.
+    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : a.b.n_samples / auto_div;
     if (opt_long_min <= 0 && lm64 < LC_LONG_MIN) lm64 = LC_LONG_MIN;
     if (lm64 < LC_LONG_MIN_FLOOR) lm64 = LC_LONG_MIN_FLOOR;
     const uint32_t lm = lm64 > 0xffffffffull ? 0xffffffffu : (uint32_t)lm64;
@@ -2698,6 +2703,28 @@ static bool lane_per_read(const StatArgs &a) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__);     \
     } while (0)
 
+// The wave kernel (wave_launch(stream)) beside k_long_chains<KIND>.  The long reads' few workgroups go to the caller's
+// stream and the wave kernel to a side stream that first waits for the fork event: launched the other way round the long
+// workgroups found every slot taken by the wave kernel's -- whose first workgroups hold the batch's longest reads -- and
+// started 2 ms late.  The side stream joins when the returned guard goes out of scope (or at guard.join()).
+template <int KIND, typename WL>
+static int launch_beside_long(SideFork &side, const StatArgs &a, const JnnP &p, const AdaptP &ap, const char *name, hipStream_t st,
+                              WL wave_launch) {
+    hipStream_t ws = st;
+    if (a.longs) {
+        const bool forked = side.open(0, st);
+        {
+            ProfScope ps_(name, st);
+            hipLaunchKernelGGL((k_long_chains<KIND>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, st, a, p, ap);
+        }
+        SGK_HIP_TRY(hipGetLastError());
+        if (forked) ws = side.stream();
+    }
+    wave_launch(ws);
+    SGK_HIP_TRY(hipGetLastError());
+    return SGK_OK;
+}
+
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
@@ -2710,20 +2737,14 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
         return SGK_OK;
     }
     // the long reads' workgroups run beside the wave kernel (which skips those reads) when a side stream is to be had
-    SideFork side;
-    if (a.longs) {
-        const bool forked = side.open(0, st);
-        hipStream_t ls = forked ? side.stream() : st;
-        {
-            ProfScope ps_("k_long_chains_stat", ls);
-            hipLaunchKernelGGL((k_long_chains<LC_STAT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{}, AdaptP{});
-        }
-        SGK_HIP_TRY(hipGetLastError());
+    {
+        SideFork side;
+        const int rc = launch_beside_long<LC_STAT>(side, a, JnnP{}, AdaptP{}, "k_long_chains_stat", st, [&](hipStream_t st) {
+            if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
+            else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
+        });
+        if (rc != SGK_OK) return rc;
     }
-    if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
-    else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
-    SGK_HIP_TRY(hipGetLastError());
-    side.join();
     SGK_LAUNCH("k_median_flagged", (k_median<REG_WHOLE, false, true>), nr, 256, a);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
@@ -2736,21 +2757,15 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
     if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
-        SideFork side;
-        if (a.longs && p.std_scale > 0.0f) {
-            const bool forked = side.open(0, st);
-            hipStream_t ls = forked ? side.stream() : st;
-            {
-                ProfScope ps_("k_long_chains_jnn", ls);
-                hipLaunchKernelGGL((k_long_chains<LC_JNN>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, p, AdaptP{});
-            }
-            SGK_HIP_TRY(hipGetLastError());
-        }
         StatArgs aw = a;
-        if (!(p.std_scale > 0.0f)) aw.longs = nullptr;
-        SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, aw, p);
-        SGK_HIP_TRY(hipGetLastError());
-        side.join();
+        if (!(p.std_scale > 0.0f)) aw.longs = nullptr;  // (fixed thresholds: no sums, k_jnn_wave does every read)
+        {
+            SideFork side;
+            const int rc = launch_beside_long<LC_JNN>(side, aw, p, AdaptP{}, "k_long_chains_jnn", st, [&](hipStream_t st) {
+                SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, aw, p);
+            });
+            if (rc != SGK_OK) return rc;
+        }
         StatArgs redo = a;
         redo.jnn_redo = 1u;  // the reads the wave kernel gave up on (none, usually: its wavefronts return at once)
         SGK_LAUNCH("k_jnn_redo", k_jnn, (nr + 63) / 64, 64, redo, p);
@@ -2765,16 +2780,10 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
         SideFork side;
-        if (a.longs) {
-            const bool forked = side.open(0, st);
-            hipStream_t ls = forked ? side.stream() : st;
-            {
-                ProfScope ps_("k_long_chains_adapt", ls);
-                hipLaunchKernelGGL((k_long_chains<LC_ADAPT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{}, p);
-            }
-            SGK_HIP_TRY(hipGetLastError());
-        }
-        SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
+        const int rc = launch_beside_long<LC_ADAPT>(side, a, JnnP{}, p, "k_long_chains_adapt", st, [&](hipStream_t st) {
+            SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
+        });
+        if (rc != SGK_OK) return rc;
     }
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
@@ -2801,17 +2810,11 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         SideFork side;  // (joins at the end of this block: the kernels behind read every read's adapt_x / adapt_y)
-        if (a.longs) {
-            const bool forked = side.open(0, st);
-            hipStream_t ls = forked ? side.stream() : st;
-            {
-                ProfScope ps_("k_long_chains_adapt", ls);
-                hipLaunchKernelGGL((k_long_chains<LC_ADAPT>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, ls, a, JnnP{},
-                                   adaptor_preset(pore));
-            }
-            SGK_HIP_TRY(hipGetLastError());
-        }
-        SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, adaptor_preset(pore));
+        const AdaptP ap = adaptor_preset(pore);
+        const int rc = launch_beside_long<LC_ADAPT>(side, a, JnnP{}, ap, "k_long_chains_adapt", st, [&](hipStream_t st) {
+            SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, ap);
+        });
+        if (rc != SGK_OK) return rc;
     }
     SGK_HIP_TRY(hipGetLastError());
     if (lanes) {
