@@ -62,8 +62,11 @@ extern "C" {
 
 /* 0.2.0: per-call options (sgk_event_options_t, sgk_stat_options_t) replace the process-wide sgk_event_configure* and
  * the environment variables of 0.1.0; sgk_event_plan takes the options; sgk_event_plan_t / sgk_event_status_t as below.
- * Bindings should compare sgk_version() with the header they were written against. */
-#define SGK_VERSION_STRING "0.2.0"
+ * Bindings should compare sgk_version() with the header they were written against.
+ * 0.2.1: sgk_stat_options_t::long_min (was reserved), sgk_stat_long_status; sgk_stat / sgk_jnn / sgk_prefix_workspace_bytes
+ *        ask for the long reads' records as well (an older, smaller workspace still works: long reads then run on one
+ *        wavefront). */
+#define SGK_VERSION_STRING "0.2.1"
 
 /* ---- error codes --------------------------------------------------------------- */
 #define SGK_OK 0

@@ -214,8 +214,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                               [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     ver = L.sgk_version().decode()
-    if tuple(int(x) for x in ver.split(".")[:2]) < (0, 2):
-        raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2" % (path, ver))
+    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 1):
+        raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2 and the long-read "
+                            "status of 0.2.1" % (path, ver))
     OE, OS = C.POINTER(EventOptions), C.POINTER(StatOptions)
     L.sgk_event_workspace_bytes_opt.restype = C.c_size_t
     L.sgk_event_workspace_bytes_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, OE]
