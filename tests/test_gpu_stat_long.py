@@ -120,3 +120,27 @@ def test_long_path_composes_most_tiles_and_equals_the_one_wave_path(gpu):
         tiles = sum((int(n) + 1023 + 7) // 1024 for n in lens[[0, 1, 3]])
         assert chains * (tiles - 12) <= s.n_tiles <= chains * (tiles + 3)
         assert 0 < s.n_true_tiles <= s.n_tiles // 20, (s.n_tiles, s.n_true_tiles)
+
+
+def test_smaller_workspaces_are_accepted(gpu):
+    """a caller that sizes the workspace as ABI 0.2.0 did (dispatch order only), or passes none, gets the same records:
+    its long reads run on one wavefront"""
+    import ctypes as C
+    import torch
+    from sigtk_amd import device
+    from sigtk_amd.device import _ptr, _stream_ptr
+    lens = np.asarray([400000, 3000, 100000] + [5000] * 1100, dtype=np.int64)   # (>= 1024 reads: the order is used)
+    dev = torch.device("cuda", 0)
+    b = device.synth_reads(len(lens), 0, seed=8, kind=0, device=dev, lengths=lens)
+    L = gpu.load_library()
+    full = device.stat(b).cpu().numpy().copy()
+    assert device.long_status(b, "stat").n_long_reads == 1
+    view = b.view()
+    order_only = 64 + (len(lens) * 4 + 128 * 4 + 63) // 64 * 64
+    for nbytes in (order_only, 64, 0):
+        out = torch.zeros(len(lens) * gpu.STAT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        gpu.check(L.sgk_stat_opt(C.byref(view), _ptr(out), _ptr(ws) if nbytes else None, nbytes, _stream_ptr(),
+                                 C.byref(gpu.STAT_OPTIONS)), "sgk_stat_opt")
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == full.tobytes(), "workspace of %d bytes" % nbytes
