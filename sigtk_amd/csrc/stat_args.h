@@ -64,6 +64,7 @@ constexpr uint32_t LC_NO_REC = 0xffffffffu;     // LongSums::rec_off of a long r
 constexpr uint32_t LC_HIST_BINS = 2048;       // stat's window histogram (WH_BINS)
 constexpr uint32_t LC_POOL_TILES = 1u << 20;  // tile records per sum (2^30 samples of long reads; 16 MB)
 constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
+constexpr uint32_t LC_AUTO_MAX_READS = 128;   // with the per-batch threshold: more long reads than this and none is treated as long
 constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for
 size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),

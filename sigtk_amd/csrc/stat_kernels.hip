@@ -2430,6 +2430,12 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     a.long_work[i].arrive = 0u;
     a.long_work[i].n_true = 0u;
 }
+// A batch whose own threshold still lists more reads than two rounds of the long kernel's grid take is a batch of
+// similar, long reads: one wave per read balances that by itself (1 000 reads of 500 000 samples: stat 1.4 ms) and
+// the long kernel, built for a few outliers, does not (64 reads at a time).  The list is dropped.
+__global__ void k_long_limit(LongHdr *hdr, uint32_t limit) {
+    if (threadIdx.x == 0 && hdr->n_long > limit) hdr->n_long = 0u;
+}
 template <int KIND>
 __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, JnnP p, AdaptP ap) {
     __shared__ uint32_t hist[KIND == LC_STAT ? WH_BINS : 1];
@@ -2660,6 +2666,7 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, u
     a.long_min = lm;
     SGK_HIP_TRY(hipMemsetAsync(a.long_hdr, 0, sizeof(LongHdr), st));
     hipLaunchKernelGGL(k_long_list, dim3((a.b.n_reads + 255) / 256), dim3(256), 0, st, a);
+    if (opt_long_min == 0) hipLaunchKernelGGL(k_long_limit, dim3(1), dim3(64), 0, st, a.long_hdr, LC_AUTO_MAX_READS);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }

@@ -144,3 +144,24 @@ def test_smaller_workspaces_are_accepted(gpu):
                                  C.byref(gpu.STAT_OPTIONS)), "sgk_stat_opt")
         torch.cuda.synchronize()
         assert out.cpu().numpy().tobytes() == full.tobytes(), "workspace of %d bytes" % nbytes
+
+
+def test_a_batch_of_similar_long_reads_is_left_to_the_wave_kernels(gpu):
+    """the per-batch threshold lists the reads one wave would outlast the batch on; 200 reads of 300 000 samples are
+    all over it (262 144) and none is an outlier: the list is dropped (LC_AUTO_MAX_READS).  An explicit threshold
+    keeps them on the long path; same records either way."""
+    import torch
+    from sigtk_amd import device
+    lens = np.full(200, 300000, dtype=np.int64)
+    b = device.synth_reads(len(lens), 0, seed=12, kind=0, device=torch.device("cuda", 0), lengths=lens)
+    try:
+        gpu.stat_configure(2, 0)
+        auto = device.stat(b).cpu().numpy().copy()
+        assert device.long_status(b, "stat").n_long_reads == 0
+        gpu.stat_configure(2, 262144)
+        forced = device.stat(b).cpu().numpy().copy()
+        st = device.long_status(b, "stat")
+        assert st.n_long_reads == 200 and st.n_tiles > 0
+    finally:
+        gpu.stat_configure(0, 0)
+    assert auto.tobytes() == forced.tobytes()
