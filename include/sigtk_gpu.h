@@ -274,7 +274,8 @@ int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t
  * composed from per-tile summaries; n_true_tiles of the n_tiles tile sums had to be evaluated from the true accumulator
  * instead (binade crossings, mispredicted binades).  All zero when the call had no long read or no room for them. */
 typedef struct sgk_long_status {
-    uint32_t n_long_reads, n_tiles, n_true_tiles, reserved;
+    uint32_t n_long_reads, n_tiles, n_true_tiles;
+    uint32_t n_timeouts;  /* must be 0: a workgroup gave up waiting for the others of its read (its results are wrong) */
 } sgk_long_status_t;
 int sgk_stat_long_status(const void *workspace, size_t workspace_bytes, uint32_t n_reads, sgk_long_status_t *out);
 

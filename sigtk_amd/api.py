@@ -65,7 +65,7 @@ class StatOptions(C.Structure):   # sgk_stat_options_t
 
 class LongStatus(C.Structure):    # sgk_long_status_t
     _fields_ = [("n_long_reads", C.c_uint32), ("n_tiles", C.c_uint32), ("n_true_tiles", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("n_timeouts", C.c_uint32)]
 
 
 def _env_int(name, default=0):

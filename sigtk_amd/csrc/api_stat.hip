@@ -120,6 +120,7 @@ int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_
     out->n_long_reads = h.n_long;
     out->n_tiles = h.n_tiles;
     out->n_true_tiles = h.n_true;
+    out->n_timeouts = h.n_timeout;
     return SGK_OK;
 }
 

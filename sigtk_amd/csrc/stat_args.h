@@ -42,11 +42,13 @@ struct LongHdr {
     uint32_t n_tiles;    // tile sums summarised
     uint32_t n_true;     // ... of which the composition had to evaluate from the true accumulator
     uint32_t pool_used;  // tile records handed out
-    uint32_t pad[12];
+    uint32_t n_timeout;  // barriers given up after seconds (never, on a GPU that dispatches a grid's workgroups in order)
+    uint32_t pad[11];
 };
 struct LongSums {
     uint32_t read;
-    uint32_t valid;      // 1: s1 / s2 are final; 2: and k_long_chains wrote the subtool's whole output for this read (stat, jnn)
+    uint32_t valid;      // set by k_long_chains when it is done with the read (1: nothing to do for it, 2: the subtool's
+                         // whole output is written); WHO does a read is decided by rec_off, see find_long
     float s1[2];         // first-stage sums (stat: raw, pA; jnn: clamped raw; prefix: rolling means), signed
     float s2[2];         // second-stage sums (squared deviations from the first stage's means)
     uint32_t rec_off;    // the read's tile records in the pool (LC_NO_REC: none, the read runs on one wave)

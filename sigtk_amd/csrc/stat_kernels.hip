@@ -2077,6 +2077,7 @@ __device__ __forceinline__ double wave_sum_d(double v) { return wave_last_d(wave
 __device__ __forceinline__ int wave_sum_i(int v) { return wave_last_i(wave_incl_scan_i(v)); }
 struct LcCtx {
     LongWork *w;
+    LongHdr *hdr;
     unsigned long long *rec[2];  // tile records of the two sums: T0 | (E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff) << 32
     uint32_t phase;              // barriers passed
     int part;                    // this workgroup's index among the read's LC_PARTS
@@ -2089,7 +2090,13 @@ __device__ inline void lc_barrier(LcCtx &cx) {
     if (threadIdx.x == 0) {
         atomicAdd(&cx.w->arrive, 1u);
         const uint32_t target = cx.phase * (uint32_t)LC_PARTS;
-        while (lc_ld(&cx.w->arrive) < target) __builtin_amdgcn_s_sleep(2);
+        // (the others are running or about to, see above; the bound -- seconds -- only keeps a GPU that does not behave
+        // that way from hanging: the read's results are then wrong and sgk_stat_long_status says so)
+        uint32_t spins = 0u;
+        while (lc_ld(&cx.w->arrive) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins == (1u << 24)) { atomicAdd(&cx.hdr->n_timeout, 1u); break; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -2452,6 +2459,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
         const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
         LcCtx cx;
         cx.w = a.long_work + i;
+        cx.hdr = a.long_hdr;
         cx.rec[0] = a.long_pool + o->rec_off;
         cx.rec[1] = a.long_pool + a.long_pool_tiles + o->rec_off;
         cx.phase = 0u;

@@ -116,7 +116,7 @@ def test_long_path_composes_most_tiles_and_equals_the_one_wave_path(gpu):
         s0, n = int(slots[r]), int(n1[r])
         assert (segs[1][s0:s0 + n] == x1[s0:s0 + n]).all() and (segs[2][s0:s0 + n] == y1[s0:s0 + n]).all()
     for s, chains in ((st, 4), (sp, 2), (sj, 2)):
-        assert s.n_long_reads == 3
+        assert s.n_long_reads == 3 and s.n_timeouts == 0
         tiles = sum((int(n) + 1023 + 7) // 1024 for n in lens[[0, 1, 3]])
         assert chains * (tiles - 12) <= s.n_tiles <= chains * (tiles + 3)
         assert 0 < s.n_true_tiles <= s.n_tiles // 20, (s.n_tiles, s.n_true_tiles)

@@ -68,7 +68,8 @@ def main():
                           "hbm_frac": round(alg_bytes / dt / 1e9 / 8000.0, 4), "kernels_ms": prof,
                           "longest_read": int(b.max_read_len), "stat_long_min": int(api.STAT_OPTIONS.long_min),
                           "long_reads": None if ls is None else {"reads": ls.n_long_reads, "tile_sums": ls.n_tiles,
-                                                                 "evaluated_from_true_accumulator": ls.n_true_tiles}}),
+                                                                 "evaluated_from_true_accumulator": ls.n_true_tiles,
+                                                                 "barrier_timeouts": ls.n_timeouts}}),
               flush=True)
 
     run("pa", lambda: device.pa(b, pa_out), 6 * S)
