@@ -2045,7 +2045,8 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
 // busy for milliseconds per sum while the rest of the batch is long done.  k_long_chains gives such a read LC_PARTS
 // workgroups of four wavefronts (on LC_PARTS compute units: the sums are bound by vector-instruction issue, one compute
 // unit's four SIMDs would not do).  What seqsum.h does with the 16 terms of a lane is done here once more with the 1 024
-// terms of a TILE (tools/proto/seqsum_segments_proto.py is the model):
+// terms of a TILE (tools/proto/seqsum_tiles_proto.py is the numpy model, seqsum_segments_proto.py the round-3 sketch it
+// grew from):
 //
 //   level 1, all waves, no dependency between them: a wave owns a contiguous run of tiles.  It PREDICTS the accumulator
 //     in front of each tile (sums of the terms in front of its run, pass A below, then tile by tile from its own

@@ -1,7 +1,7 @@
 """CPU: tools/proto/seqsum_segments_proto.py -- a sequential float32 sum over a read cut into segments that are
 summarised independently (two surrogate starts per segment) and composed, against the plain loop, bit for bit.
-Groundwork for long reads on several wavefronts in `stat` / `jnn` / `prefix`; nothing on the product
-path uses it yet."""
+The round-3 sketch of long reads on several wavefronts in `stat` / `jnn` / `prefix`; the kernel that came of it
+(k_long_chains, round 4) summarises per 1024-term tile: tools/proto/seqsum_tiles_proto.py, tests/test_seqsum_tiles_model.py."""
 import os
 import sys
 
