@@ -63,7 +63,7 @@ extern "C" {
 /* 0.2.0: per-call options (sgk_event_options_t, sgk_stat_options_t) replace the process-wide sgk_event_configure* and
  * the environment variables of 0.1.0; sgk_event_plan takes the options; sgk_event_plan_t / sgk_event_status_t as below.
  * Bindings should compare sgk_version() with the header they were written against.
- * 0.2.1: sgk_stat_options_t::long_min (was reserved), sgk_stat_long_status; sgk_stat / sgk_jnn / sgk_prefix_workspace_bytes
+ * 0.2.1: sgk_stat_options_t::long_min (was reserved), sgk_stat_long_status, sgk_stat_plan; sgk_stat / sgk_jnn / sgk_prefix_workspace_bytes
  *        ask for the long reads' records as well (an older, smaller workspace still works: long reads then run on one
  *        wavefront). */
 #define SGK_VERSION_STRING "0.2.1"
@@ -273,6 +273,19 @@ int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t
  * the stream has drained).  A long read's sequential float sums (src/stat.h:17-54, src/jnn.c:106-124, 195-199) are
  * composed from per-tile summaries; n_true_tiles of the n_tiles tile sums had to be evaluated from the true accumulator
  * instead (binade crossings, mispredicted binades).  All zero when the call had no long read or no room for them. */
+/* What a stat (tool 0) / jnn (1) / prefix (2) call would do with a batch of these totals (host arithmetic only, no GPU):
+ * which implementation kernels = 0 resolves to, the long-read threshold it uses (0: no read of the batch can be long)
+ * and how many long reads it accepts (under the per-batch threshold more than that many and none is treated as long;
+ * under an explicit one the surplus runs on one wavefront each), the workspace sgk_*_workspace_bytes asks for. */
+typedef struct sgk_stat_plan {
+    uint32_t kernels;         /* 1: one read per lane, 2: one read per wavefront */
+    uint32_t long_min;
+    uint32_t long_max_reads;
+    uint32_t reserved;
+    uint64_t workspace_bytes;
+} sgk_stat_plan_t;
+int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, const sgk_stat_options_t *opt,
+                  sgk_stat_plan_t *out);
 typedef struct sgk_long_status {
     uint32_t n_long_reads, n_tiles, n_true_tiles;
     uint32_t n_timeouts;  /* must be 0: a workgroup gave up waiting for the others of its read (its results are wrong) */

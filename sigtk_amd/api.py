@@ -63,6 +63,11 @@ class StatOptions(C.Structure):   # sgk_stat_options_t
     _fields_ = [("kernels", C.c_int32), ("long_min", C.c_int32), ("reserved", C.c_uint32 * 2)]
 
 
+class StatPlan(C.Structure):      # sgk_stat_plan_t
+    _fields_ = [("kernels", C.c_uint32), ("long_min", C.c_uint32), ("long_max_reads", C.c_uint32),
+                ("reserved", C.c_uint32), ("workspace_bytes", C.c_uint64)]
+
+
 class LongStatus(C.Structure):    # sgk_long_status_t
     _fields_ = [("n_long_reads", C.c_uint32), ("n_tiles", C.c_uint32), ("n_true_tiles", C.c_uint32),
                 ("n_timeouts", C.c_uint32)]
@@ -103,6 +108,15 @@ def stat_configure(kernels: int = 0, long_min: int = 0) -> None:
     """kernels 0: chosen per batch, 1: one read per lane (round-1 kernels), 2: one read per wavefront; long_min: reads of
     at least that many samples take the 16-wavefront sums (0 = 262 144, -1 = never)"""
     STAT_OPTIONS.kernels, STAT_OPTIONS.long_min = int(kernels), int(long_min)
+
+
+def stat_plan(tool: str, n_reads: int, n_samples: int, max_read_len: int, opt: "StatOptions" = None) -> StatPlan:
+    """sgk_stat_plan for tool 'stat' / 'jnn' / 'prefix' (host arithmetic only)"""
+    p = StatPlan()
+    check(load_library().sgk_stat_plan({"stat": 0, "jnn": 1, "prefix": 2}[tool], int(n_reads), int(n_samples),
+                                       int(max_read_len), C.byref(opt if opt is not None else STAT_OPTIONS), C.byref(p)),
+          "sgk_stat_plan")
+    return p
 
 
 def event_plan(n_reads: int, n_samples: int, max_read_len: int, rna: int, opt: "EventOptions" = None) -> EventPlan:
@@ -162,7 +176,7 @@ ABI_SYMBOLS = [
     "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan",
     "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
-    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
+    "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_plan", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
     "sgk_stat_host_opt", "sgk_jnn_host_opt", "sgk_prefix_host_opt", "sgk_job_set_options", "sgk_ent", "sgk_ent_finish", "sgk_svbzd_decode",
     "sgk_qts", "sgk_svbzd_size", "sgk_svbzd_encode", "sgk_synth_reads", "sgk_synth_reads_host",
     "sgk_profile_enable", "sgk_profile_reset", "sgk_profile_read",
@@ -232,6 +246,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     for f in ("sgk_stat", "sgk_stat_pa", "sgk_jnn", "sgk_prefix"):
         getattr(L, f + "_opt").argtypes = getattr(L, f).argtypes + [OS]
     L.sgk_stat_long_status.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(LongStatus)]
+    L.sgk_stat_plan.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, OS, C.POINTER(StatPlan)]
     L.sgk_svbzd_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
     L.sgk_synth_reads.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,

@@ -39,7 +39,7 @@ int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_
     a.kernels = opt ? opt->kernels : 0;
     a.stat = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_STAT, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -59,7 +59,7 @@ int sgk_stat_pa_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, vo
     a.stat = out;
     a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_STAT, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_stat(a, static_cast<hipStream_t>(stream));
 }
 
@@ -82,7 +82,7 @@ int sgk_jnn_opt(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_
     a.n_segs = n_segs;
     a.err_count = static_cast<uint32_t *>(ws);
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 3072u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_JNN, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_jnn(a, jnn_preset(rna), static_cast<hipStream_t>(stream));
 }
 
@@ -101,13 +101,30 @@ int sgk_prefix_opt(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *ou
     a.kernels = opt ? opt->kernels : 0;
     a.prefix = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
-    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, 2048u, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
+    if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_PREFIX, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     return launch_prefix(a, rna, pore, static_cast<hipStream_t>(stream));
 }
 
 int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, void *ws, size_t ws_bytes,
                void *stream) {
     return sgk_prefix_opt(b, rna, pore, out, ws, ws_bytes, stream, nullptr);
+}
+
+int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, const sgk_stat_options_t *opt,
+                  sgk_stat_plan_t *out) {
+    if (!out || tool < 0 || tool > 2) return SGK_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    const int kernels = opt ? opt->kernels : 0;
+    const int32_t lm_opt = opt ? opt->long_min : 0;
+    out->kernels = stat_lane_per_read(kernels, n_reads, n_samples, max_read_len) ? 1u : 2u;
+    out->workspace_bytes = stat_ws(n_reads, n_samples, max_read_len);
+    const uint32_t lm = long_threshold(n_samples, lm_opt, tool == 0 ? LC_AUTO_DIV_STAT : (tool == 1 ? LC_AUTO_DIV_JNN : LC_AUTO_DIV_PREFIX));
+    // (the long-read path belongs to the wave-per-read kernels and needs a read that long in the batch)
+    if (out->kernels == 2u && lm_opt >= 0 && max_read_len >= lm) {
+        out->long_min = lm;
+        out->long_max_reads = lm_opt == 0 ? LC_AUTO_MAX_READS : LC_CAP;
+    }
+    return SGK_OK;
 }
 
 int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_long_status_t *out) {

@@ -2633,6 +2633,12 @@ size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len) {
     return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork) + LC_HIST_BINS * 4) +
            (size_t)long_pool_tiles(n_samples, max_read_len) * 16;
 }
+uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, uint32_t auto_div) {
+    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : n_samples / auto_div;
+    if (opt_long_min <= 0 && lm64 < LC_LONG_MIN) lm64 = LC_LONG_MIN;
+    if (lm64 < LC_LONG_MIN_FLOOR) lm64 = LC_LONG_MIN_FLOOR;
+    return lm64 > 0xffffffffull ? 0xffffffffu : (uint32_t)lm64;
+}
 int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st) {
     a.long_hdr = nullptr;
     a.long_list = nullptr;
@@ -2648,10 +2654,7 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, u
     // kernel ends (and one of less than 262 144 samples costs less than the long path's barriers).  Measured on 20 000
     // log-normal reads (1 081 of 262 144 samples or more): with all of those on the long path stat takes 6.8 ms
     // instead of 3.9 -- the wave kernels balance them.
-    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : a.b.n_samples / auto_div;
-    if (opt_long_min <= 0 && lm64 < LC_LONG_MIN) lm64 = LC_LONG_MIN;
-    if (lm64 < LC_LONG_MIN_FLOOR) lm64 = LC_LONG_MIN_FLOOR;
-    const uint32_t lm = lm64 > 0xffffffffull ? 0xffffffffu : (uint32_t)lm64;
+    const uint32_t lm = long_threshold(a.b.n_samples, opt_long_min, auto_div);
     const size_t off = order_workspace_bytes(a.b.n_reads);
     if (!ws || ws_bytes < off + long_workspace_bytes(0, 0) || (reinterpret_cast<uintptr_t>(ws) & 7u)) return SGK_OK;
     char *base = static_cast<char *>(ws) + off;
@@ -2706,12 +2709,12 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 // wavefront, nothing to gain from intra-read parallelism and no per-read costs (native heads, binade crossings, chunk
 // start-up), and are up to 4 x faster (400 000 x 5 000 samples: jnn 3.6 ms against 14.5 ms); everywhere else -- ragged,
 // small or long-read batches -- the wave kernels win by 1.5 - 40 x.
-static bool lane_per_read(const StatArgs &a) {
-    if (a.kernels == 1) return true;
-    if (a.kernels == 2) return false;
-    const sgk_batch_t &b = a.b;
-    return b.n_reads >= 65536u && b.max_read_len <= 16384u && (uint64_t)b.max_read_len * b.n_reads <= b.n_samples + b.n_samples / 2;
+bool stat_lane_per_read(int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
+    if (kernels == 1) return true;
+    if (kernels == 2) return false;
+    return n_reads >= 65536u && max_read_len <= 16384u && (uint64_t)max_read_len * n_reads <= n_samples + n_samples / 2;
 }
+static bool lane_per_read(const StatArgs &a) { return stat_lane_per_read(a.kernels, a.b.n_reads, a.b.n_samples, a.b.max_read_len); }
 
 #define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
     do {                                                                           \
