@@ -642,7 +642,8 @@ __device__ __forceinline__ void pa_write_tile(const WaveRead &wr, int t, const S
         const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
                                      to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
         float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
-        if (pa_interior) *reinterpret_cast<float4 *>(dst) = o;
+        // (a group of four inside the region is stored whole in an edge tile as well: dst is 16-byte aligned)
+        if (pa_interior || (qs >= q_lo && qs + 4 <= q_hi)) *reinterpret_cast<float4 *>(dst) = o;
         else {
             if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
             if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
