@@ -105,3 +105,20 @@ def test_seqsum_chains_on_hostile_float_arrays(gpu, oracle):
                 a, b = np.float32(a), np.float32(b)
                 assert (np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32), \
                     "array %d (n=%d) %s: gpu %r oracle %r" % (k, x.size, name, a, b)
+
+
+def test_per_read_shims_on_a_long_read(gpu, oracle):
+    """a read of 700 001 samples through the reference-signature per-read calls: they take the long-read path of the
+    batch API (k_long_chains) and give the reference's segments / adaptor"""
+    for kind in (0, 1):
+        reads, dig, off, rng = _reads(gpu, kind, [700001], 53 + kind)
+        raw = reads[0]
+        clamped = np.clip(raw, 0, 1200).astype(np.float32)
+        for kw in (dict(std_scale=0.75, corrector=50, seg_dist=50, window=150, stall_len=0.25, error=5),
+                   dict(std_scale=0.75, corrector=50, seg_dist=50, window=1000, stall_len=1.0, error=5)):
+            po = oracle.jnn_param(**kw)
+            pg = gpu.JnnParam(po.std_scale, po.corrector, po.seg_dist, po.window, po.stall_len, po.error, po.top, po.bot)
+            ex, ey = oracle.jnn_core(clamped, po)
+            assert gpu.shim_jnn_raw(raw, pg) == list(zip(ex.tolist(), ey.tolist()))
+        for pore in (0, 2):
+            assert gpu.shim_find_adaptor(raw, pore) == oracle.find_adaptor(raw, pore)
