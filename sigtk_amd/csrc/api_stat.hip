@@ -116,7 +116,7 @@ int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_r
     memset(out, 0, sizeof *out);
     const int kernels = opt ? opt->kernels : 0;
     const int32_t lm_opt = opt ? opt->long_min : 0;
-    out->kernels = stat_lane_per_read(kernels, n_reads, n_samples, max_read_len) ? 1u : 2u;
+    out->kernels = stat_lane_per_read(tool, kernels, n_reads, n_samples, max_read_len) ? 1u : 2u;
     out->workspace_bytes = stat_ws(n_reads, n_samples, max_read_len);
     const uint32_t lm = long_threshold(n_samples, lm_opt, tool == 0 ? LC_AUTO_DIV_STAT : (tool == 1 ? LC_AUTO_DIV_JNN : LC_AUTO_DIV_PREFIX));
     // (the long-read path belongs to the wave-per-read kernels and needs a read that long in the batch)

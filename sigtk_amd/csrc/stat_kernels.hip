@@ -2705,17 +2705,23 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 // ---------------------------------------------------------------- launchers
 // Two implementations (sgk_stat_options_t::kernels): the lane-per-read kernels of round 1 (1; kept as an independent
 // second implementation: tests compare the two, tools/bench_subtools.py times both) and the wave-per-read kernels (2).
-// By default (0) a batch takes the wave kernels unless it is a LARGE batch of SHORT reads of SIMILAR length (>= 65 536
-// reads of at most 16 384 samples, the longest at most 1.5 x the mean): there the lane-per-read kernels have 64 reads per
-// wavefront, nothing to gain from intra-read parallelism and no per-read costs (native heads, binade crossings, chunk
-// start-up), and are up to 4 x faster (400 000 x 5 000 samples: jnn 3.6 ms against 14.5 ms); everywhere else -- ragged,
-// small or long-read batches -- the wave kernels win by 1.5 - 40 x.
-bool stat_lane_per_read(int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
+// By default (0) a batch takes the wave kernels unless it is a LARGE batch of SHORT reads of SIMILAR length (stat:
+// >= 49 152 reads of at most 32 768 samples; jnn, prefix: >= 65 536 reads of at most 12 288; the longest at most 1.5 x
+// the mean): there the lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and
+// no per-read costs (native heads, binade crossings, chunk start-up), and are up to 2 x faster (400 000 x 5 000 samples:
+// jnn 3.7 ms against 7.7 ms); everywhere else -- ragged, small or long-read batches -- the wave kernels win by 1.5 - 40 x.
+// Per subtool (profiles/r04_z_subtools_wave_vs_lane_short_reads.txt, 2e9 samples per batch): stat's lane kernels win up to
+// 32 768 samples per read (2.67 against 3.05 ms; at 65 536 the wave kernel wins), jnn's and prefix' only up to ~12 000
+// (8 192: 3.5 / 7.0 against 5.4 / 7.6 ms; 16 384: 4.0 / 7.3 against 3.5 / 5.6).
+bool stat_lane_per_read(int tool, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
     if (kernels == 1) return true;
     if (kernels == 2) return false;
-    return n_reads >= 65536u && max_read_len <= 16384u && (uint64_t)max_read_len * n_reads <= n_samples + n_samples / 2;
+    const uint32_t min_reads = tool == 0 ? 49152u : 65536u, max_len = tool == 0 ? 32768u : 12288u;
+    return n_reads >= min_reads && max_read_len <= max_len && (uint64_t)max_read_len * n_reads <= n_samples + n_samples / 2;
 }
-static bool lane_per_read(const StatArgs &a) { return stat_lane_per_read(a.kernels, a.b.n_reads, a.b.n_samples, a.b.max_read_len); }
+static bool lane_per_read(int tool, const StatArgs &a) {
+    return stat_lane_per_read(tool, a.kernels, a.b.n_reads, a.b.n_samples, a.b.max_read_len);
+}
 
 #define SGK_LAUNCH(name, kern, grid, block, ...)                                   \
     do {                                                                           \
@@ -2748,7 +2754,7 @@ static int launch_beside_long(SideFork &side, const StatArgs &a, const JnnP &p, 
 int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read(a)) {
+    if (lane_per_read(0, a)) {
         SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
         SGK_HIP_TRY(hipGetLastError());
         if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
@@ -2775,7 +2781,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     SGK_HIP_TRY(hipMemsetAsync(a.err_count, 0, 4, st));
     const bool wave_ok = p.error >= 0 && p.error < p.corrector && p.error <= 31 && p.window >= 128;
-    if (lane_per_read(a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read(1, a) || !wave_ok) SGK_LAUNCH("k_jnn", k_jnn, (nr + 63) / 64, 64, a, p);
     else {
         StatArgs aw = a;
         if (!(p.std_scale > 0.0f)) aw.longs = nullptr;  // (fixed thresholds: no sums, k_jnn_wave does every read)
@@ -2797,7 +2803,7 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
 int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
-    if (lane_per_read(a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
+    if (lane_per_read(2, a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
         SideFork side;
         const int rc = launch_beside_long<LC_ADAPT>(side, a, JnnP{}, p, "k_long_chains_adapt", st, [&](hipStream_t st) {
@@ -2826,7 +2832,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
-    const bool lanes = lane_per_read(a);
+    const bool lanes = lane_per_read(2, a);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         SideFork side;  // (joins at the end of this block: the kernels behind read every read's adapt_x / adapt_y)

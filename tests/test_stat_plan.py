@@ -19,9 +19,14 @@ def test_uniform_batches_have_no_long_reads_and_take_the_wave_kernels():
 def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 400000, 5000).kernels == 1
     assert plan("stat", 400000, 5000, kernels=2).kernels == 2
-    assert plan("stat", 60000, 5000).kernels == 2            # fewer than 65 536 reads
-    assert plan("stat", 400000, 20000).kernels == 2          # longer than 16 384 samples
+    assert plan("stat", 40000, 5000).kernels == 2            # fewer than 49 152 reads
+    assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
+    assert plan("stat", 100000, 40000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
+    for tool in ("jnn", "prefix"):                           # jnn, prefix: >= 65 536 reads of up to 12 288 samples
+        assert plan(tool, 400000, 5000).kernels == 1
+        assert plan(tool, 60000, 5000).kernels == 2
+        assert plan(tool, 100000, 16384).kernels == 2
     assert plan("jnn", 10, 100000, kernels=1).kernels == 1
     assert plan("jnn", 10, 3000001, kernels=1).long_min == 0  # the long-read path belongs to the wave kernels
 
