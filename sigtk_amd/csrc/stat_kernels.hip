@@ -290,9 +290,24 @@ __device__ __forceinline__ void visit_keys(const int16_t *x, int64_t n, F f, flo
     }
 }
 
+// exclusive prefix of one count per thread over a 256-thread workgroup (a DPP scan per wave + the four wave totals
+// through part[260 .. 263]; a serial pass of one thread over 256 LDS words cost a short read more than counting its
+// samples did)
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t s, uint32_t *part /*264*/) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)s);
+    if (lane == 63) part[260 + wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - s;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) before += w < wv ? part[260 + w] : 0u;
+    __syncthreads();
+    return before;
+}
+
 // rank-k order statistic of the int16 keys of a region, by a 256-thread workgroup
 template <bool PA = false>
-__device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t *hist /*4096*/, uint32_t *part /*256+2*/,
+__device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t *hist /*4096*/, uint32_t *part /*264*/,
                             float *pa = nullptr, Scale sc = Scale{0.0f, 1.0f}) {
     const int t = threadIdx.x;
     for (int i = t; i < 4096; i += 256) hist[i] = 0;
@@ -302,14 +317,7 @@ __device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t 
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += hist[t * 16 + k];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
-    }
-    __syncthreads();
-    const uint32_t before = part[t];
+    const uint32_t before = block_excl_scan_256(s, part);
     if ((uint64_t)rank >= before && (uint64_t)rank < (uint64_t)before + s) {
         uint32_t acc = before;
         for (int k = 0; k < 16; ++k) {
@@ -346,12 +354,12 @@ __device__ int block_select(const int16_t *x, int64_t n, int64_t rank, uint32_t 
 // clipped into the two edge bins.  A rank that lands in an edge bin is not trusted (ok = false -> the caller
 // falls back to the two-level select).  Nanopore raw signals span a few hundred ADC codes, so this is the path taken.
 constexpr int RANGE_BINS = 8192;
-template <bool PA>
+template <bool PA, int nb /* bins: RANGE_BINS or a narrower window */>
 __device__ bool block_select_range(const int16_t *x, int64_t n, int64_t k1, int64_t k2, int lo,
-                                   uint32_t *hist /*RANGE_BINS*/, uint32_t *part /*256+4*/, int &r1, int &r2,
+                                   uint32_t *hist /*RANGE_BINS*/, uint32_t *part /*264*/, int &r1, int &r2,
                                    float *pa, Scale sc) {
     const int t = threadIdx.x;
-    constexpr int nb = RANGE_BINS, per = RANGE_BINS / 256;
+    constexpr int per = nb / 256;
     for (int i = t; i < nb; i += 256) hist[i] = 0;
     __syncthreads();
     const int base = lo + 32768;
@@ -364,14 +372,7 @@ __device__ bool block_select_range(const int16_t *x, int64_t n, int64_t k1, int6
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < per; ++k) s += hist[t * per + k];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
-    }
-    __syncthreads();
-    const uint32_t before = part[t];
+    const uint32_t before = block_excl_scan_256(s, part);
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
         const int64_t rank = w ? k2 : k1;
@@ -396,7 +397,7 @@ __device__ bool block_select_range(const int16_t *x, int64_t n, int64_t k1, int6
 template <int MODE, bool PA = false, bool FLAGGED = false>
 __global__ __launch_bounds__(256) void k_median(StatArgs a) {
     __shared__ uint32_t hist[MODE == REG_WHOLE ? RANGE_BINS : 4096];
-    __shared__ uint32_t part[260];
+    __shared__ uint32_t part[264];
     const uint32_t r = blockIdx.x;
     if (FLAGGED) {
         const uint32_t fl = MODE == REG_WHOLE ? a.stat[r].reserved : a.prefix[r].reserved;
@@ -416,11 +417,16 @@ __global__ __launch_bounds__(256) void k_median(StatArgs a) {
     bool done = false;
     if (MODE == REG_WHOLE) {
         // window centred on the read's raw mean (written by k_moments, which runs before this kernel)
+        // (a short read gets a narrower window: clearing and scanning 8192 bins costs a 5 000-sample read more than
+        // counting its samples; +-1024 raw values around the mean still hold any nanopore read's median)
         const float m = a.stat[r].raw_mean;
+        const int nb = g.len <= 65536 ? 2048 : RANGE_BINS;
         int c = (m == m) ? (int)fminf(fmaxf(m, -32768.0f), 32767.0f) : 0;
-        int lo = c - RANGE_BINS / 2;
-        lo = lo < -32768 ? -32768 : (lo > 32768 - RANGE_BINS ? 32768 - RANGE_BINS : lo);
-        done = block_select_range<PA>(x, g.len, k, mirrored ? g.len - 1 - k : k, lo, hist, part, med, med_for_pa, pa, sc);
+        int lo = c - nb / 2;
+        lo = lo < -32768 ? -32768 : (lo > 32768 - nb ? 32768 - nb : lo);
+        const int64_t k2 = mirrored ? g.len - 1 - k : k;
+        done = nb == 2048 ? block_select_range<PA, 2048>(x, g.len, k, k2, lo, hist, part, med, med_for_pa, pa, sc)
+                          : block_select_range<PA, RANGE_BINS>(x, g.len, k, k2, lo, hist, part, med, med_for_pa, pa, sc);
         pa = nullptr;  // already written
     }
     if (!done) {
