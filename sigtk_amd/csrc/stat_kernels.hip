@@ -2712,18 +2712,21 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 // Two implementations (sgk_stat_options_t::kernels): the lane-per-read kernels of round 1 (1; kept as an independent
 // second implementation: tests compare the two, tools/bench_subtools.py times both) and the wave-per-read kernels (2).
 // By default (0) a batch takes the wave kernels unless it is a LARGE batch of SHORT reads of SIMILAR length (stat:
-// >= 49 152 reads of at most 32 768 samples; jnn, prefix: >= 65 536 reads of at most 12 288; the longest at most 1.5 x
-// the mean): there the lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and
+// >= 49 152 reads of at most 32 768 samples or >= 16 384 of at most 16 384; jnn, prefix: >= 65 536 reads of at most
+// 12 288; the longest at most 1.5 x the mean): there the lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and
 // no per-read costs (native heads, binade crossings, chunk start-up), and are up to 2 x faster (400 000 x 5 000 samples:
 // jnn 3.7 ms against 7.7 ms); everywhere else -- ragged, small or long-read batches -- the wave kernels win by 1.5 - 40 x.
 // Per subtool (profiles/r04_z_subtools_wave_vs_lane_short_reads.txt, 2e9 samples per batch): stat's lane kernels win up to
 // 32 768 samples per read (2.67 against 3.05 ms; at 65 536 the wave kernel wins), jnn's and prefix' only up to ~12 000
-// (8 192: 3.5 / 7.0 against 5.4 / 7.6 ms; 16 384: 4.0 / 7.3 against 3.5 / 5.6).
+// (8 192: 3.5 / 7.0 against 5.4 / 7.6 ms; 16 384: 4.0 / 7.3 against 3.5 / 5.6).  stat's also win on smaller batches of
+// short reads (20 000 x 5 000: 0.28 against 0.49 ms; 40 000 x 10 000: 0.61 against 1.13; 20 000 x 20 000: a tie), jnn's and
+// prefix' need the 65 536 reads (40 000 x 5 000: 0.74 / 1.48 against 0.85 / 0.85).
 bool stat_lane_per_read(int tool, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
     if (kernels == 1) return true;
     if (kernels == 2) return false;
-    const uint32_t min_reads = tool == 0 ? 49152u : 65536u, max_len = tool == 0 ? 32768u : 12288u;
-    return n_reads >= min_reads && max_read_len <= max_len && (uint64_t)max_read_len * n_reads <= n_samples + n_samples / 2;
+    if ((uint64_t)max_read_len * n_reads > n_samples + n_samples / 2) return false;  // not of similar length
+    if (tool == 0) return (n_reads >= 49152u && max_read_len <= 32768u) || (n_reads >= 16384u && max_read_len <= 16384u);
+    return n_reads >= 65536u && max_read_len <= 12288u;
 }
 static bool lane_per_read(int tool, const StatArgs &a) {
     return stat_lane_per_read(tool, a.kernels, a.b.n_reads, a.b.n_samples, a.b.max_read_len);

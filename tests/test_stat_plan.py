@@ -19,7 +19,9 @@ def test_uniform_batches_have_no_long_reads_and_take_the_wave_kernels():
 def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 400000, 5000).kernels == 1
     assert plan("stat", 400000, 5000, kernels=2).kernels == 2
-    assert plan("stat", 40000, 5000).kernels == 2            # fewer than 49 152 reads
+    assert plan("stat", 40000, 5000).kernels == 1            # >= 16 384 reads of up to 16 384 samples
+    assert plan("stat", 40000, 20000).kernels == 2           # ... longer reads need 49 152
+    assert plan("stat", 10000, 5000).kernels == 2
     assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
     assert plan("stat", 100000, 40000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
