@@ -133,18 +133,23 @@ def test_fused_stat_pa_matches_stat_and_pa(gpu, oracle):
     b.dig.copy_(torch.from_numpy(np.asarray(dig, dtype=np.float64)).to(dev))
     b.off.copy_(torch.from_numpy(np.asarray(off, dtype=np.float64)).to(dev))
     b.rng.copy_(torch.from_numpy(np.asarray(rng, dtype=np.float64)).to(dev))
-    rec, pa = device.stat_pa(b)
-    rec2 = device.stat(b)
-    torch.cuda.synchronize()
-    got = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
-    got2 = np.frombuffer(rec2.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
-    assert got.tobytes() == got2.tobytes()
-    _check_stat(oracle, reads, dig, off, rng, got)
-    pa_h = pa.cpu().numpy()
-    for r, raw in enumerate(reads):
-        o = int(b.offsets_host[r])
-        exp = oracle.pa(raw, dig[r], off[r], rng[r])
-        assert np.array_equal(pa_h[o:o + raw.size].view(np.uint32), exp.view(np.uint32)), "read %d pA" % r
+    for kernels in (0, 1, 2):   # chosen per batch / one read per lane (k_moments + k_median) / one read per wavefront
+        gpu.stat_configure(kernels)
+        try:
+            rec, pa = device.stat_pa(b)
+            rec2 = device.stat(b)
+            torch.cuda.synchronize()
+        finally:
+            gpu.stat_configure(0)
+        got = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
+        got2 = np.frombuffer(rec2.cpu().numpy().tobytes(), dtype=gpu.STAT_DTYPE)[:len(lens)]
+        assert got.tobytes() == got2.tobytes()
+        _check_stat(oracle, reads, dig, off, rng, got)
+        pa_h = pa.cpu().numpy()
+        for r, raw in enumerate(reads):
+            o = int(b.offsets_host[r])
+            exp = oracle.pa(raw, dig[r], off[r], rng[r])
+            assert np.array_equal(pa_h[o:o + raw.size].view(np.uint32), exp.view(np.uint32)), "kernels %d read %d pA" % (kernels, r)
 
 
 def _adversarial_reads(gpu, seed):
