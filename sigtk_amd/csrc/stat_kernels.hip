@@ -2712,8 +2712,8 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 // Two implementations (sgk_stat_options_t::kernels): the lane-per-read kernels of round 1 (1; kept as an independent
 // second implementation: tests compare the two, tools/bench_subtools.py times both) and the wave-per-read kernels (2).
 // By default (0) a batch takes the wave kernels unless it is a LARGE batch of SHORT reads of SIMILAR length (stat:
-// >= 49 152 reads of at most 32 768 samples or >= 16 384 of at most 16 384; jnn, prefix: >= 65 536 reads of at most
-// 12 288; the longest at most 1.5 x the mean): there the lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and
+// >= 49 152 reads of at most 32 768 samples or >= 16 384 of at most 16 384; jnn: >= 65 536 reads of at most 12 288; the
+// longest at most 1.5 x the mean; prefix: see launch_prefix): there the lane-per-read kernels have 64 reads per wavefront, nothing to gain from intra-read parallelism and
 // no per-read costs (native heads, binade crossings, chunk start-up), and are up to 2 x faster (400 000 x 5 000 samples:
 // jnn 3.7 ms against 7.7 ms); everywhere else -- ragged, small or long-read batches -- the wave kernels win by 1.5 - 40 x.
 // Per subtool (profiles/r04_z_subtools_wave_vs_lane_short_reads.txt, 2e9 samples per batch): stat's lane kernels win up to
@@ -2726,6 +2726,7 @@ bool stat_lane_per_read(int tool, int kernels, uint32_t n_reads, uint64_t n_samp
     if (kernels == 2) return false;
     if ((uint64_t)max_read_len * n_reads > n_samples + n_samples / 2) return false;  // not of similar length
     if (tool == 0) return (n_reads >= 49152u && max_read_len <= 32768u) || (n_reads >= 16384u && max_read_len <= 16384u);
+    if (tool == 2) return false;  // (prefix: the wave finders win at every shape; its region statistics: launch_prefix)
     return n_reads >= 65536u && max_read_len <= 12288u;
 }
 static bool lane_per_read(int tool, const StatArgs &a) {
@@ -2841,7 +2842,13 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     const uint32_t gw = (nr + 63) / 64;
+    // The adaptor and polyA finders: one read per wavefront unless the caller forces the lane kernels (k_adaptor_wave 4.3
+    // against k_adaptor 5.5 ms on 400 000 x 5 000, 13.4 against 29 on 125 000 x 100 000; k_polya_wave 0.2 against 1.2 - 5.9).
+    // The statistics of the regions they find are a few thousand samples per read whatever the read's length: with enough
+    // reads to fill the lanes (64 per wavefront) the lane kernels do them in 1.0 ms where k_stat_wave takes 2.4 (400 000 x
+    // 5 000), 0.9 + 1.2 against 1.1 + 1.4 (50 000 x 100 000 RNA, adaptor + polyA), a tie at 125 000 x 100 000.
     const bool lanes = lane_per_read(2, a);
+    const bool lane_regions = lanes || (a.kernels == 0 && nr >= 49152u);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         SideFork side;  // (joins at the end of this block: the kernels behind read every read's adapt_x / adapt_y)
@@ -2852,7 +2859,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
         if (rc != SGK_OK) return rc;
     }
     SGK_HIP_TRY(hipGetLastError());
-    if (lanes) {
+    if (lane_regions) {
         SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
         SGK_HIP_TRY(hipGetLastError());
         SGK_LAUNCH("k_median_adapt", (k_median<REG_ADAPT>), nr, 256, a);
@@ -2866,7 +2873,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
         if (lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
-        if (lanes) {
+        if (lane_regions) {
             SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
             SGK_HIP_TRY(hipGetLastError());
             SGK_LAUNCH("k_median_polya", (k_median<REG_POLYA>), nr, 256, a);

@@ -25,10 +25,11 @@ def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
     assert plan("stat", 100000, 40000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
-    for tool in ("jnn", "prefix"):                           # jnn, prefix: >= 65 536 reads of up to 12 288 samples
-        assert plan(tool, 400000, 5000).kernels == 1
-        assert plan(tool, 60000, 5000).kernels == 2
-        assert plan(tool, 100000, 16384).kernels == 2
+    assert plan("jnn", 400000, 5000).kernels == 1            # jnn: >= 65 536 reads of up to 12 288 samples
+    assert plan("jnn", 60000, 5000).kernels == 2
+    assert plan("jnn", 100000, 16384).kernels == 2
+    assert plan("prefix", 400000, 5000).kernels == 2         # prefix: the wave finders at every shape
+    assert plan("prefix", 400000, 5000, kernels=1).kernels == 1
     assert plan("jnn", 10, 100000, kernels=1).kernels == 1
     assert plan("jnn", 10, 3000001, kernels=1).long_min == 0  # the long-read path belongs to the wave kernels
 
