@@ -248,7 +248,8 @@ int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *ou
 
 /* Per-call options of stat / jnn / prefix (null = defaults).  The library has two implementations of these subtools:
  * one read per wavefront (round 2; any batch) and one read per lane (round 1; wins on large batches of short reads of
- * similar length: stat >= 49 152 reads of <= 32 768 samples or >= 16 384 reads of <= 16 384, jnn >= 65 536 reads of <= 12 288 samples,
+ * similar length: stat >= 49 152 reads of <= 32 768 samples or >= 16 384 reads of <= 16 384 (without the pA output also
+ * >= 100 000 reads of <= 131 072), jnn >= 65 536 reads of <= 12 288 samples,
  * the longest <= 1.5 x the mean; prefix: the wave finders, and the lane kernels for the statistics of the regions they find
  * when the batch has >= 49 152 reads; sgk_stat_plan tells).  kernels: 0 chosen per batch,
  * 1 one read per lane, 2 one read per wavefront.  Results do not depend on it (the tests compare the two bit for bit). */
@@ -275,7 +276,7 @@ int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t
  * the stream has drained).  A long read's sequential float sums (src/stat.h:17-54, src/jnn.c:106-124, 195-199) are
  * composed from per-tile summaries; n_true_tiles of the n_tiles tile sums had to be evaluated from the true accumulator
  * instead (binade crossings, mispredicted binades).  All zero when the call had no long read or no room for them. */
-/* What a stat (tool 0) / jnn (1) / prefix (2) call would do with a batch of these totals (host arithmetic only, no GPU):
+/* What a stat (tool 0) / jnn (1) / prefix (2) / stat_pa (3) call would do with a batch of these totals (host arithmetic only, no GPU):
  * which implementation kernels = 0 resolves to, the long-read threshold it uses (0: no read of the batch can be long)
  * and how many long reads it accepts (under the per-batch threshold more than that many and none is treated as long;
  * under an explicit one the surplus runs on one wavefront each), the workspace sgk_*_workspace_bytes asks for. */

@@ -111,9 +111,9 @@ def stat_configure(kernels: int = 0, long_min: int = 0) -> None:
 
 
 def stat_plan(tool: str, n_reads: int, n_samples: int, max_read_len: int, opt: "StatOptions" = None) -> StatPlan:
-    """sgk_stat_plan for tool 'stat' / 'jnn' / 'prefix' (host arithmetic only)"""
+    """sgk_stat_plan for tool 'stat' / 'jnn' / 'prefix' / 'stat_pa' (host arithmetic only)"""
     p = StatPlan()
-    check(load_library().sgk_stat_plan({"stat": 0, "jnn": 1, "prefix": 2}[tool], int(n_reads), int(n_samples),
+    check(load_library().sgk_stat_plan({"stat": 0, "jnn": 1, "prefix": 2, "stat_pa": 3}[tool], int(n_reads), int(n_samples),
                                        int(max_read_len), C.byref(opt if opt is not None else STAT_OPTIONS), C.byref(p)),
           "sgk_stat_plan")
     return p

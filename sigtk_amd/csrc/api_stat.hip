@@ -112,13 +112,13 @@ int sgk_prefix(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *out, v
 
 int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, const sgk_stat_options_t *opt,
                   sgk_stat_plan_t *out) {
-    if (!out || tool < 0 || tool > 2) return SGK_ERR_ARG;
+    if (!out || tool < 0 || tool > 3) return SGK_ERR_ARG;
     memset(out, 0, sizeof *out);
     const int kernels = opt ? opt->kernels : 0;
     const int32_t lm_opt = opt ? opt->long_min : 0;
     out->kernels = stat_lane_per_read(tool, kernels, n_reads, n_samples, max_read_len) ? 1u : 2u;
     out->workspace_bytes = stat_ws(n_reads, n_samples, max_read_len);
-    const uint32_t lm = long_threshold(n_samples, lm_opt, tool == 0 ? LC_AUTO_DIV_STAT : (tool == 1 ? LC_AUTO_DIV_JNN : LC_AUTO_DIV_PREFIX));
+    const uint32_t lm = long_threshold(n_samples, lm_opt, tool == 1 ? LC_AUTO_DIV_JNN : (tool == 2 ? LC_AUTO_DIV_PREFIX : LC_AUTO_DIV_STAT));
     // (the long-read path belongs to the wave-per-read kernels and needs a read that long in the batch)
     if (out->kernels == 2u && lm_opt >= 0 && max_read_len >= lm) {
         out->long_min = lm;

@@ -73,7 +73,7 @@ size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
 uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, uint32_t auto_div);
 constexpr uint32_t LC_AUTO_DIV_STAT = 2048, LC_AUTO_DIV_JNN = 3072, LC_AUTO_DIV_PREFIX = 2048;
 // which implementation a batch takes (sgk_stat_options_t::kernels)
-bool stat_lane_per_read(int tool /* 0 stat, 1 jnn, 2 prefix */, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
+bool stat_lane_per_read(int tool /* 0 stat, 1 jnn, 2 prefix, 3 stat + pA */, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
 // clears the header and lists the long reads; auto_div: long_min = max(262 144, n_samples / auto_div) when the option is 0
 int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st);

@@ -10,10 +10,13 @@ def plan(tool, n_reads, read_len, longest=None, **opt):
 
 
 def test_uniform_batches_have_no_long_reads_and_take_the_wave_kernels():
-    for tool in ("stat", "jnn", "prefix"):
+    for tool in ("stat_pa", "jnn", "prefix"):
         p = plan(tool, 125000, 100000)
         assert (p.kernels, p.long_min, p.long_max_reads) == (2, 0, 0)
         assert p.workspace_bytes > 125000 * 4
+    assert plan("stat", 60000, 100000).kernels == 2
+    assert plan("stat", 125000, 100000).kernels == 1        # plain stat on >= 100 000 reads: the lane kernels
+    assert plan("stat_pa", 400000, 5000).kernels == 1
 
 
 def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
@@ -23,7 +26,8 @@ def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 40000, 20000).kernels == 2           # ... longer reads need 49 152
     assert plan("stat", 10000, 5000).kernels == 2
     assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
-    assert plan("stat", 100000, 40000).kernels == 2
+    assert plan("stat", 90000, 40000).kernels == 2
+    assert plan("stat_pa", 100000, 40000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
     assert plan("jnn", 400000, 5000).kernels == 1            # jnn: >= 65 536 reads of up to 12 288 samples
     assert plan("jnn", 60000, 5000).kernels == 2
@@ -60,6 +64,6 @@ def test_bad_arguments():
     import ctypes as C
     L = api.load_library()
     p = api.StatPlan()
-    assert L.sgk_stat_plan(3, 1, 1, 1, None, C.byref(p)) != 0
+    assert L.sgk_stat_plan(4, 1, 1, 1, None, C.byref(p)) != 0
     assert L.sgk_stat_plan(0, 1, 1, 1, None, None) != 0
     assert L.sgk_stat_plan(0, 10, 1000, 100, None, C.byref(p)) == 0 and p.kernels == 2
