@@ -193,11 +193,26 @@ __device__ inline RowPrefetch make_stream(char *lds, const sgk_batch_t &b, int64
     return rs;
 }
 
+// (sgk_stat_rec_t::reserved / sgk_prefix_rec_t::reserved between kernels: reads whose median is still to be found)
+constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_POLYA = 2u;
+
 // ---------------------------------------------------------------- moments (src/stat.h:17-54)
-template <int MODE>
+// HIST (stat without the pA output): the deviation pass also counts, per lane, the samples in a window of MH_BINS raw
+// values around the read's mean (a column of LDS words per lane: no other lane touches it) and those below it, and the
+// read's median (rank n/2 and, for a negative unit, n-1-n/2: src/stat.h:56-73) is read off that: the third pass over
+// the samples (k_median) is only needed for reads whose median lies outside the window (flagged for k_median; the sp1
+// fixture's reads have their median -10 .. +21 raw values from their mean, 13 at the 99th percentile: a few per cent of
+// real reads, whose k_median workgroups cost in proportion).  The lane kernels are bound by HBM and close to bound by
+// instruction issue: 125 000 x 100 000 samples 13.0 (k_moments 9.0 + k_median 4.0) -> 10.8 ms with 32 bins; 64 bins
+// (16 KB of LDS per wave) lose the occupancy the kernel streams with (16.5 ms), 64 16-bit counters packed two to a word
+// cost more instructions than they save (12.6 ms).
+constexpr int MH_BINS = 32;
+template <int MODE, bool HIST = false>
 __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
-    const uint32_t r = blockIdx.x * 64 + lane_id();
+    __shared__ uint32_t mh[HIST ? MH_BINS * 64 : 1];
+    const int lane = lane_id();
+    const uint32_t r = blockIdx.x * 64 + lane;
     const bool valid = r < a.b.n_reads;
     Region g = {0, 0};
     Scale sc = {0.0f, 1.0f};
@@ -215,11 +230,24 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
     });
     const float mraw = sraw / nf, mpa = spa / nf;
     float qraw = 0.0f, qpa = 0.0f;
+    int lo = 0;
+    uint32_t below = 0u;
+    if (HIST) {
+        const int c = (mraw == mraw) ? (int)fminf(fmaxf(mraw, -32768.0f), 32767.0f) : 0;
+        lo = c - MH_BINS / 2;
+#pragma unroll
+        for (int b = 0; b < MH_BINS; ++b) mh[b * 64 + lane] = 0u;
+    }
     sweep_rows(rs, skip, g.len, [&](int64_t, int16_t v) {
         const float d = (float)v - mraw;
         qraw = qraw + d * d;
         const float e = to_pa(v, sc) - mpa;
         qpa = qpa + e * e;
+        if (HIST) {
+            const int b = (int)v - lo;
+            if ((unsigned)b < (unsigned)MH_BINS) atomicAdd(&mh[b * 64 + lane], 1u);  // (this lane's column)
+            below += b < 0 ? 1u : 0u;
+        }
     });
     if (!valid) return;
     const float sdraw = sqrtf(qraw / nf), sdpa = sqrtf(qpa / nf);
@@ -228,6 +256,24 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
         o->raw_mean = mraw; o->pa_mean = mpa; o->raw_std = sdraw; o->pa_std = sdpa;
         o->n = (uint32_t)g.len;
         o->reserved = 0;
+        if (HIST) {
+            if (g.len <= 0) { o->raw_median = 0; o->pa_median = 0.0f; return; }
+            const uint32_t k = (uint32_t)(g.len / 2);
+            const bool mirrored = sc.unit < 0.0f && g.len - 1 - (int64_t)k != (int64_t)k;  // pA order is the reverse of the raw order
+            const uint32_t k2 = mirrored ? (uint32_t)(g.len - 1 - (int64_t)k) : k;
+            int b1 = -1, b2 = -1;
+            uint32_t acc = below;
+            for (int b = 0; b < MH_BINS; ++b) {
+                const uint32_t h = mh[b * 64 + lane];
+                if (b1 < 0 && k >= acc && k < acc + h) b1 = b;
+                if (b2 < 0 && k2 >= acc && k2 < acc + h) b2 = b;
+                acc += h;
+            }
+            if (b1 >= 0 && b2 >= 0) {
+                o->raw_median = lo + b1;
+                o->pa_median = to_pa((int16_t)(lo + b2), sc);
+            } else o->reserved = FLAG_MEDIAN_WHOLE;  // outside the window: k_median (FLAGGED) takes the read
+        }
     } else if (MODE == REG_ADAPT) {
         a.prefix[r].adapt_mean = mpa;
         a.prefix[r].adapt_std = sdpa;
@@ -464,7 +510,6 @@ __device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
 // length of ITS read, not for the longest read among 64 neighbours as in the lane-per-read kernels above.
 constexpr int WH_BINS = 2048;
 static_assert(WH_BINS == (int)LC_HIST_BINS, "the long reads' histograms in the workspace");
-constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_POLYA = 2u;
 
 struct WaveTile {
     uint32_t w[SS_SPL / 2];
@@ -2768,10 +2813,22 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
     const uint32_t nr = a.b.n_reads;
     if (nr == 0) return SGK_OK;
     if (lane_per_read(a.pa_out ? 3 : 0, a)) {
-        SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
-        SGK_HIP_TRY(hipGetLastError());
-        if (a.pa_out) SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
-        else SGK_LAUNCH("k_median", (k_median<REG_WHOLE, false>), nr, 256, a);
+        if (a.pa_out) {
+            SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
+        } else if (nr >= 81920u) {
+            // the medians come out of the moments' second pass; k_median only for the reads it flagged.  (With fewer reads
+            // k_moments has too few wavefronts -- 64 reads each -- to hide what the counting adds, and k_median, a
+            // workgroup per read, fills the GPU: 61 035 x 32 768 fused 2.70, apart 2.33 ms; 100 000 x 20 000 2.00 / 2.24.)
+            SGK_LAUNCH("k_moments_median", (k_moments<REG_WHOLE, true>), (nr + 63) / 64, 64, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median_flagged", (k_median<REG_WHOLE, false, true>), nr, 256, a);
+        } else {
+            SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median", (k_median<REG_WHOLE, false>), nr, 256, a);
+        }
         SGK_HIP_TRY(hipGetLastError());
         return SGK_OK;
     }
