@@ -251,25 +251,29 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
     });
     if (!valid) return;
     const float sdraw = sqrtf(qraw / nf), sdpa = sqrtf(qpa / nf);
+    // HIST: the order statistics of ranks n/2 and (negative unit) n-1-n/2 from the window's counts
+    int b1 = -1, b2 = -1;
+    if (HIST && g.len > 0) {
+        const uint32_t k = (uint32_t)(g.len / 2);
+        const bool mirrored = sc.unit < 0.0f && g.len - 1 - (int64_t)k != (int64_t)k;  // pA order is the reverse of the raw order
+        const uint32_t k2 = mirrored ? (uint32_t)(g.len - 1 - (int64_t)k) : k;
+        uint32_t acc = below;
+        for (int b = 0; b < MH_BINS; ++b) {
+            const uint32_t h = mh[b * 64 + lane];
+            if (b1 < 0 && k >= acc && k < acc + h) b1 = b;
+            if (b2 < 0 && k2 >= acc && k2 < acc + h) b2 = b;
+            acc += h;
+        }
+    }
+    const bool have_median = b1 >= 0 && b2 >= 0;
     if (MODE == REG_WHOLE) {
         sgk_stat_rec_t *o = a.stat + r;
         o->raw_mean = mraw; o->pa_mean = mpa; o->raw_std = sdraw; o->pa_std = sdpa;
         o->n = (uint32_t)g.len;
         o->reserved = 0;
         if (HIST) {
-            if (g.len <= 0) { o->raw_median = 0; o->pa_median = 0.0f; return; }
-            const uint32_t k = (uint32_t)(g.len / 2);
-            const bool mirrored = sc.unit < 0.0f && g.len - 1 - (int64_t)k != (int64_t)k;  // pA order is the reverse of the raw order
-            const uint32_t k2 = mirrored ? (uint32_t)(g.len - 1 - (int64_t)k) : k;
-            int b1 = -1, b2 = -1;
-            uint32_t acc = below;
-            for (int b = 0; b < MH_BINS; ++b) {
-                const uint32_t h = mh[b * 64 + lane];
-                if (b1 < 0 && k >= acc && k < acc + h) b1 = b;
-                if (b2 < 0 && k2 >= acc && k2 < acc + h) b2 = b;
-                acc += h;
-            }
-            if (b1 >= 0 && b2 >= 0) {
+            if (g.len <= 0) { o->raw_median = 0; o->pa_median = 0.0f; }
+            else if (have_median) {
                 o->raw_median = lo + b1;
                 o->pa_median = to_pa((int16_t)(lo + b2), sc);
             } else o->reserved = FLAG_MEDIAN_WHOLE;  // outside the window: k_median (FLAGGED) takes the read
@@ -277,9 +281,17 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
     } else if (MODE == REG_ADAPT) {
         a.prefix[r].adapt_mean = mpa;
         a.prefix[r].adapt_std = sdpa;
+        if (HIST && g.len > 0) {
+            if (have_median) a.prefix[r].adapt_median = to_pa((int16_t)(lo + b2), sc);
+            else a.prefix[r].reserved |= FLAG_MEDIAN_ADAPT;
+        }
     } else {
         a.prefix[r].polya_mean = mpa;
         a.prefix[r].polya_std = sdpa;
+        if (HIST && g.len > 0) {
+            if (have_median) a.prefix[r].polya_median = to_pa((int16_t)(lo + b2), sc);
+            else a.prefix[r].reserved |= FLAG_MEDIAN_POLYA;
+        }
     }
 }
 
@@ -2919,7 +2931,11 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
         if (rc != SGK_OK) return rc;
     }
     SGK_HIP_TRY(hipGetLastError());
-    if (lane_regions) {
+    if (lane_regions && !lanes) {  // (the medians out of the moments' second pass, k_median for the regions it flags)
+        SGK_LAUNCH("k_moments_median_adapt", (k_moments<REG_ADAPT, true>), gw, 64, a);
+        SGK_HIP_TRY(hipGetLastError());
+        SGK_LAUNCH("k_median_adapt_flagged", (k_median<REG_ADAPT, false, true>), nr, 256, a);
+    } else if (lane_regions) {
         SGK_LAUNCH("k_moments_adapt", (k_moments<REG_ADAPT>), gw, 64, a);
         SGK_HIP_TRY(hipGetLastError());
         SGK_LAUNCH("k_median_adapt", (k_median<REG_ADAPT>), nr, 256, a);
@@ -2933,7 +2949,11 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
         if (lanes) SGK_LAUNCH("k_polya", k_polya, gw, 64, a);
         else SGK_LAUNCH("k_polya_wave", k_polya_wave, (nr + 3) / 4, 256, a);
         SGK_HIP_TRY(hipGetLastError());
-        if (lane_regions) {
+        if (lane_regions && !lanes) {
+            SGK_LAUNCH("k_moments_median_polya", (k_moments<REG_POLYA, true>), gw, 64, a);
+            SGK_HIP_TRY(hipGetLastError());
+            SGK_LAUNCH("k_median_polya_flagged", (k_median<REG_POLYA, false, true>), nr, 256, a);
+        } else if (lane_regions) {
             SGK_LAUNCH("k_moments_polya", (k_moments<REG_POLYA>), gw, 64, a);
             SGK_HIP_TRY(hipGetLastError());
             SGK_LAUNCH("k_median_polya", (k_median<REG_POLYA>), nr, 256, a);

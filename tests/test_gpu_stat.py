@@ -340,3 +340,37 @@ def test_stat_negative_raw_sum_is_exact_and_not_slow(gpu, oracle):
         torch.cuda.synchronize()
         times[name] = e0.elapsed_time(e1) / 5
     assert times["neg"] < 1.5 * times["pos"] + 0.05, times
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_large_batch_choices_match_the_wave_kernels(gpu, kind):
+    """what kernels = 0 picks for a large batch (stat: one read per lane with the median out of k_moments' second pass;
+    prefix: the wave finders + the lane kernels for the region statistics, medians likewise) against the wave kernels
+    alone, record for record; reads that defeat the 32-value median window (constant, two-valued, wide) included"""
+    import torch
+    from sigtk_amd import device
+    rs = np.random.RandomState(17 + kind)
+    n = 90000
+    lens = rs.randint(2500, 4200, size=n).astype(np.int64)
+    dev = torch.device("cuda", 0)
+    b = device.synth_reads(n, 0, seed=29 + kind, kind=kind, device=dev, lengths=lens)
+    host = b.samples.cpu().numpy().copy()
+    for r in rs.randint(0, n, size=400):
+        o, m = int(b.offsets_host[r]), int(lens[r])
+        u = rs.rand()
+        if u < 0.3: host[o:o + m] = rs.randint(-100, 2000)
+        elif u < 0.6: host[o:o + m] = np.where(rs.rand(m) < 0.5, 300, 900)
+        else: host[o:o + m] = rs.randint(-2000, 2000, size=m)
+    b.samples.copy_(torch.from_numpy(host).to(dev))
+    out = {}
+    for kernels in (0, 2):
+        gpu.stat_configure(kernels)
+        try:
+            st = device.stat(b).cpu().numpy().copy()
+            pf = device.prefix(b, kind, 0).cpu().numpy().copy()
+        finally:
+            gpu.stat_configure(0)
+        out[kernels] = (st, pf)
+    assert gpu.stat_plan("stat", n, int(lens.sum()), int(lens.max())).kernels == 1
+    assert out[0][0].tobytes() == out[2][0].tobytes()
+    assert out[0][1].tobytes() == out[2][1].tobytes()
