@@ -352,15 +352,21 @@ def test_large_batch_choices_match_the_wave_kernels(gpu, kind):
     rs = np.random.RandomState(17 + kind)
     n = 90000
     lens = rs.randint(2500, 4200, size=n).astype(np.int64)
+    lens[rs.randint(0, n, size=300)] = rs.randint(0, 12, size=300)       # empty and tiny reads
     dev = torch.device("cuda", 0)
     b = device.synth_reads(n, 0, seed=29 + kind, kind=kind, device=dev, lengths=lens)
+    rng = b.rng.cpu().numpy().copy()
+    rng[rs.randint(0, n, size=2000)] *= -1.0                              # negative unit: the pA median mirrors the raw ranks
+    b.rng.copy_(torch.from_numpy(rng).to(dev))
     host = b.samples.cpu().numpy().copy()
     for r in rs.randint(0, n, size=400):
         o, m = int(b.offsets_host[r]), int(lens[r])
         u = rs.rand()
-        if u < 0.3: host[o:o + m] = rs.randint(-100, 2000)
-        elif u < 0.6: host[o:o + m] = np.where(rs.rand(m) < 0.5, 300, 900)
-        else: host[o:o + m] = rs.randint(-2000, 2000, size=m)
+        if m == 0: continue
+        if u < 0.25: host[o:o + m] = rs.randint(-100, 2000)
+        elif u < 0.5: host[o:o + m] = np.where(rs.rand(m) < 0.5, 300, 900)
+        elif u < 0.75: host[o:o + m] = rs.randint(-2000, 2000, size=m)
+        else: host[o:o + m] = np.where(rs.rand(m) < 0.5, 500, 500 + rs.randint(1, 40))   # the median on a window edge
     b.samples.copy_(torch.from_numpy(host).to(dev))
     out = {}
     for kernels in (0, 2):
