@@ -203,14 +203,15 @@ constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_P
 // the samples (k_median) is only needed for reads whose median lies outside the window (flagged for k_median; the sp1
 // fixture's reads have their median -10 .. +21 raw values from their mean, 13 at the 99th percentile: a few per cent of
 // real reads, whose k_median workgroups cost in proportion).  The lane kernels are bound by HBM and close to bound by
-// instruction issue: 125 000 x 100 000 samples 13.0 (k_moments 9.0 + k_median 4.0) -> 10.8 ms with 32 bins; 64 bins
+// instruction issue: 125 000 x 100 000 samples 13.0 (k_moments 9.0 + k_median 4.0) -> 10.0 ms with 32 bins (10.8 with a
+// branch around the counting instead of the extra row); 64 bins
 // (16 KB of LDS per wave) lose the occupancy the kernel streams with (16.5 ms), 64 16-bit counters packed two to a word
 // cost more instructions than they save (12.6 ms).
 constexpr int MH_BINS = 32;
 template <int MODE, bool HIST = false>
 __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
-    __shared__ uint32_t mh[HIST ? MH_BINS * 64 : 1];
+    __shared__ uint32_t mh[HIST ? (MH_BINS + 1) * 64 : 1];  // (+ a row nobody reads: samples outside the window)
     const int lane = lane_id();
     const uint32_t r = blockIdx.x * 64 + lane;
     const bool valid = r < a.b.n_reads;
@@ -244,9 +245,10 @@ __global__ __launch_bounds__(64) void k_moments(StatArgs a) {
         const float e = to_pa(v, sc) - mpa;
         qpa = qpa + e * e;
         if (HIST) {
-            const int b = (int)v - lo;
-            if ((unsigned)b < (unsigned)MH_BINS) atomicAdd(&mh[b * 64 + lane], 1u);  // (this lane's column)
-            below += b < 0 ? 1u : 0u;
+            // (no branch: a sample outside the window goes to the extra row; this lane's column)
+            const uint32_t b = (uint32_t)((int)v - lo);
+            atomicAdd(&mh[(b < (uint32_t)MH_BINS ? b : (uint32_t)MH_BINS) * 64u + (uint32_t)lane], 1u);
+            below += b >> 31;
         }
     });
     if (!valid) return;
