@@ -249,7 +249,7 @@ int sgk_prefix(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *ou
 /* Per-call options of stat / jnn / prefix (null = defaults).  The library has two implementations of these subtools:
  * one read per wavefront (round 2; any batch) and one read per lane (round 1; wins on large batches of short reads of
  * similar length: stat >= 49 152 reads of <= 32 768 samples or >= 16 384 reads of <= 16 384 (without the pA output also
- * >= 100 000 reads of <= 131 072), jnn >= 65 536 reads of <= 12 288 samples,
+ * >= 81 920 reads of <= 131 072), jnn >= 65 536 reads of <= 12 288 samples,
  * the longest <= 1.5 x the mean; prefix: the wave finders, and the lane kernels for the statistics of the regions they find
  * when the batch has >= 49 152 reads; sgk_stat_plan tells).  kernels: 0 chosen per batch,
  * 1 one read per lane, 2 one read per wavefront.  Results do not depend on it (the tests compare the two bit for bit). */

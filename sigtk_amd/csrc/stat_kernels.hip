@@ -2784,9 +2784,10 @@ bool stat_lane_per_read(int tool, int kernels, uint32_t n_reads, uint64_t n_samp
     if (kernels == 1) return true;
     if (kernels == 2) return false;
     if ((uint64_t)max_read_len * n_reads > n_samples + n_samples / 2) return false;  // not of similar length
-    // (plain stat on very large batches as well: 125 000 x 100 000 13.0 against 14.1 ms, 250 000 x 50 000 12.3 against 16.2;
-    // with the pA output -- tool 3 -- the wave kernel's fused pass stays ahead there: 22.9 against 24.6)
-    if (tool == 0 && n_reads >= 100000u && max_read_len <= 131072u) return true;
+    // (plain stat on very large batches as well, where the median comes out of k_moments' second pass: 82 000 x 100 000
+    // 8.0 against 9.2 ms, 125 000 x 100 000 10.0 against 14.1, 250 000 x 50 000 10.5 against 16.2; with the pA output --
+    // tool 3 -- the wave kernel's fused pass stays ahead there: 22.9 against 24.6)
+    if (tool == 0 && n_reads >= 81920u && max_read_len <= 131072u) return true;
     if (tool == 0 || tool == 3) return (n_reads >= 49152u && max_read_len <= 32768u) || (n_reads >= 16384u && max_read_len <= 16384u);
     if (tool == 2) return false;  // (prefix: the wave finders win at every shape; its region statistics: launch_prefix)
     return n_reads >= 65536u && max_read_len <= 12288u;

@@ -15,7 +15,8 @@ def test_uniform_batches_have_no_long_reads_and_take_the_wave_kernels():
         assert (p.kernels, p.long_min, p.long_max_reads) == (2, 0, 0)
         assert p.workspace_bytes > 125000 * 4
     assert plan("stat", 60000, 100000).kernels == 2
-    assert plan("stat", 125000, 100000).kernels == 1        # plain stat on >= 100 000 reads: the lane kernels
+    assert plan("stat", 125000, 100000).kernels == 1        # plain stat on >= 81 920 reads: the lane kernels
+    assert plan("stat", 82000, 100000).kernels == 1
     assert plan("stat_pa", 400000, 5000).kernels == 1
 
 
@@ -26,7 +27,7 @@ def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 40000, 20000).kernels == 2           # ... longer reads need 49 152
     assert plan("stat", 10000, 5000).kernels == 2
     assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
-    assert plan("stat", 90000, 40000).kernels == 2
+    assert plan("stat", 80000, 40000).kernels == 2
     assert plan("stat_pa", 100000, 40000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
     assert plan("jnn", 400000, 5000).kernels == 1            # jnn: >= 65 536 reads of up to 12 288 samples
