@@ -65,8 +65,12 @@ extern "C" {
  * Bindings should compare sgk_version() with the header they were written against.
  * 0.2.1: sgk_stat_options_t::long_min (was reserved), sgk_stat_long_status, sgk_stat_plan; sgk_stat / sgk_jnn / sgk_prefix_workspace_bytes
  *        ask for the long reads' records as well (an older, smaller workspace still works: long reads then run on one
- *        wavefront). */
-#define SGK_VERSION_STRING "0.2.1"
+ *        wavefront).
+ * 0.2.2: the long-read path of stat / jnn / prefix declines a read whose workgroups time out at a barrier and the wave
+ *        kernel redoes it (no result depends on the long path having worked; sgk_long_status_t::n_timeouts counts those
+ *        reads); sgk_stat_options_t::debug_fault (was reserved[0]); sgk_job_long_declined;
+ *        the six-argument plan call is sgk_event_plan_opt; sgk_event_plan is the 0.1.0 five-argument form again (deprecated). */
+#define SGK_VERSION_STRING "0.2.2"
 
 /* ---- error codes --------------------------------------------------------------- */
 #define SGK_OK 0
@@ -128,6 +132,9 @@ typedef struct sgk_event_rec {
  * (incl. reads shorter than 2*window) yields one event [0,n); empty reads yield none. */
 static inline uint64_t sgk_event_slots_for(uint64_t n_samples_of_read) { return n_samples_of_read / 3 + 2; }
 
+/* (the tail split is planned from the CURRENT device's compute units -- 256 without one: size a workspace with the
+ * device the launch will use current, sgk_set_device; a workspace sized for another device makes the launch return
+ * SGK_ERR_WORKSPACE, never write out of bounds) */
 size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 
 int sgk_event(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events,
@@ -188,7 +195,8 @@ int sgk_event_pa_opt(const float *pa, const uint64_t *offsets, const uint32_t *l
 
 /* How sgk_event_opt would take a batch with these totals under `opt` (host only, no GPU work; the tail split assumes
  * the current device's CU count, 256 without a device): the segment geometry and list capacities of the long reads, the
- * threshold and the lanes per read of the short ones (0: every read has a wavefront of its own), the tail split. */
+ * threshold and the lanes per read of the short ones (0: every read has a wavefront of its own), the tail split.
+ * Run it with the device the launch will use current (sgk_set_device): so must sgk_event_workspace_bytes(_opt). */
 typedef struct sgk_event_plan {
     uint32_t segment_len, long_min;         /* long reads: >= long_min samples, cut into segments of segment_len */
     uint32_t max_segments, max_long_reads;  /* capacities reserved in the workspace (0: no read is cut)           */
@@ -199,8 +207,12 @@ typedef struct sgk_event_plan {
     uint32_t tail_segment_len;              /* ... are cut into segments of this many samples (0: none)           */
     uint32_t reserved[3];
 } sgk_event_plan_t;
-int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
-                   sgk_event_plan_t *out);
+int sgk_event_plan_opt(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
+                       const sgk_event_options_t *opt, sgk_event_plan_t *out);
+/* Deprecated: the 0.1.0 call under its 0.1.0 name and signature -- the defaults, and only the first 32 bytes of the
+ * struct (what sgk_event_plan_t was then: up to warmup_override + one reserved word).  0.2.0 / 0.2.1 had the
+ * six-argument form under this symbol; it is sgk_event_plan_opt now, so that no caller can bind the wrong one. */
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, void *out32);
 
 /* Synchronises `stream`, copies the status block of the last sgk_event on this workspace.
  * Returns SGK_ERR_CAPACITY if any read overflowed its slots. */
@@ -262,7 +274,9 @@ typedef struct sgk_stat_options {
                          * none if that still lists more than 128 reads: a batch of similar long reads balances itself);
                          * -1 = never; else the threshold (>= 8 192).  Results do not depend on it.  Needs the workspace
                          * sgk_*_workspace_bytes asks for (with less, such reads run on one wavefront). */
-    uint32_t reserved[2];
+    uint32_t debug_fault; /* 0.  Tests only: fault injection into the long-read path's barriers (a withheld workgroup /
+                           * a tiny spin bound, see lc_barrier in csrc/stat_kernels.hip) to exercise the decline-and-redo path */
+    uint32_t reserved;
 } sgk_stat_options_t;
 int sgk_stat_opt(const sgk_batch_t *batch, sgk_stat_rec_t *out, void *workspace, size_t workspace_bytes, void *stream,
                  const sgk_stat_options_t *opt);
@@ -291,7 +305,11 @@ int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_r
                   sgk_stat_plan_t *out);
 typedef struct sgk_long_status {
     uint32_t n_long_reads, n_tiles, n_true_tiles;
-    uint32_t n_timeouts;  /* must be 0: a workgroup gave up waiting for the others of its read (its results are wrong) */
+    uint32_t n_timeouts;  /* long reads DECLINED by the long path: a workgroup of the read gave up at a barrier (after
+                           * seconds: never on a GPU of its own) or was told that another one had.  Nothing of such a read
+                           * is written by the long path; the wave-per-read kernel redoes it on one wavefront behind the
+                           * join, so the results are right either way (0.2.1 left them wrong and only counted here);
+                           * jobs report the count through sgk_job_long_declined() */
 } sgk_long_status_t;
 int sgk_stat_long_status(const void *workspace, size_t workspace_bytes, uint32_t n_reads, sgk_long_status_t *out);
 
@@ -479,6 +497,10 @@ int sgk_job_submit_qts(sgk_job_t *job, int bits, int method, int out_signal_form
 int sgk_job_wait(sgk_job_t *job);
 /* valid after sgk_job_wait until the job's next sgk_job_begin */
 int sgk_job_output(const sgk_job_t *job, sgk_job_output_t *out);
+/* stat / jnn / prefix jobs, after sgk_job_wait: long reads the 16-workgroup path declined (a barrier wait timed out) and
+ * the wave-per-read kernel redid -- sgk_long_status_t::n_timeouts of the job's last submit.  The records are right
+ * either way; non-zero means the GPU did not dispatch a grid's workgroups the way the long path assumes (0.2.2). */
+uint32_t sgk_job_long_declined(const sgk_job_t *job);
 
 /* ---- per-read shims with the reference's own signatures (batch of one) ------------- */
 /* event_t / event_table exactly as src/sigtk.h:55-70 */

@@ -60,7 +60,7 @@ class EventOptions(C.Structure):   # sgk_event_options_t (all zero = the default
 
 
 class StatOptions(C.Structure):   # sgk_stat_options_t
-    _fields_ = [("kernels", C.c_int32), ("long_min", C.c_int32), ("reserved", C.c_uint32 * 2)]
+    _fields_ = [("kernels", C.c_int32), ("long_min", C.c_int32), ("debug_fault", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class StatPlan(C.Structure):      # sgk_stat_plan_t
@@ -121,8 +121,8 @@ def stat_plan(tool: str, n_reads: int, n_samples: int, max_read_len: int, opt: "
 
 def event_plan(n_reads: int, n_samples: int, max_read_len: int, rna: int, opt: "EventOptions" = None) -> EventPlan:
     p = EventPlan()
-    check(load_library().sgk_event_plan(int(n_reads), int(n_samples), int(max_read_len), int(rna),
-                                        C.byref(opt if opt is not None else EVENT_OPTIONS), C.byref(p)), "sgk_event_plan")
+    check(load_library().sgk_event_plan_opt(int(n_reads), int(n_samples), int(max_read_len), int(rna),
+                                        C.byref(opt if opt is not None else EVENT_OPTIONS), C.byref(p)), "sgk_event_plan_opt")
     return p
 
 
@@ -173,7 +173,7 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan", "sgk_event_plan_opt", "sgk_job_long_declined",
     "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
     "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_plan", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
@@ -228,16 +228,20 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                               [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     ver = L.sgk_version().decode()
-    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 1):
-        raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2 and the long-read "
-                            "status of 0.2.1" % (path, ver))
+    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 2):
+        raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2, the long-read status of "
+                            "0.2.1 and sgk_event_plan_opt / sgk_job_long_declined of 0.2.2" % (path, ver))
     OE, OS = C.POINTER(EventOptions), C.POINTER(StatOptions)
     L.sgk_event_workspace_bytes_opt.restype = C.c_size_t
     L.sgk_event_workspace_bytes_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, OE]
     L.sgk_event_opt.argtypes = L.sgk_event.argtypes + [OE]
     L.sgk_event_pa_opt.argtypes = L.sgk_event_pa.argtypes + [OE]
-    L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, OE, C.POINTER(EventPlan)]
+    L.sgk_event_plan_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, OE, C.POINTER(EventPlan)]
+    L.sgk_event_plan_opt.restype = C.c_int
+    L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]  # (0.1.0 form, deprecated)
     L.sgk_event_plan.restype = C.c_int
+    L.sgk_job_long_declined.argtypes = [C.c_void_p]
+    L.sgk_job_long_declined.restype = C.c_uint32
     L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sgk_stat_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

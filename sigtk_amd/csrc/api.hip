@@ -440,8 +440,8 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     return h.n_overflow ? SGK_ERR_CAPACITY : SGK_OK;
 }
 
-int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
-                   sgk_event_plan_t *out) {
+int sgk_event_plan_opt(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
+                       sgk_event_plan_t *out) {
     if (!out) return SGK_ERR_ARG;
     const sgk::EvSegConfig sc = sgk::event_config(opt);
     uint32_t max_segs = 0, max_long = 0, lanes = 0, mmax = 0, sf = n_reads, ss = 0;
@@ -460,6 +460,15 @@ int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, 
     out->tail_split_from = sf;
     out->tail_segment_len = ss;
     return SGK_OK;
+}
+// the 0.1.0 form under its 0.1.0 name (0.2.0 / 0.2.1 had put the six-argument form under this symbol: a caller compiled
+// against 0.1.0 then passed its `out` in the options' slot): the defaults, and only the 32 bytes that struct had
+int sgk_event_plan(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, void *out32) {
+    if (!out32) return SGK_ERR_ARG;
+    sgk_event_plan_t p;
+    const int rc = sgk_event_plan_opt(n_reads, n_samples, max_read_len, rna, nullptr, &p);
+    if (rc == SGK_OK) memcpy(out32, &p, 32);
+    return rc;
 }
 
 // ---------------------------------------------------------------- synthetic reads

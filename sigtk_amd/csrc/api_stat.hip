@@ -37,6 +37,7 @@ int sgk_stat_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, void *ws, size_t ws_
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
     a.kernels = opt ? opt->kernels : 0;
+    a.long_fault = opt ? opt->debug_fault : 0u;
     a.stat = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_STAT, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
@@ -56,6 +57,7 @@ int sgk_stat_pa_opt(const sgk_batch_t *b, sgk_stat_rec_t *out, float *pa_out, vo
     if (reinterpret_cast<uintptr_t>(pa_out) & 15u) return SGK_ERR_ALIGN;
     StatArgs a = make_args(b);
     a.kernels = opt ? opt->kernels : 0;
+    a.long_fault = opt ? opt->debug_fault : 0u;
     a.stat = out;
     a.pa_out = pa_out;  // written by the first pass of k_stat_wave (lane-per-read kernels: by the median pass)
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
@@ -76,6 +78,7 @@ int sgk_jnn_opt(const sgk_batch_t *b, int rna, const uint64_t *seg_slots, int32_
     if (ws_bytes < 64) return SGK_ERR_WORKSPACE;
     StatArgs a = make_args(b);
     a.kernels = opt ? opt->kernels : 0;
+    a.long_fault = opt ? opt->debug_fault : 0u;
     a.seg_slots = seg_slots;
     a.seg_x = seg_x;
     a.seg_y = seg_y;
@@ -99,6 +102,7 @@ int sgk_prefix_opt(const sgk_batch_t *b, int rna, int pore, sgk_prefix_rec_t *ou
     if (!out) return SGK_ERR_ARG;
     StatArgs a = make_args(b);
     a.kernels = opt ? opt->kernels : 0;
+    a.long_fault = opt ? opt->debug_fault : 0u;
     a.prefix = out;
     if ((rc = prepare_order(a, ws, ws_bytes, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
     if ((rc = prepare_long(a, ws, ws_bytes, opt ? opt->long_min : 0, LC_AUTO_DIV_PREFIX, static_cast<hipStream_t>(stream))) != SGK_OK) return rc;
@@ -137,7 +141,7 @@ int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_
     out->n_long_reads = h.n_long;
     out->n_tiles = h.n_tiles;
     out->n_true_tiles = h.n_true;
-    out->n_timeouts = h.n_timeout;
+    out->n_timeouts = h.n_declined;  // (h.n_timeout: the waits given up -- none when a fault was only injected)
     return SGK_OK;
 }
 

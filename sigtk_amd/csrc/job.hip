@@ -21,6 +21,7 @@
 #include <new>
 
 #include "sgk_common.h"
+#include "stat_args.h"
 
 namespace sgk {
 
@@ -85,7 +86,9 @@ struct sgk_job {
     // outputs: four generic arrays (start/length/mean/stdv | seg x/y | pa | records) + per-read counts
     GrowDev d_out[4], d_cnt;
     GrowDev d_dense[4], d_doffs;      // event / jnn: items gathered to dense per-read ranges before the download
-    GrowPin h_out[4], h_cnt, h_dstat, h_doffs, h_err;
+    GrowPin h_out[4], h_cnt, h_dstat, h_doffs, h_err, h_long;
+    bool long_fetched = false;        // stat / jnn / prefix: the long-read header of the call is on its way to h_long
+    uint32_t long_declined = 0;       // ... long reads the long path declined (n_timeouts of sgk_long_status_t), after wait
     int n_dense = 0;                  // arrays to fetch in sgk_job_wait once the dense total is known
     size_t ws_bytes = 0;
     int tool = -1, flags = 0;
@@ -94,6 +97,20 @@ struct sgk_job {
     sgk_event_options_t ev_opt;   // sgk_job_set_options (all zero: the defaults)
     sgk_stat_options_t st_opt;
 };
+
+// stat / jnn / prefix: the long-read path's header (64 bytes behind the dispatch order in the workspace) rides home with
+// the results, so that sgk_job_wait can tell how many long reads were declined and redone (n_timeouts of
+// sgk_long_status_t; the results are right either way)
+static int fetch_long_hdr(sgk_job *j, hipStream_t st) {
+    j->long_fetched = false;
+    const size_t off = order_workspace_bytes(j->n_reads);
+    if (!j->d_ws.p || j->d_ws.cap < off + long_workspace_bytes(0, 0)) return SGK_OK;
+    int rc;
+    if ((rc = j->h_long.ensure(sizeof(LongHdr))) != SGK_OK) return rc;
+    SGK_HIP_TRY(hipMemcpyAsync(j->h_long.p, static_cast<const char *>(j->d_ws.p) + off, sizeof(LongHdr), hipMemcpyDeviceToHost, st));
+    j->long_fetched = true;
+    return SGK_OK;
+}
 
 extern "C" {
 
@@ -375,6 +392,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
                 rc = sgk_jnn_opt(&view, rna, j->d_slots.as<uint64_t>(), j->d_out[0].as<int32_t>(),
                                  j->d_out[1].as<int32_t>(), j->d_cnt.as<uint32_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
+            if (!ev && (rc = fetch_long_hdr(j, st)) != SGK_OK) return rc;
             if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
             // the arena is capacity-sized (sgk_event_slots_for(n) slots per read): gather what was produced into dense ranges on the
             // device and download only that (sgk_job_wait fetches the arrays once the total is known)
@@ -411,6 +429,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
             rc = sgk_stat_opt(&view, j->d_out[0].as<sgk_stat_rec_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
+            if ((rc = fetch_long_hdr(j, st)) != SGK_OK) return rc;
             if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_stat_rec_t), st)) != SGK_OK) return rc;
             break;
         }
@@ -430,6 +449,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = j->d_ws.ensure(j->ws_bytes)) != SGK_OK) return rc;
             rc = sgk_prefix_opt(&view, rna, pore, j->d_out[0].as<sgk_prefix_rec_t>(), j->d_ws.p, j->d_ws.cap, st, &j->st_opt);
             if (rc != SGK_OK) return rc;
+            if ((rc = fetch_long_hdr(j, st)) != SGK_OK) return rc;
             if ((rc = d2h(j->h_out[0], j->d_out[0], nr * sizeof(sgk_prefix_rec_t), st)) != SGK_OK) return rc;
             break;
         }
@@ -487,7 +507,14 @@ int sgk_job_wait(sgk_job_t *j) {
     j->submitted = false;  // the staged batch stays valid: it may be submitted again (e.g. with another tool)
     memset(&j->ev_status, 0, sizeof j->ev_status);
     SGK_HIP_TRY(hipStreamSynchronize(j->st));
+    j->long_declined = 0u;
     if (j->n_reads == 0) return SGK_OK;
+    if (j->long_fetched) {
+        // n_timeouts of sgk_long_status_t: long reads whose workgroups gave up at a barrier; they were redone on one
+        // wavefront, the records are right -- a caller that wants to know (the CLI warns) asks sgk_job_long_declined
+        j->long_declined = reinterpret_cast<const LongHdr *>(j->h_long.p)->n_declined;
+        j->long_fetched = false;
+    }
     if (j->fmt == SGK_SIGNAL_SVBZD) {
         const uint32_t *ds = j->h_dstat.as<uint32_t>();
         for (uint32_t r = 0; r < j->n_reads; ++r)
@@ -526,6 +553,8 @@ int sgk_job_wait(sgk_job_t *j) {
     }
     return SGK_OK;
 }
+
+uint32_t sgk_job_long_declined(const sgk_job_t *j) { return j ? j->long_declined : 0u; }
 
 int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
     if (!j || !out) return SGK_ERR_ARG;

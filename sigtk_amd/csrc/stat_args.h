@@ -27,6 +27,9 @@ struct StatArgs {
     uint32_t *long_hist;         // stat: LC_CAP window histograms of LC_HIST_BINS bins
     uint32_t long_pool_tiles;
     uint32_t long_min;           // reads of at least this many samples are long
+    uint32_t long_redo;          // wave kernels: 1 = this launch only takes the long reads k_long_chains DECLINED (a barrier
+                                 // of theirs timed out): wave i looks at long_list[i], everything else returns at once
+    uint32_t long_fault;         // sgk_stat_options_t::debug_fault (tests): see lc_barrier
 };
 constexpr uint32_t JNN_REDO_MARK = 0xffffffffu;
 
@@ -42,8 +45,10 @@ struct LongHdr {
     uint32_t n_tiles;    // tile sums summarised
     uint32_t n_true;     // ... of which the composition had to evaluate from the true accumulator
     uint32_t pool_used;  // tile records handed out
-    uint32_t n_timeout;  // barriers given up after seconds (never, on a GPU that dispatches a grid's workgroups in order)
-    uint32_t pad[11];
+    uint32_t n_timeout;  // barrier waits given up after seconds (never, on a GPU that dispatches a grid's workgroups in
+                         // order): the read is DECLINED -- nothing of it is written -- and redone on one wavefront
+    uint32_t n_declined; // reads declined that way (counted by the redo launch that takes them)
+    uint32_t pad[10];
 };
 struct LongSums {
     uint32_t read;
@@ -58,9 +63,12 @@ struct LongWork {        // what the workgroups of one long read exchange (agent
     uint32_t arrive;     // barrier counter
     uint32_t n_true;
     float m[2];          // the sums' accumulators after level 2 (oriented)
+    uint32_t failed;     // a workgroup of the read gave up at a barrier: every workgroup leaves the read, its output is
+                         // whatever the redo launch of the wave kernel writes (lc_barrier)
+    uint32_t pad;
     unsigned long long seg_tot[LC_WAVES][2];  // pass A: sum of the terms of a wave's tiles (a double's bits)
 };
-static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64 && sizeof(LongWork) == 16 + 16 * LC_WAVES, "long-read workspace layout");
+static_assert(sizeof(LongSums) == 32 && sizeof(LongHdr) == 64 && sizeof(LongWork) == 24 + 16 * LC_WAVES, "long-read workspace layout");
 constexpr uint32_t LC_CAP = 512;              // long reads per batch that get a record (the rest run as before)
 constexpr uint32_t LC_NO_REC = 0xffffffffu;     // LongSums::rec_off of a long read without tile records
 constexpr uint32_t LC_HIST_BINS = 2048;       // stat's window histogram (WH_BINS)

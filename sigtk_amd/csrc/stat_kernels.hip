@@ -94,6 +94,19 @@ __device__ inline const LongSums *find_long(const StatArgs &a, uint32_t r, int64
     return nullptr;
 }
 
+// The redo launch of a wave kernel (StatArgs::long_redo): wave widx looks at entry widx of the long list and takes its
+// read iff k_long_chains declined it (a barrier of its workgroups timed out, lc_barrier).  Usually none: every wave
+// returns at once.
+__device__ inline bool long_redo_read(const StatArgs &a, uint32_t widx, uint32_t &r) {
+    if (!a.longs) return false;
+    const uint32_t nl = a.long_hdr->n_long, n = nl < LC_CAP ? nl : LC_CAP;
+    if (widx >= n) return false;
+    if (a.longs[widx].rec_off == LC_NO_REC || a.long_work[widx].failed == 0u) return false;
+    r = a.long_list[widx];
+    if (lane_id() == 0) atomicAdd(&a.long_hdr->n_declined, 1u);
+    return true;
+}
+
 __device__ inline float clampf_raw(int16_t v) {  // rm_outlier, src/jnn.c:61-77
     return v > 1200 ? 1200.0f : (v < 0 ? 0.0f : (float)v);
 }
@@ -799,8 +812,13 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     __shared__ uint32_t hist_all[4][WH_BINS];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
-    if (widx >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
-    const uint32_t r = a.order ? a.order[widx] : widx;
+    uint32_t r;
+    if (MODE == REG_WHOLE && a.long_redo) {
+        if (!long_redo_read(a, widx, r)) return;
+    } else {
+        if (widx >= a.b.n_reads) return;  // (no workgroup barrier anywhere in this kernel)
+        r = a.order ? a.order[widx] : widx;
+    }
     uint32_t *hist = hist_all[wv];
     const Region g = get_region(MODE, a.b, a.prefix, r);
     const Scale sc = make_scale(a.b.digitisation[r], a.b.offset[r], a.b.range[r]);
@@ -808,7 +826,7 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
     wr.init(a.b, g);
     const float nf = (float)(int)g.len;
     // a long read's record (and pA) is k_long_chains' work
-    if (MODE == REG_WHOLE) {
+    if (MODE == REG_WHOLE && !a.long_redo) {
         const LongSums *lg = find_long(a, r, g.len);
         if (lg && lg->rec_off != LC_NO_REC) return;
     }
@@ -1345,8 +1363,13 @@ __device__ inline uint32_t jnn_merge_flush(const JnnCarry &cy, int32_t *out_y, u
 __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;
-    if (widx >= a.b.n_reads) return;
-    const uint32_t r = a.order ? a.order[widx] : widx;
+    uint32_t r;
+    if (a.long_redo) {
+        if (!long_redo_read(a, widx, r)) return;
+    } else {
+        if (widx >= a.b.n_reads) return;
+        r = a.order ? a.order[widx] : widx;
+    }
     const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
     if (n <= 0) {
@@ -1360,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
         const float nf = (float)(int)n;
         float s = 0.0f, q = 0.0f;
         // a long read is k_long_chains' (sums, automaton and merge) if its slots have room for 4 096 chunks' headers
-        const LongSums *lg = find_long(a, r, n);
+        const LongSums *lg = a.long_redo ? nullptr : find_long(a, r, n);
         if (lg && lg->rec_off != LC_NO_REC && jnn_long_cap(a, r, wr.skip + n) >= 4u) return;
         {
             WaveTile cur, nxt;
@@ -2072,12 +2095,17 @@ __device__ inline void adaptor_find(const WaveRead &wr, int first_total, float s
 __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;
-    if (widx >= a.b.n_reads) return;
-    const uint32_t r = a.order ? a.order[widx] : widx;
+    uint32_t r;
+    if (a.long_redo) {
+        if (!long_redo_read(a, widx, r)) return;
+    } else {
+        if (widx >= a.b.n_reads) return;
+        r = a.order ? a.order[widx] : widx;
+    }
     const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
     // a long read is k_long_chains' (which runs beside this kernel): its sums, thresholds, run finder and record
-    const LongSums *lg = find_long(a, r, n);
+    const LongSums *lg = a.long_redo ? nullptr : find_long(a, r, n);
     if (lg && lg->rec_off != LC_NO_REC) return;
     sgk_prefix_rec_t *o = a.prefix + r;
     if (lane == 0) adaptor_init_rec(o, n);
@@ -2148,25 +2176,51 @@ struct LcCtx {
     unsigned long long *rec[2];  // tile records of the two sums: T0 | (E << 24 | LC_VALID | (T1 - T0 + 0x8000) & 0xffff) << 32
     uint32_t phase;              // barriers passed
     int part;                    // this workgroup's index among the read's LC_PARTS
+    uint32_t fault;              // StatArgs::long_fault
 };
-// all workgroups of the read; what they wrote with lc_st before is readable with lc_ld behind it
-__device__ inline void lc_barrier(LcCtx &cx) {
+// All workgroups of the read; what they wrote with lc_st before is readable with lc_ld behind it.  Returns false when
+// the read is DECLINED: this workgroup waited in vain (the bound -- seconds -- keeps a GPU that does not dispatch a
+// grid's workgroups in order, or shares its slots with something that does not end, from hanging) or another one of the
+// read did and said so in LongWork::failed.  Every workgroup then leaves the read without writing anything of the
+// subtool's output (all of it is written behind a read's LAST barrier: whoever passes that one has seen all LC_PARTS
+// arrive, so what it writes is right even if a late workgroup flagged the read meanwhile), and the redo launch of the
+// wave kernel (StatArgs::long_redo, behind the join) takes the read on one wavefront -- the path of every read before
+// round 4.  The event chain treats a timeout the same way (event_kernels.hip, chain_segment).
+// long_fault (tests only, sgk_stat_options_t::debug_fault): 1 | part << 8 | phase << 16: workgroup `part` never arrives
+// at barrier `phase` (1-based) and the spin bound is 2^12; 2 | bound << 8: that spin bound, nobody withheld.
+__device__ inline bool lc_barrier(LcCtx &cx) {
+    __shared__ uint32_t s_fail;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ++cx.phase;
     if (threadIdx.x == 0) {
-        atomicAdd(&cx.w->arrive, 1u);
-        const uint32_t target = cx.phase * (uint32_t)LC_PARTS;
-        // (the others are running or about to, see above; the bound -- seconds -- only keeps a GPU that does not behave
-        // that way from hanging: the read's results are then wrong and sgk_stat_long_status says so)
-        uint32_t spins = 0u;
-        while (lc_ld(&cx.w->arrive) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins == (1u << 24)) { atomicAdd(&cx.hdr->n_timeout, 1u); break; }
+        uint32_t fail = 0u, bound = 1u << 24;
+        const uint32_t mode = cx.fault & 0xffu;
+        if (mode == 1u) bound = 1u << 12;
+        else if (mode == 2u) bound = (cx.fault >> 8) ? (cx.fault >> 8) : 1u;
+        if (mode == 1u && (uint32_t)cx.part == ((cx.fault >> 8) & 0xffu) && cx.phase == ((cx.fault >> 16) & 0xffu)) {
+            lc_st(&cx.w->failed, 1u);  // (the withheld workgroup: it leaves, the others find out)
+            fail = 1u;
+        } else {
+            atomicAdd(&cx.w->arrive, 1u);
+            const uint32_t target = cx.phase * (uint32_t)LC_PARTS;
+            uint32_t spins = 0u;
+            while (lc_ld(&cx.w->arrive) < target) {
+                if (lc_ld(&cx.w->failed)) { fail = 1u; break; }
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins >= bound) {
+                    lc_st(&cx.w->failed, 1u);
+                    atomicAdd(&cx.hdr->n_timeout, 1u);
+                    fail = 1u;
+                    break;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_fail = fail;
     }
     __syncthreads();
+    return s_fail == 0u;  // (the next barrier's leading __syncthreads orders this read before the next write)
 }
 
 // level 1: the summary of one tile for the binade of the predicted accumulator mt; tsum: (about) the sum of its terms
@@ -2253,9 +2307,10 @@ __device__ inline float lc_compose(float m, const unsigned long long *rec, int n
 //   flip(c) / negated(c)     from now on sum c runs on the negated terms / does it?
 //   pass_a(t) / pass_b(t) / end_b()   what else the subtool does with the current tile in either pass, and once per
 //                            workgroup behind pass B (stat: pA output; window histogram)
-// Returns the SIGNED sums in out[].  Every wave of the read's LC_PARTS workgroups calls it (barriers inside).
+// Returns the SIGNED sums in out[]; false: the read is declined (lc_barrier), out[] means nothing.  Every wave of the
+// read's LC_PARTS workgroups calls it (barriers inside).
 template <typename SRC>
-__device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2], uint32_t &n_true_out) {
+__device__ inline bool lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2], uint32_t &n_true_out) {
     constexpr int N = SRC::NCH;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const int gw = cx.part * LC_WG_WAVES + wv;  // this wave among the read's LC_WAVES
@@ -2284,7 +2339,7 @@ __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2]
         const double tot = wave_sum_d(acc[c]);
         if (lane == 0) lc_st(&cx.w->seg_tot[gw][c], (unsigned long long)__double_as_longlong(tot));
     }
-    lc_barrier(cx);
+    if (!lc_barrier(cx)) return false;
     // the sum is oriented by the sign of the read's total (as the wave kernels orient it by the sign of the
     // accumulator): non-negative terms are what the summaries cover
     double mt[N];
@@ -2312,7 +2367,7 @@ __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2]
         }
     }
     src.end_b();
-    lc_barrier(cx);
+    if (!lc_barrier(cx)) return false;
     // ---- level 2: wave c of the read's first workgroup composes sum c
     if (cx.part == 0 && wv < N) {
         uint32_t n_true = 0u;
@@ -2322,10 +2377,11 @@ __device__ inline void lc_stage(SRC &src, LcCtx &cx, int ntiles, float (&out)[2]
             atomicAdd(&cx.w->n_true, n_true);
         }
     }
-    lc_barrier(cx);
+    if (!lc_barrier(cx)) return false;
 #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = ss_signed(ss_float(lc_ld(reinterpret_cast<const uint32_t *>(&cx.w->m[c]))), src.negated(c));
     n_true_out = lc_ld(&cx.w->n_true);
+    return true;
 }
 
 // ---- the tile sources
@@ -2503,6 +2559,7 @@ __global__ __launch_bounds__(256) void k_long_list(StatArgs a) {
     o->rec_off = off + need <= a.long_pool_tiles ? off : LC_NO_REC;  // (no room: the read runs on one wave as before)
     a.long_work[i].arrive = 0u;
     a.long_work[i].n_true = 0u;
+    a.long_work[i].failed = 0u;
 }
 // A batch whose own threshold still lists more reads than two rounds of the long kernel's grid take is a batch of
 // similar, long reads: one wave per read balances that by itself (1 000 reads of 500 000 samples: stat 1.4 ms) and
@@ -2531,6 +2588,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
         cx.rec[1] = a.long_pool + a.long_pool_tiles + o->rec_off;
         cx.phase = 0u;
         cx.part = (int)(blockIdx.x % LC_PARTS);
+        cx.fault = a.long_fault;
         float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
         uint32_t tiles = 0u, n_true = 0u, done = 1u;  // done: 1 the sums, 2 the subtool's whole output for this read
         if (KIND == LC_STAT) {
@@ -2541,11 +2599,11 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
             for (int b = (int)threadIdx.x; b < WH_BINS; b += LC_WG_WAVES * 64) hist[b] = 0u;
             SrcStatSums src1;
             src1.init(a.b, g, sc, a.pa_out);
-            lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
+            if (!lc_stage(src1, cx, src1.wr.ntiles, s1, n_true)) continue;  // declined: the redo launch has the read
             SrcStatDevs src2;
             src2.wr = src1.wr; src2.sc = sc; src2.mraw = s1[0] / nf; src2.mpa = s1[1] / nf;
             src2.lo = hist_window_lo(src2.mraw); src2.hist = hist; src2.ghist = ghist;
-            lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
+            if (!lc_stage(src2, cx, src2.wr.ntiles, s2, n_true)) continue;
             tiles = 4u * (uint32_t)src1.wr.ntiles;
             // the record: the read's histogram through this workgroup's LDS (everybody is behind the stage's last barrier)
             if (cx.part == 0 && threadIdx.x < 64) {
@@ -2563,10 +2621,10 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                 const float nf = (float)(int)g.len;
                 SrcClamp<false> src1;
                 src1.wr.init(a.b, g); src1.mean = 0.0f;
-                lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
+                if (!lc_stage(src1, cx, src1.wr.ntiles, s1, n_true)) continue;
                 SrcClamp<true> src2;
                 src2.wr = src1.wr; src2.mean = s1[0] / nf;
-                lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
+                if (!lc_stage(src2, cx, src2.wr.ntiles, s2, n_true)) continue;
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
                 // ---- the automaton on all waves: 64 chunks per wave (jnn_chunks), every chunk stages its first
                 // candidate and its strong segments in its part of the upper half of the read's slots; one wave merges
@@ -2601,7 +2659,7 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                             lc_st(sy_, (uint32_t)(has_first | (fstrong << 1))); lc_st(sy_ + 1, cnt);
                         }
                     }
-                    lc_barrier(cx);
+                    if (!lc_barrier(cx)) continue;
                     if (cx.part == 0 && wv == 0) {
                         JnnCarry cy = {false, false, false, 0, 0u};
                         for (int j = 0; j < C; j += 64) {
@@ -2625,10 +2683,10 @@ __global__ __launch_bounds__(LC_WG_WAVES * 64) void k_long_chains(StatArgs a, Jn
                 const float mf = (float)(int)m;
                 SrcRoll<false> src1;
                 src1.wr.init(a.b, Region{g.start, m}); src1.mean = 0.0f;
-                lc_stage(src1, cx, src1.wr.ntiles, s1, n_true);
+                if (!lc_stage(src1, cx, src1.wr.ntiles, s1, n_true)) continue;
                 SrcRoll<true> src2;
                 src2.wr = src1.wr; src2.mean = s1[0] / mf;
-                lc_stage(src2, cx, src2.wr.ntiles, s2, n_true);
+                if (!lc_stage(src2, cx, src2.wr.ntiles, s2, n_true)) continue;
                 tiles = 2u * (uint32_t)src1.wr.ntiles;
                 // thresholds, run finder (it stops at the first adaptor candidate) and the record: one wave
                 if (cx.part == 0 && threadIdx.x < 64) {
@@ -2726,7 +2784,7 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, u
     char *base = static_cast<char *>(ws) + off;
     const uint32_t pool = long_pool_tiles(a.b.n_samples, a.b.max_read_len);
     if (opt_long_min < 0 || a.b.max_read_len < lm || pool == 0u || ws_bytes < off + long_workspace_bytes(a.b.n_samples, a.b.max_read_len)) {
-        SGK_HIP_TRY(hipMemsetAsync(base, 0, 16, st));  // no long read in this call: sgk_stat_long_status says so
+        SGK_HIP_TRY(hipMemsetAsync(base, 0, sizeof(LongHdr), st));  // no long read in this call: sgk_stat_long_status says so
         return SGK_OK;
     }
     a.long_hdr = reinterpret_cast<LongHdr *>(base);
@@ -2806,20 +2864,32 @@ static bool lane_per_read(int tool, const StatArgs &a) {
 // stream and the wave kernel to a side stream that first waits for the fork event: launched the other way round the long
 // workgroups found every slot taken by the wave kernel's -- whose first workgroups hold the batch's longest reads -- and
 // started 2 ms late.  The side stream joins when the returned guard goes out of scope (or at guard.join()).
+// Behind the join the wave kernel is launched once more over the long list (wave_launch(stream, redo args): LC_CAP waves)
+// for the reads k_long_chains declined -- a barrier of theirs timed out, lc_barrier; usually none, the launch costs a few
+// microseconds: no read's result depends on the long path having worked.
 template <int KIND, typename WL>
-static int launch_beside_long(SideFork &side, const StatArgs &a, const JnnP &p, const AdaptP &ap, const char *name, hipStream_t st,
+static int launch_beside_long(const StatArgs &a, const JnnP &p, const AdaptP &ap, const char *name, hipStream_t st,
                               WL wave_launch) {
-    hipStream_t ws = st;
-    if (a.longs) {
+    if (!a.longs) {
+        wave_launch(st, a, (a.b.n_reads + 3) / 4);
+        SGK_HIP_TRY(hipGetLastError());
+        return SGK_OK;
+    }
+    {
+        SideFork side;  // (joins at the end of this block)
         const bool forked = side.open(0, st);
         {
             ProfScope ps_(name, st);
             hipLaunchKernelGGL((k_long_chains<KIND>), dim3(long_grid(a)), dim3(LC_WG_WAVES * 64), 0, st, a, p, ap);
         }
         SGK_HIP_TRY(hipGetLastError());
-        if (forked) ws = side.stream();
+        wave_launch(forked ? side.stream() : st, a, (a.b.n_reads + 3) / 4);
+        SGK_HIP_TRY(hipGetLastError());
     }
-    wave_launch(ws);
+    StatArgs redo = a;
+    redo.long_redo = 1u;
+    redo.order = nullptr;
+    wave_launch(st, redo, LC_CAP / 4);
     SGK_HIP_TRY(hipGetLastError());
     return SGK_OK;
 }
@@ -2849,10 +2919,9 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
     }
     // the long reads' workgroups run beside the wave kernel (which skips those reads) when a side stream is to be had
     {
-        SideFork side;
-        const int rc = launch_beside_long<LC_STAT>(side, a, JnnP{}, AdaptP{}, "k_long_chains_stat", st, [&](hipStream_t st) {
-            if (a.pa_out) SGK_LAUNCH("k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), (nr + 3) / 4, 256, a);
-            else SGK_LAUNCH("k_stat_wave", (k_stat_wave<REG_WHOLE, false>), (nr + 3) / 4, 256, a);
+        const int rc = launch_beside_long<LC_STAT>(a, JnnP{}, AdaptP{}, "k_long_chains_stat", st, [&](hipStream_t st, const StatArgs &aw, uint32_t grid) {
+            if (aw.pa_out) SGK_LAUNCH(aw.long_redo ? "k_stat_wave_pa_redo" : "k_stat_wave_pa", (k_stat_wave<REG_WHOLE, true>), grid, 256, aw);
+            else SGK_LAUNCH(aw.long_redo ? "k_stat_wave_redo" : "k_stat_wave", (k_stat_wave<REG_WHOLE, false>), grid, 256, aw);
         });
         if (rc != SGK_OK) return rc;
     }
@@ -2871,9 +2940,8 @@ int launch_jnn(const StatArgs &a, const JnnP &p, hipStream_t st) {
         StatArgs aw = a;
         if (!(p.std_scale > 0.0f)) aw.longs = nullptr;  // (fixed thresholds: no sums, k_jnn_wave does every read)
         {
-            SideFork side;
-            const int rc = launch_beside_long<LC_JNN>(side, aw, p, AdaptP{}, "k_long_chains_jnn", st, [&](hipStream_t st) {
-                SGK_LAUNCH("k_jnn_wave", k_jnn_wave, (nr + 3) / 4, 256, aw, p);
+            const int rc = launch_beside_long<LC_JNN>(aw, p, AdaptP{}, "k_long_chains_jnn", st, [&](hipStream_t st, const StatArgs &ax, uint32_t grid) {
+                SGK_LAUNCH(ax.long_redo ? "k_jnn_wave_redo" : "k_jnn_wave", k_jnn_wave, grid, 256, ax, p);
             });
             if (rc != SGK_OK) return rc;
         }
@@ -2890,9 +2958,8 @@ int launch_adaptor(const StatArgs &a, const AdaptP &p, hipStream_t st) {
     if (nr == 0) return SGK_OK;
     if (lane_per_read(2, a)) SGK_LAUNCH("k_adaptor", k_adaptor, (nr + 63) / 64, 64, a, p);
     else {
-        SideFork side;
-        const int rc = launch_beside_long<LC_ADAPT>(side, a, JnnP{}, p, "k_long_chains_adapt", st, [&](hipStream_t st) {
-            SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, p);
+        const int rc = launch_beside_long<LC_ADAPT>(a, JnnP{}, p, "k_long_chains_adapt", st, [&](hipStream_t st, const StatArgs &ax, uint32_t grid) {
+            SGK_LAUNCH(ax.long_redo ? "k_adaptor_wave_redo" : "k_adaptor_wave", k_adaptor_wave, grid, 256, ax, p);
         });
         if (rc != SGK_OK) return rc;
     }
@@ -2926,10 +2993,10 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     const bool lane_regions = lanes || (a.kernels == 0 && nr >= 49152u);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
-        SideFork side;  // (joins at the end of this block: the kernels behind read every read's adapt_x / adapt_y)
+        // (joined inside: the kernels behind read every read's adapt_x / adapt_y)
         const AdaptP ap = adaptor_preset(pore);
-        const int rc = launch_beside_long<LC_ADAPT>(side, a, JnnP{}, ap, "k_long_chains_adapt", st, [&](hipStream_t st) {
-            SGK_LAUNCH("k_adaptor_wave", k_adaptor_wave, (nr + 3) / 4, 256, a, ap);
+        const int rc = launch_beside_long<LC_ADAPT>(a, JnnP{}, ap, "k_long_chains_adapt", st, [&](hipStream_t st, const StatArgs &ax, uint32_t grid) {
+            SGK_LAUNCH(ax.long_redo ? "k_adaptor_wave_redo" : "k_adaptor_wave", k_adaptor_wave, grid, 256, ax, ap);
         });
         if (rc != SGK_OK) return rc;
     }

@@ -370,6 +370,7 @@ typedef struct {
     int n_created, n_max, n_gpus;
     uint64_t batches_read;
     double t_read, t_parse, t_stage, t_wait, t_format, t_write; /* --verbose timing */
+    uint64_t n_long_declined; /* long reads the 16-workgroup path of stat / jnn / prefix declined (redone on one wavefront) */
     uint64_t n_reads, n_samples;
 } pipe_t;
 
@@ -732,6 +733,7 @@ static void *writer_main(void *arg) {
         double t0 = realtime();
         int rc = sgk_job_wait(b->job);
         if (rc != SGK_OK) gpu_fail("sgk_job_wait", rc);
+        P->n_long_declined += sgk_job_long_declined(b->job);
         wctx_t c;
         c.P = P;
         c.b = b;
@@ -891,6 +893,9 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
     pthread_join(wth, NULL);
     pool_destroy(P->load_pool);
     g_t_pipeline_end = realtime();
+    if (P->n_long_declined)
+        WARNING("pipeline", "%lu long read(s) were declined by the long-read path (a barrier wait timed out) and redone on one "
+                "wavefront each; the output is unaffected", (unsigned long)P->n_long_declined);
     if (getenv("SGK_CLI_TIMING"))
         fprintf(stderr,
                 "[sigtk-amd] %lu reads, %lu samples, %d threads, %d GPU(s): read %.3f s, inflate+parse %.3f s, "
@@ -1207,7 +1212,9 @@ static int dumpmain(int argc, char *argv[]) {
         if (ret == 0) ret = b5_parse_raw(f, raw, size, &scratch, &scap, &v);
         if (ret == 0) {
             int16_t *sig = (int16_t *)malloc(sizeof(int16_t) * (v.n_samples ? v.n_samples : 1));
-            if (f->signal_press == 1) ret = b5_svb_zd_decode(v.signal, v.signal_bytes, sig, v.n_samples);
+            if (!sig) ret = -1;
+            else if (f->signal_press == 1) ret = b5_svb_zd_decode(v.signal, v.signal_bytes, sig, v.n_samples);
+            else if (v.signal_bytes != 2 * (uint64_t)v.n_samples) ret = -1;  /* (a malformed record: the copy would overrun) */
             else memcpy(sig, v.signal, v.signal_bytes);
             if (ret == 0)
                 printf("%.*s\t%lu\t%.17g\t%.17g\t%.17g\t%016lx\n", (int)v.id_len, v.read_id, (unsigned long)v.n_samples,

@@ -25,7 +25,7 @@ def plan(L, lens, rna=0, opt=None):
     lens = np.asarray(lens, dtype=np.int64)
     n_samples = int(((lens + 7) // 8 * 8).sum())   # reads laid out on 8-sample boundaries
     p = api.EventPlan()
-    assert L.sgk_event_plan(len(lens), n_samples, int(lens.max()), rna, C.byref(opt if opt is not None else opts()),
+    assert L.sgk_event_plan_opt(len(lens), n_samples, int(lens.max()), rna, C.byref(opt if opt is not None else opts()),
                             C.byref(p)) == 0
     return p, n_samples
 
@@ -40,7 +40,7 @@ def test_defaults_and_no_long_reads(lib):
     # a null options pointer is the defaults
     from sigtk_amd import api
     q = api.EventPlan()
-    assert lib.sgk_event_plan(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0 and q.segment_len == 131072
+    assert lib.sgk_event_plan_opt(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0 and q.segment_len == 131072
 
 
 def test_segment_capacities_cover_any_batch_with_these_totals(lib):
@@ -111,3 +111,16 @@ def test_tail_split(lib):
     a = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts(tail_split=-1)))
     b = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts()))
     assert b >= a + 784 * 4 * 320
+
+
+def test_the_0_1_0_plan_call_keeps_its_signature(lib):
+    """0.2.0 / 0.2.1 had put the six-argument plan under the 0.1.0 symbol; it is sgk_event_plan_opt now and
+    sgk_event_plan is the five-argument call again: the defaults, and only the 32 bytes sgk_event_plan_t had then"""
+    from sigtk_amd import api
+    buf = (C.c_uint32 * 12)(*([0xdeadbeef] * 12))
+    assert lib.sgk_event_plan(10, 10 * 5000, 5000, 0, C.cast(buf, C.c_void_p)) == 0
+    q = api.EventPlan()
+    assert lib.sgk_event_plan_opt(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0
+    assert (buf[0], buf[1], buf[4], buf[5]) == (q.segment_len, q.long_min, q.short_max, q.lanes_per_short_read)
+    assert all(buf[k] == 0xdeadbeef for k in range(8, 12))   # nothing behind the 32 bytes is touched
+    assert lib.sgk_event_plan(10, 50000, 5000, 0, None) != 0
