@@ -228,7 +228,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                               [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     ver = L.sgk_version().decode()
-    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 2):
+    old_ok = os.environ.get("SIGTK_AMD_LIB_ANY") == "1"   # development: an A/B build of an earlier round under the event calls
+    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 2) and not old_ok:
         raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2, the long-read status of "
                             "0.2.1 and sgk_event_plan_opt / sgk_job_long_declined of 0.2.2" % (path, ver))
     OE, OS = C.POINTER(EventOptions), C.POINTER(StatOptions)
@@ -236,12 +237,13 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_event_workspace_bytes_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, OE]
     L.sgk_event_opt.argtypes = L.sgk_event.argtypes + [OE]
     L.sgk_event_pa_opt.argtypes = L.sgk_event_pa.argtypes + [OE]
-    L.sgk_event_plan_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, OE, C.POINTER(EventPlan)]
-    L.sgk_event_plan_opt.restype = C.c_int
-    L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]  # (0.1.0 form, deprecated)
-    L.sgk_event_plan.restype = C.c_int
-    L.sgk_job_long_declined.argtypes = [C.c_void_p]
-    L.sgk_job_long_declined.restype = C.c_uint32
+    if not (old_ok and not hasattr(L, "sgk_event_plan_opt")):
+        L.sgk_event_plan_opt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, OE, C.POINTER(EventPlan)]
+        L.sgk_event_plan_opt.restype = C.c_int
+        L.sgk_event_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]  # (0.1.0 form, deprecated)
+        L.sgk_event_plan.restype = C.c_int
+        L.sgk_job_long_declined.argtypes = [C.c_void_p]
+        L.sgk_job_long_declined.restype = C.c_uint32
     L.sgk_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.sgk_stat.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sgk_stat_pa.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

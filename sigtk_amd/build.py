@@ -75,6 +75,32 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(tag: str, defines, sources=("event_kernels.hip", "api.hip"), verbose: bool = False) -> str:
+    """A development variant of the library: `sources` recompiled with the given -D flags, everything else taken from
+    the shipped build's objects -> sigtk_amd/_variants/libsigtk_gpu_<tag>.so (select it with SIGTK_AMD_LIB=<path>).
+    -DSGK_DEV=1 is the instrumented build of event_args.h (phases switched off per call, per-wave timestamps)."""
+    build_lib(verbose=verbose)
+    vdir = os.path.join(PKG, "_variants")
+    os.makedirs(vdir, exist_ok=True)
+    cc = hipcc()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines)
+    objs = []
+    for s_ in HIP_SOURCES:
+        base = s_[:-4]
+        if s_ in sources:
+            obj = os.path.join(vdir, "%s_%s.o" % (base, tag))
+            cmd = [cc, *flags, "-c", "-o", obj, os.path.join(CSRC, s_)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        else:
+            obj = os.path.join(PKG, "build", base + ".o")
+        objs.append(obj)
+    out = os.path.join(vdir, "libsigtk_gpu_%s.so" % tag)
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
+
+
 def build_cli(force: bool = False, verbose: bool = False) -> str:
     if not os.path.isdir(HOST):
         return ""
@@ -130,6 +156,10 @@ def build_tools(force: bool = False, verbose: bool = False) -> None:
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:   # python -m sigtk_amd.build --variant <tag> -DNAME=VALUE ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [x for x in sys.argv[i + 2:] if x.startswith("-D")], verbose=True))
+        sys.exit(0)
     build_tools(force="--force" in sys.argv, verbose=True)
     build_lib(force="--force" in sys.argv, verbose=True)
     build_cli(force="--force" in sys.argv, verbose=True)

@@ -58,6 +58,7 @@ ProfScope::~ProfScope() {
 // (no process-wide state: every entry point derives its configuration from the caller's options)
 EvSegConfig event_config(const sgk_event_options_t *o) {
     EvSegConfig c;
+    c.dev = 0;
     c.seg_len = 131072;    // one wavefront's share of a long read: ~0.6 ms of detector + builder
     c.long_min = 262144;   // reads at least this long are cut into segments
     c.lead_override = 0;
@@ -65,6 +66,9 @@ EvSegConfig event_config(const sgk_event_options_t *o) {
     c.multi_max = 0;
     c.tail_split = 0;
     if (!o) return c;
+#ifdef SGK_DEV
+    c.dev = o->reserved[0];
+#endif
     if (o->segment_len >= 1024 && o->segment_len <= (1u << 30)) c.seg_len = o->segment_len / 1024 * 1024;
     if (o->long_min >= 1) c.long_min = o->long_min;
     if (c.long_min <= c.seg_len) c.long_min = c.seg_len + 1;  // a long read has at least two segments
@@ -100,12 +104,17 @@ static uint32_t event_wave_slots(int rna) {
     return (uint32_t)cus[dev] * 4u * (rna ? 2u : 3u);
 }
 
-// The tail split (event_kernels.hip: seg_len_of).  A batch of fewer than 8 rounds of waves whose last round is neither
-// empty nor nearly full: the reads of that round (the last dispatch positions) are cut into segments, as many per read
-// as fill a round (2 .. 8), never shorter than 16 384 samples.  Not in a batch with packed short reads (they balance
-// by themselves), not for reads under 32 768 samples on average.
-// Measured (profiles/r04_*): 10 000 x 100 000 DNA 3.78 -> 3.67 ms, 9 300 reads 3.77 -> 3.52, 1 000 reads 0.78 -> 0.68;
-// the number of segments per read hardly matters (2 .. 16: 3.62 - 3.71 ms).
+// The tail split (event_kernels.hip: seg_len_of).  A batch of fewer than 8 rounds of waves whose last round is a SMALL
+// fraction of one: the reads of that round (the last dispatch positions) are cut into segments, as many per read as fill
+// a round (up to 8), never shorter than 16 384 samples.  Not in a batch with packed short reads (they balance by
+// themselves), not for reads under 32 768 samples on average.
+// A cut read costs ~1.5 x a whole one (every lane of every segment warms up, the chain waits for the segment in front,
+// the builder starts from the last boundary in front of it), so cutting pays only where FEW reads would otherwise keep
+// the whole GPU waiting: measured on the round-5 kernel (profiles/r05_tail_split_sweep.txt, 100 000-sample reads, off /
+// on): 500 reads 0.69 / 0.42 ms, 1 000 0.69 / 0.62, 9 300 (84 reads over 3 rounds) 3.56 / 3.35; but 2 000 0.89 / 1.14,
+// 4 000 1.58 / 1.76, 5 000 1.82 / 2.22, 10 000 (784 over) 3.52 / 3.69, 20 000 6.75 / 7.02 -- round 4's rule (any last
+// round under 7 / 8 full) was tuned on a kernel whose whole reads were 6 % slower.  Now: the last round at most a sixth
+// of a round (six or more segments per read), or a batch of at most a third of a round.
 void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
                      bool packed, uint32_t &split_from, uint32_t &split_seg) {
     split_from = n_reads;
@@ -116,7 +125,7 @@ void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples
     if (mean < 32768 || (sc.tail_split == 0 && n_reads >= 8ull * slots)) return;
     uint32_t rem = n_reads % slots;
     if (sc.tail_split > 0) rem = (uint32_t)sc.tail_split < n_reads ? (uint32_t)sc.tail_split : n_reads;   // the caller's number
-    else if (rem == 0 || rem > slots - slots / 8) return;
+    else if (rem == 0 || rem * (n_reads < slots ? 3u : 6u) > slots) return;
     // (the number of segments per read hardly matters: 2 .. 16 per read, one or two rounds of them: 3.77 - 3.89 ms)
     uint32_t G = (slots - slots / 16 + rem - 1) / rem;   // units of the split reads ~ one round
     if (G < 2) G = 2;
@@ -281,6 +290,7 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     a.seg_len = sc.seg_len;
     a.long_min = sc.long_min;
     a.lead_override = sc.lead_override;
+    a.dev = sc.dev;
     a.segs = reinterpret_cast<SegDesc *>(base + w.off_segs);
     a.seg_state = reinterpret_cast<SegState *>(base + w.off_seg_state);
     a.longs = reinterpret_cast<LongRead *>(base + w.off_longs);
@@ -288,8 +298,6 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     event_multi_plan(sc, n_reads, n_samples, max_read_len, rna, sorted, a.multi_lanes, a.multi_max);
     event_tail_plan(sc, n_reads, n_samples, max_read_len, rna, a.multi_lanes != 0, a.split_from, a.split_seg);
     a.has_long = max_read_len >= sc.long_min ? 1u : 0u;
-    a.seg_blocks = 0;
-    a.seg_last = 0;
     return launch_event(a, rna, float_input, w.n_fb_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -394,6 +402,13 @@ size_t sgk_event_workspace_bytes_opt(uint32_t n_reads, uint64_t n_samples, uint3
 size_t sgk_event_workspace_bytes(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
     return sgk_event_workspace_bytes_opt(n_reads, n_samples, max_read_len, nullptr);
 }
+#ifdef SGK_DEV
+// development builds only: where in the workspace the fallback scratch -- SGK_DEV_TRACE's records -- begins
+size_t sgk_debug_scratch_offset(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, const sgk_event_options_t *opt,
+                                size_t ws_bytes) {
+    return event_workspace_layout(event_config(opt), n_reads, n_samples, max_read_len, ws_bytes).off_scratch;
+}
+#endif
 
 int sgk_event_opt(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
                   void *ws, size_t ws_bytes, void *stream, const sgk_event_options_t *opt) {

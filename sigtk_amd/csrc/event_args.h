@@ -107,11 +107,21 @@ struct EvArgs {
     // tail split (k_seg_plan): reads at dispatch positions >= split_from are cut into split_seg-sample segments
     uint32_t split_from, split_seg;  // (split_from >= n_reads: none)
     uint32_t has_long;               // the batch may hold reads of long_min samples or more
-    uint32_t seg_blocks;             // k_event: its first seg_blocks workgroups take segments (set per launch)
-    uint32_t seg_last;               // ... its last ones instead
+    uint32_t dev;                    // development builds only (-DSGK_DEV, tools/build_variant.sh): SGK_DEV_* below; else 0
 };
+// What a development build (never the shipped library) can switch off or record per call, from
+// sgk_event_options_t::reserved[0]: the ablation behind profiles/r05_event_instruction_table.md and the per-wave
+// timestamps behind profiles/r05_event_first_round.md.
+constexpr uint32_t SGK_DEV_NO_BUILD = 1;     // k_event: detector + bitmap only
+constexpr uint32_t SGK_DEV_NO_DETECT = 2;    // ... builder only (the bitmap of the previous call on this workspace)
+constexpr uint32_t SGK_DEV_NO_ROUNDS = 4;    // builder: the sample walk only, no event rounds
+constexpr uint32_t SGK_DEV_RAW_EVENTS = 8;   // builder: event rounds without create_event's arithmetic (sums stored as they are)
+constexpr uint32_t SGK_DEV_TRACE = 16;       // k_event: s_memrealtime at wave start / detector end / builder end + HW_ID, XCC_ID
+                                             // per workgroup, 32 bytes each, into the fallback scratch (unused when no read is flagged)
+
 
 struct EvSegConfig {
+    uint32_t dev;        // SGK_DEV builds: sgk_event_options_t::reserved[0]
     uint32_t seg_len, long_min;
     int lead_override;
     int multi;  // lanes per short read: 0 = chosen per batch, -1 = off (64 lanes per read), 1 .. 32 = forced

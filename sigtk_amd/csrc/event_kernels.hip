@@ -208,6 +208,7 @@ struct ReadCtx {
     bool vec_ok;
     unsigned long long *bm;   // bitmap words of this read
     const double *P, *P2;     // fallback prefix arrays (n+1 entries) or null
+    uint32_t dev;             // EvArgs::dev (development builds; 0 otherwise)
 };
 
 template <typename T>
@@ -224,6 +225,7 @@ __device__ inline ReadCtx<T> make_ctx(const EvArgs &a, uint32_t r) {
     rc.bm = a.bitmap + (o0 >> 6) + r;
     rc.P = nullptr;
     rc.P2 = nullptr;
+    rc.dev = a.dev;
     return rc;
 }
 
@@ -855,6 +857,26 @@ __device__ __forceinline__ void lz_flush(uint32_t *ring, unsigned long long *bm,
     }
 }
 
+// Issue priority by REMAINING work (round 5).  A SIMD arbitrates oldest-first among waves of equal priority: of the three
+// waves that start together on a SIMD the oldest finishes its detector pass in 0.50 ms, the second in 0.71, the youngest
+// in 0.97 (per-wave timestamps, profiles/r05_event_first_round.md) -- and then runs on alone, on a SIMD one wave cannot
+// saturate (an instruction per 4.5 - 6 cycles instead of 2.3 - 4.45).  That, not the instruction cache (0.003 % misses)
+// or address translation (949 misses per launch), is the "slow first round" of rounds 3 and 4, and the same thing happens
+// when a launch drains.  A wave therefore lowers its own priority as it gets on with its read -- 3 while more than 1 200
+// steps of its pass are left, 2, 1, 0 for the last 400 and in the builder -- so that whichever wave of a SIMD has most
+// left to do issues first and the waves of a SIMD end together.
+#ifndef SGK_PRIO_POLICY
+#define SGK_PRIO_POLICY 1   // 0: none; 1: by the steps left of the detector pass 3 / 2 / 1 / 0, builder 0; 2: ... builder 3; 3: builder 3 only
+#endif
+__device__ __forceinline__ uint32_t prio_policy(uint32_t dev) {
+#ifdef SGK_DEV
+    return ((dev >> 8) & 7u) ? ((dev >> 8) & 7u) - 1u : (uint32_t)SGK_PRIO_POLICY;   // dev bits 8..10: policy + 1
+#else
+    (void)dev;
+    return (uint32_t)SGK_PRIO_POLICY;
+#endif
+}
+
 // One pass of the lazy detector over the wave's chunks.
 //   given  : (per lane) this lane starts from snap.st0 -- the true state at its first index: a re-run of a lane whose
 //            speculation failed, or the first lane of a segment that is run from a known state; the other lanes
@@ -865,7 +887,7 @@ __device__ __forceinline__ void lz_flush(uint32_t *ring, unsigned long long *bm,
 // Writes the lane's bitmap words, its hot-run records and (speculative pass) snap.init / snap.at_e.
 template <int W1, typename T, bool FLAGGED>
 __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int lead, int steps, bool active, int s,
-                                          int e, LzLds *L, const RepairCtx *rep) {
+                                          int e, LzLds *L, const RepairCtx *rep, bool by_progress = false) {
     using LP = LazyPass<W1, T, FLAGGED>;
     constexpr int W2 = LP::W2, R = LP::R;
     if (!__any(active)) return;
@@ -973,6 +995,17 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         return st;
     };
 
+    // (by_progress: the wave's first pass over its span, under a policy that ranks by what is left to do -- in steps, not
+    // as a fraction of the span: a segment of a cut read starts where a whole read is when it has as much left)
+    constexpr int PRIO_STEPS = 400;   // a quarter of the pass over a 100 000-sample read
+    const int q1 = by_progress ? main_steps - 3 * PRIO_STEPS : -1, q2 = by_progress ? main_steps - 2 * PRIO_STEPS : -1,
+              q3 = by_progress ? main_steps - PRIO_STEPS : -1;
+    if (by_progress) {
+        if (q1 > 0) __builtin_amdgcn_s_setprio(3);
+        else if (q2 > 0) __builtin_amdgcn_s_setprio(2);
+        else if (q3 > 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
     int jb = 0;
     for (;;) {
         const int ib = i_begin + jb;
@@ -1003,6 +1036,9 @@ __device__ __forceinline__ void pass_lazy(const ReadCtx<T> &rc, bool given, int 
         f.r0 -= R;
         if constexpr (FLAGGED) f.dirty = f.dirty < -(1 << 20) ? f.dirty : f.dirty - R;
         jb += R;
+        if (jb == q1) __builtin_amdgcn_s_setprio(2);
+        else if (jb == q2) __builtin_amdgcn_s_setprio(1);
+        else if (jb == q3) __builtin_amdgcn_s_setprio(0);
         {
             // state snapshots live in LDS (they are only needed after the pass)
             const int nb = i_begin + jb;  // first index of the next block
@@ -1181,9 +1217,10 @@ __device__ __forceinline__ int detect_span(const ReadCtx<T> &rc, EvHeader *hdr, 
     bool run = active;
     bool first = true;
     const int l = lane_id();
+    const uint32_t pol = FLAGGED ? 0u : prio_policy(rc.dev);
     for (int iter = 0; iter < 66; ++iter) {
         pass_lazy<W1, T, FLAGGED>(rc, first ? (mode == 2 && c == 0) : true, first ? lead_c : 0, first ? TT : Kmax, run, s, e,
-                                  L, rep);
+                                  L, rep, first && (pol == 1u || pol == 2u));
         __syncthreads();
         // chunk c is right iff it started (at s) from the state chunk c-1 ended with
         const LzSnapState pe = L->snap.at_e[c > 0 ? l - 1 : l];
@@ -1330,10 +1367,21 @@ constexpr int BT = 32;      // samples per lane per builder tile: 64 bytes of in
 struct EvOut {
     uint4 *ev;   // the read's first slot
     uint32_t cap;
+#ifdef SGK_DEV
+    bool raw;    // SGK_DEV_RAW_EVENTS
+#endif
 };
 __device__ __forceinline__ void store_event_fast(const EvOut &o, uint32_t k, uint32_t ps, uint32_t pe, double dsum,
                                                  double dsumsq, bool &overflow) {
     if (k >= o.cap) { overflow = true; return; }
+#ifdef SGK_DEV
+    if (o.raw) {
+        uint4 e;
+        e.x = ps; e.y = pe - ps; e.z = __float_as_uint((float)dsum); e.w = __float_as_uint((float)dsumsq);
+        o.ev[k] = e;
+        return;
+    }
+#endif
     const float len = (float)(pe - ps);
     const float r1 = sgk_refined_rcp(len);
     const float m = sgk_div_with_rcp((float)dsum, len, r1);
@@ -1382,15 +1430,36 @@ typedef short sgk_s2 __attribute__((ext_vector_type(2)));
 
 // One lane's walk over its 32 samples of a tile: lane-relative double prefix sums, one record per boundary bit.
 // FULL: every sample of the tile is inside the read (no per-sample validity select).
+// A lane's 32 samples of a tile AS THEY SIT IN MEMORY (16 dwords of packed int16, or 32 floats).  Kept packed on purpose:
+// as an array of 32 int16 elements the compiler gives every sample a register of its own and unpacks the high halves
+// right behind the load -- an s_waitcnt vmcnt directly after the "prefetch" of the next tile, i.e. no prefetch at all
+// (round 5: the whole memory latency was exposed once per tile).  The walk converts straight from the packed words
+// (v_cvt_f32_i32_sdwa).
+template <typename T>
+struct TileRegs {
+    static constexpr int NW = BT * (int)sizeof(T) / 4;
+    uint32_t w[NW];
+    __device__ __forceinline__ float pa(int k, const Scale &sc) const {   // k: a constant after unrolling
+        if constexpr (std::is_same<T, int16_t>::value) {
+            const int v = (k & 1) ? ((int)w[k / 2] >> 16) : (int)(short)(w[k / 2] & 0xffffu);
+            return ((float)v + sc.offf) * sc.unit;
+        } else {
+            return __uint_as_float(w[k]);
+        }
+    }
+};
 template <typename T, bool FULL>
-__device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, int nvalid, const Scale &sc, int l,
+__device__ __forceinline__ void build_walk(const TileRegs<T> &buf, uint32_t bits, int nvalid, const Scale &sc, int l,
                                            int excl, BuildLds *L, double &S, double &S2, uint32_t &mnb,
                                            uint32_t &mxb) {
-    char *rr = reinterpret_cast<char *>(L->rec) + excl * 16;
-    char *rp = reinterpret_cast<char *>(L->p) + excl * 2;
+    // (LDS addresses as 32-bit offsets: what ds_write takes)
+    typedef __attribute__((address_space(3))) char *LdsBytes;
+    typedef __attribute__((address_space(3))) uint16_t *LdsU16;
+    uint32_t rr32 = (uint32_t)(uintptr_t)(LdsBytes)(char *)L->rec + (uint32_t)excl * 16u;
+    uint32_t rp32 = (uint32_t)(uintptr_t)(LdsBytes)(char *)L->p + (uint32_t)excl * 2u;
 #pragma unroll
     for (int k = 0; k < BT; ++k) {
-        float x = to_pa(buf[k], sc);
+        float x = buf.pa(k, sc);
         if (!FULL && k >= nvalid) x = 0.0f;
         const float xq = x * x;
         if constexpr (std::is_same<T, float>::value) {
@@ -1402,13 +1471,12 @@ __device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, in
             mnb = (ab - 1u) < mnb ? (ab - 1u) : mnb;
         }
         if ((bits >> k) & 1u) {
-            BuildRec rc;
-            rc.S = S;
-            rc.S2 = S2;
-            *reinterpret_cast<BuildRec *>(rr) = rc;
-            *reinterpret_cast<uint16_t *>(rp) = (uint16_t)(l * BT + k);
-            rr += 16;
-            rp += 2;
+            typedef double __attribute__((ext_vector_type(2))) sgk_d2;
+            *(__attribute__((address_space(3))) sgk_d2 *)(uintptr_t)rr32 = sgk_d2{S, S2};   // BuildRec {S, S2}
+            *(LdsU16)(uintptr_t)rp32 = (uint16_t)(l * BT + k);
+            // (in place, under the lane mask: written as `rr += 16` the two pointers come out as an add into a new
+            // register plus a move each -- four vector instructions per sample instead of two)
+            asm volatile("v_add_u32 %0, 16, %0\n\tv_add_u32 %1, 2, %1" : "+v"(rr32), "+v"(rp32));
         }
         S = S + (double)x;
         S2 = S2 + (double)xq;
@@ -1422,7 +1490,7 @@ __device__ __forceinline__ void build_walk(const T (&buf)[BT], uint32_t bits, in
 // of the segment the bitmap words are another wave's: the only boundaries the walk knows there are the one it starts
 // at (prev_p) and the ones this segment owns (pre: peaks that were pending at the seam).
 template <typename T, bool SEG = false>
-__device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined,
+__device__ __forceinline__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, BuildLds *L, bool declined,
                            int64_t seg_a = 0, int64_t seg_b = 0, SegState *st = nullptr, uint32_t cnt_before = 0,
                            int prev_p = -1, const int *pre = nullptr, int n_pre = 0) {
     const int64_t n = rc.n;
@@ -1433,9 +1501,17 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         return;
     }
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(rc.bm);
+    {
+        const uint32_t pol = prio_policy(a.dev);
+        if (pol == 2u || pol == 3u) __builtin_amdgcn_s_setprio(3);
+        else if (pol == 1u) __builtin_amdgcn_s_setprio(0);
+    }
     EvOut eo;
     eo.ev = reinterpret_cast<uint4 *>(a.events + slot0);
     eo.cap = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
+#ifdef SGK_DEV
+    eo.raw = (a.dev & SGK_DEV_RAW_EVENTS) != 0u;
+#endif
     bool overflow = false, dense = false;
     uint32_t rank = 0, prevp = 0;
     // SEG: bits in [bit_lo, bit_hi) count; the first of them (the boundary in front of the segment) ends no event of
@@ -1459,12 +1535,16 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
     constexpr int NV = BT * (int)sizeof(T) / 16;
     // tile loader: this lane's 32 samples and its 32 bitmap bits.  The next tile is fetched while the
     // current one is processed (register double buffer).
-    auto load_tile = [&](int64_t tb, T (&buf)[BT], uint32_t &bits, int &nvalid) {
+    // (bits of the tile = (raw & keep) | extra: the masks are formed WITHOUT touching the loaded word, so that nothing waits
+    // for the load where it is issued -- one `bits &= mask` here put an s_waitcnt vmcnt(0) right behind the prefetch)
+    auto load_tile = [&](int64_t tb, TileRegs<T> &buf, uint32_t &raw, uint32_t &keep, uint32_t &extra, int &nvalid) {
         const int64_t pos0 = tb + (int64_t)l * BT;
-        bits = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
+        raw = (pos0 < n) ? bm32[pos0 >> 5] : 0u;
+        keep = 0xffffffffu;
+        extra = 0u;
         const int64_t rem = n - pos0;
         nvalid = rem <= 0 ? 0 : (rem >= BT ? BT : (int)rem);
-        if (nvalid < BT) bits &= (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
+        if (nvalid < BT) keep = (nvalid == 0) ? 0u : ((1u << nvalid) - 1u);
         if constexpr (SEG) {
             if (pos0 < seg_a) {
                 uint32_t sb = 0u;
@@ -1473,38 +1553,51 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
                     const int64_t q = pre[k];
                     if (q >= pos0 && q < pos0 + BT) sb |= 1u << (int)(q - pos0);
                 }
-                bits = sb;
+                extra = sb & keep;
+                keep = 0u;
             }
             const int64_t dl = bit_lo - pos0, dh = bit_hi - pos0;
-            if (dl > 0) bits = dl >= BT ? 0u : (bits & ~((1u << (int)dl) - 1u));
-            if (dh < BT) bits = dh <= 0 ? 0u : (bits & ((1u << (int)dh) - 1u));
+            uint32_t m = 0xffffffffu;
+            if (dl > 0) m = dl >= BT ? 0u : ~((1u << (int)dl) - 1u);
+            if (dh < BT) m = dh <= 0 ? 0u : (m & ((1u << (int)dh) - 1u));
+            keep &= m;
+            extra &= m;
         }
         if (pos0 >= n) {
             // lanes behind the read's end (every read's last tile has some): nothing to load
 #pragma unroll
-            for (int k = 0; k < BT; ++k) buf[k] = (T)0;
+            for (int k = 0; k < TileRegs<T>::NW; ++k) buf.w[k] = 0u;
         } else if (rc.vec_ok && pos0 + BT <= rc.hi) {
             const uint4 *src = reinterpret_cast<const uint4 *>(rc.base + pos0);
             uint4 v[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) v[k] = src[k];
-            __builtin_memcpy(buf, v, sizeof(buf));
+            __builtin_memcpy(buf.w, v, sizeof(buf.w));
         } else {
+            // (a read on an odd address / at the end of the buffer: element by element, packed by hand -- both branches
+            // must define the same dwords, or the compiler unpacks the vector loads to match this one)
+            if constexpr (std::is_same<T, int16_t>::value) {
 #pragma unroll
-            for (int k = 0; k < BT; ++k) buf[k] = (k < nvalid) ? rc.base[pos0 + k] : (T)0;
+                for (int k = 0; k < BT; k += 2) {
+                    const uint32_t lo = (k < nvalid) ? (uint32_t)(uint16_t)rc.base[pos0 + k] : 0u;
+                    const uint32_t hi = (k + 1 < nvalid) ? (uint32_t)(uint16_t)rc.base[pos0 + k + 1] : 0u;
+                    buf.w[k / 2] = lo | (hi << 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < BT; ++k) buf.w[k] = (k < nvalid) ? __float_as_uint(rc.base[pos0 + k]) : 0u;
+            }
         }
     };
-    T nbuf[BT];
-    uint32_t nbits;
+    TileRegs<T> nbuf;
+    uint32_t nraw, nkeep, nextra;
     int nnvalid;
-    load_tile(walk0, nbuf, nbits, nnvalid);
+    load_tile(walk0, nbuf, nraw, nkeep, nextra, nnvalid);
     for (int64_t tb = walk0; tb < bit_hi; tb += 64 * BT) {
-        T buf[BT];
-#pragma unroll
-        for (int k = 0; k < BT; ++k) buf[k] = nbuf[k];
-        const uint32_t bits = nbits;
+        const TileRegs<T> buf = nbuf;
+        const uint32_t bits = (nraw & nkeep) | nextra;
         const int nvalid = nnvalid;
-        if (tb + 64 * BT < bit_hi) load_tile(tb + 64 * BT, nbuf, nbits, nnvalid);
+        if (tb + 64 * BT < bit_hi) load_tile(tb + 64 * BT, nbuf, nraw, nkeep, nextra, nnvalid);
         const int cnt = __popc(bits);
         const int incl = wave_incl_scan_i(cnt);
         const int excl = incl - cnt;
@@ -1513,7 +1606,7 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         if constexpr (std::is_same<T, int16_t>::value) {
             // raw extremes (samples behind the read's end repeat a valid one)
             sgk_s2 w[BT / 2];
-            __builtin_memcpy(w, buf, sizeof(w));
+            __builtin_memcpy(w, buf.w, sizeof(w));
             if (!full) {
                 const sgk_s2 first = {(short)rc.base[0], (short)rc.base[0]};
 #pragma unroll
@@ -1539,19 +1632,48 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
         L->pt2[l] = inS2 - S2;
         const double tileS = wave_last_d(inS), tileS2 = wave_last_d(inS2);
         __syncthreads();
+        // The next tile's samples and bitmap word were requested before the walk and have long arrived: say so HERE,
+        // in front of the rounds' event stores.  Left to the compiler the wait sits at their first use -- behind those
+        // stores, and vmcnt counts loads and stores in one queue on gfx9: every tile would wait for its events to be
+        // acknowledged by memory.  (vmcnt(0), expcnt / lgkmcnt untouched)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef SGK_DEV
+        const int tot = (total > BREC || (a.dev & SGK_DEV_NO_ROUNDS)) ? 0 : total;
+#else
         const int tot = total > BREC ? 0 : total;
+#endif
         // one event per lane per round.  Prefix sums are kept relative to the tile start (exact under the guard, so
         // no absolute base is needed); the previous boundary of lane l is lane l-1's record, lane 0 takes the
         // carry: the last record of the previous round / tile.
+        // The LDS look-ups of a round are two dependent trips (position -> lane -> that lane's prefix); they run two
+        // rounds ahead of the arithmetic (round 5: the rounds were 0.41 ms for 7.3 vector instructions per sample --
+        // waits, profiles/r05_event_instruction_table.md): records of round i + 2 and lane prefixes of round i + 1 are
+        // in flight while round i is evaluated.
+        auto rec_at = [&](int k0, uint32_t &pr, double &S_, double &S2_) {
+            const int k = k0 + l;
+            const int kk = k < tot ? k : tot - 1;
+            pr = L->p[kk];
+            const BuildRec rcd = L->rec[kk];
+            S_ = rcd.S;
+            S2_ = rcd.S2;
+        };
+        uint32_t pr0 = 0u, pr1 = 0u, pr2 = 0u;
+        double S0 = 0.0, S20 = 0.0, S1 = 0.0, S21 = 0.0, Sn = 0.0, S2n = 0.0, pt0 = 0.0, pt20 = 0.0, pt1 = 0.0, pt21 = 0.0;
+        if (tot > 0) {
+            rec_at(0, pr0, S0, S20);
+            rec_at(64, pr1, S1, S21);
+            pt0 = L->pt[pr0 / BT];
+            pt20 = L->pt2[pr0 / BT];
+        }
         for (int k0 = 0; k0 < tot; k0 += 64) {
+            pt1 = L->pt[pr1 / BT];            // round k0 + 64
+            pt21 = L->pt2[pr1 / BT];
+            rec_at(k0 + 128, pr2, Sn, S2n);   // round k0 + 128
             const int k = k0 + l;
             const bool act = k < tot;
-            const int kk = act ? k : tot - 1;
-            const uint32_t pr = L->p[kk], p = (uint32_t)tb + pr;
-            const int ln = (int)(pr / BT);
-            const BuildRec rcd = L->rec[kk];
-            const double G = L->pt[ln] + rcd.S;
-            const double G2 = L->pt2[ln] + rcd.S2;
+            const uint32_t p = (uint32_t)tb + pr0;
+            const double G = pt0 + S0;
+            const double G2 = pt20 + S20;
             const uint32_t pp = (uint32_t)wave_shr1_i((int)p, (int)prevp);
             const double Gp = wave_shr1_d(G, Gprev), G2p = wave_shr1_d(G2, G2prev);
             if (act && (!SEG || rank + (uint32_t)k != skip_rank))
@@ -1560,6 +1682,8 @@ __device__ void build_read(const EvArgs &a, const ReadCtx<T> &rc, uint32_t r, Bu
             prevp = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
             Gprev = readlane_d(G, last);
             G2prev = readlane_d(G2, last);
+            pr0 = pr1; S0 = S1; S20 = S21; pt0 = pt1; pt20 = pt21;
+            pr1 = pr2; S1 = Sn; S21 = S2n;
         }
         rank += (uint32_t)tot;
         // rebase the carry to the next tile's start
@@ -1829,50 +1953,46 @@ __global__ __launch_bounds__(256) void k_seg_plan(EvArgs a) {
 template <int W1, typename T>
 __global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event(EvArgs a) {
     __shared__ EventLds L;
-    // The first (or last) seg_blocks workgroups take the segments of the reads that several waves share (chain_segment;
-    // the segment list is usually much shorter than its capacity), the others one read each,
-    // longest first (launch_order): a kernel cannot end before its longest read has, so that one should start first,
-    // not wherever it sits in the batch.
-    // (seg_last: the segments are the tail split's and take the LAST workgroups -- small units into the slots the last
-    // whole reads leave empty; long reads' segments take the first: a kernel cannot end before its longest read has)
-    const uint32_t bx = a.seg_last ? (blockIdx.x >= a.n_reads ? blockIdx.x - a.n_reads : blockIdx.x + a.seg_blocks) : blockIdx.x;
-    const bool is_seg = bx < a.seg_blocks;
-    uint32_t r, g = 0, seg_len = 0, lread = 0;
-    if (is_seg) {
-        if (bx >= a.hdr->n_segs) return;
-        const SegDesc d = a.segs[bx];
-        if (d.read == SEG_NONE) return;
-        r = d.read;
-        g = d.g;
-        lread = d.lread;
-        seg_len = a.longs[d.lread].seg_len;
-    } else {
-        const uint32_t bi = bx - a.seg_blocks;
-        r = a.order ? a.order[bi] : bi;
-    }
+    // One read per workgroup, longest first (launch_order): a kernel cannot end before its longest read has, so that one
+    // should start first, not wherever it sits in the batch.  Reads that several waves share -- long reads, the tail
+    // split -- are k_event_seg's (round 5: a kernel of its own.  While one kernel held both paths the whole-read path --
+    // 9 216 of config 2's 10 000 workgroups -- carried the chain's state: 33 spilled registers, 688 bytes of scratch per
+    // lane; as a device function called from here the chain spilled in its own detector pass instead.)
+    const uint32_t bi = blockIdx.x;
+    const uint32_t r = a.order ? a.order[bi] : bi;
     const ReadCtx<T> rc = make_ctx<T>(a, r);
-    int sa = 0, sb = (int)rc.n;
-    SegState *st = nullptr;
-    if (is_seg) {
-        seg_span(seg_len, g, rc.n, sa, sb);
-        st = a.seg_state + bx;
-    } else {
-        if (seg_len_of(a, bx - a.seg_blocks, (uint32_t)rc.n) != 0u) return;  // taken by its segments
-        if (a.multi_lanes && rc.n < (int64_t)a.multi_max) return;  // taken by k_event_multi
-    }
-    const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, sa, sb, g == 0 ? 0 : 1, a.lead_override, st);
-    if (is_seg) {
-        if (lane_id() == 0) st->status = rcode;
-        chain_segment<W1, T>(a, rc, r, g, lread, seg_len, st, rcode, sa, sb, &L);
-        return;
-    }
+    if (seg_len_of(a, bi, (uint32_t)rc.n) != 0u) return;  // taken by its segments (k_event_seg)
+    if (a.multi_lanes && rc.n < (int64_t)a.multi_max) return;  // taken by k_event_multi
+#ifdef SGK_DEV  // development builds (tools/build_variant.sh): phases switched off / timestamps, see event_args.h
+    unsigned long long t0 = 0ull, t1 = 0ull;
+    if (a.dev & SGK_DEV_TRACE) t0 = wall_clock64();
+    int rcode = 0;
+    if (!(a.dev & SGK_DEV_NO_DETECT)) rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr);
+    if (a.dev & SGK_DEV_TRACE) t1 = wall_clock64();
+#else
+    const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L.lz, nullptr, 0, (int)rc.n, 0, a.lead_override, nullptr);
+#endif
     // the bitmap words of every lane (and the replay's atomics) are complete before any lane of this workgroup reads
     // them back.  Workgroup scope: the wave's own CU only -- an agent-scope release / acquire pair here writes back and
     // invalidates L2 once per read, which made 5 000-sample reads 1.7x slower than with two kernels.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef SGK_DEV
+    if (!(a.dev & SGK_DEV_NO_BUILD)) build_read<T>(a, rc, r, &L.b, rcode != 0);
+    if ((a.dev & SGK_DEV_TRACE) && lane_id() == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(a.scratch) + 4ull * blockIdx.x;
+        tr[0] = t0;
+        tr[1] = t1;
+        tr[2] = wall_clock64();
+        tr[3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#else
     build_read<T>(a, rc, r, &L.b, rcode != 0);
+#endif
 }
 
 // ---- the chain: detector, seam check and builder of one segment in one wave (round 4) -------------------------
@@ -1900,23 +2020,42 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (out of line, arguments BY VALUE: inlined into k_event its second copy of the detector pass costs the whole-read path
-// 36 spilled registers; a reference parameter would pin the kernel's argument block and the read context in scratch)
+// (ONE call site of detect_span for the speculative pass and the re-run from the true state: each inlined copy of the
+// detector pass is ~25 KB of code.)
 template <int W1, typename T>
-__device__ __attribute__((noinline)) void chain_segment(const EvArgs a, const ReadCtx<T> rc, uint32_t r, uint32_t g,
-                                                        uint32_t lread, uint32_t seg_len, SegState *st, int rcode, int sa,
-                                                        int sb, EventLds *L) {
-    const int l = lane_id();
+__device__ __forceinline__ void chain_segment(const EvArgs &a, uint32_t bx, EventLds *L) {
+    if (bx >= a.hdr->n_segs) return;
+    const SegDesc d = a.segs[bx];
+    if (d.read == SEG_NONE) return;
+    const uint32_t r = d.read, g = d.g, lread = d.lread;
+    const ReadCtx<T> rc = make_ctx<T>(a, r);
     LongRead *lrp = a.longs + lread;
+    const uint32_t seg_len = lrp->seg_len;
+    int sa, sb;
+    seg_span(seg_len, g, rc.n, sa, sb);
+    SegState *st = a.seg_state + bx;
+    const int l = lane_id();
     const uint32_t nseg = lrp->nseg;
-    bool declined = rcode != 0;
+    bool declined = false;
     uint32_t prev_cum = 0u;
     int prev_last = -1;
-    // (what detect_span's lanes stored -- st->end, cross runs, pre peaks -- is visible to the wave's other lanes)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (g > 0) {
+    int mode = g == 0 ? 0 : 1;
+#ifdef SGK_DEV
+    unsigned long long tt0 = 0ull, tt1 = 0ull, tt2 = 0ull;
+    if (a.dev & SGK_DEV_TRACE) tt0 = wall_clock64();
+#endif
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int rcode = detect_span<W1, T, false>(rc, a.hdr, &L->lz, nullptr, sa, sb, mode, a.lead_override, st);
+#ifdef SGK_DEV
+        if ((a.dev & SGK_DEV_TRACE) && attempt == 0) tt1 = wall_clock64();
+#endif
+        if (l == 0) st->status = rcode;
+        declined = rcode != 0;
+        // (what detect_span's lanes stored -- st->end, cross runs, pre peaks -- is visible to the wave's other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (g == 0 || attempt == 1) break;
         SegState *ps = st - 1;
         int ok = 1;
         if (l == 0) {
@@ -1939,35 +2078,28 @@ __device__ __attribute__((noinline)) void chain_segment(const EvArgs a, const Re
         prev_cum = ld_agent(&ps->cum_cnt);
         prev_last = (int)ld_agent(reinterpret_cast<const uint32_t *>(&ps->last_pos));
         if (!ok || (ld_agent(&ps->cflags) & 1u)) declined = true;
-        if (!declined) {
-            // the seam (st->init0 / st->end: this wave's own stores; the states are in LDS as well)
-            const LzSnapState mine = L->lz.snap.init[0];
-            if (!lz_equal(pe, mine)) {
-                __syncthreads();
-                if (l == 0) {
-                    L->lz.snap.st0[0] = pe;
-                    atomicAdd(&a.hdr->n_seam_rerun, 1u);
-                }
-                __syncthreads();
-                rcode = detect_span<W1, T, false>(rc, a.hdr, &L->lz, nullptr, sa, sb, 2, a.lead_override, st);
-                if (l == 0) st->status = rcode;
-                declined = rcode != 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+        if (declined) break;
+        // the seam (st->init0 / st->end: this wave's own stores; the states are in LDS as well)
+        const LzSnapState mine = L->lz.snap.init[0];
+        if (lz_equal(pe, mine)) break;
+        __syncthreads();
+        if (l == 0) {
+            L->lz.snap.st0[0] = pe;
+            atomicAdd(&a.hdr->n_seam_rerun, 1u);
         }
-        if (!declined) {
-            // hot runs that began in front of the seam: the part in front of it
-            __syncthreads();
-            const int nc = (int)st->n_cross;
-            if (nc > 0) {
-                const bool has = l < nc;
-                const LzRun run = has ? st->cross[l] : LzRun{0, 0};
-                int found = 0;
-                replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr, &found);
-                if (__any(found != 0)) declined = true;
-            }
+        __syncthreads();
+        mode = 2;   // once more, from the true state
+    }
+    if (g > 0 && !declined) {
+        // hot runs that began in front of the seam: the part in front of it
+        __syncthreads();
+        const int nc = (int)st->n_cross;
+        if (nc > 0) {
+            const bool has = l < nc;
+            const LzRun run = has ? st->cross[l] : LzRun{0, 0};
+            int found = 0;
+            replay_run<W1, T, false>(rc, nullptr, has, run.a, run.b, 0, sa, a.hdr, &found);
+            if (__any(found != 0)) declined = true;
         }
     }
     // this wave's bitmap words (and the replay's atomics) are complete before any of its lanes reads them back
@@ -2016,9 +2148,21 @@ __device__ __attribute__((noinline)) void chain_segment(const EvArgs a, const Re
         st_agent(&st->stage, 1u);
     }
     uint32_t fl = declined ? 1u : 0u;
+#ifdef SGK_DEV
+    if (a.dev & SGK_DEV_TRACE) tt2 = wall_clock64();
+#endif
     if (!declined) {
         build_read<T, true>(a, rc, r, &L->b, false, sa, sb, st, prev_cum, prev_last, st->pre, n_pre);
         __syncthreads();
+#ifdef SGK_DEV
+        if ((a.dev & SGK_DEV_TRACE) && l == 0) {   // (segments: start, detector end, seam + publish end | builder end in the top bits)
+            unsigned long long *tr = reinterpret_cast<unsigned long long *>(a.scratch) + 4ull * (a.n_reads + blockIdx.x);
+            tr[0] = tt0;
+            tr[1] = tt1;
+            tr[2] = wall_clock64();
+            tr[3] = (1ull << 63) | ((tt2 - tt0) << 16) | (g & 0xffffu);
+        }
+#endif
         if (l == 0) {
             const uint32_t lo = st->ext_lo, hi = st->ext_hi;
             if constexpr (std::is_same<T, int16_t>::value) {
@@ -2067,6 +2211,13 @@ __device__ __attribute__((noinline)) void chain_segment(const EvArgs a, const Re
         atomicAdd(&a.hdr->n_events_total, (unsigned long long)nev);
         if (flags & 2u) atomicAdd(&a.hdr->n_overflow, 1u);
     }
+}
+
+// The segments' kernel: a workgroup per entry of the segment list (usually much shorter than its capacity).
+template <int W1, typename T>
+__global__ __launch_bounds__(64, (W1 == 3 ? SGK_DET_WAVES_DNA : SGK_DET_WAVES_RNA)) void k_event_seg(EvArgs a) {
+    __shared__ EventLds L;
+    chain_segment<W1, T>(a, blockIdx.x, &L);
 }
 
 // Short reads, several per wavefront: `lanes` consecutive lanes share a read (detector: detect_span<MULTI>), then the
@@ -2202,15 +2353,28 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         if (rc != SGK_OK) return rc;
     } else ao.order = nullptr;
     if (ao.max_segs) hipLaunchKernelGGL(k_seg_plan, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, ao);
-    // (no dispatch order and packing on: every read is under multi_max.  k_event would have nothing to do -- unless
-    // the segments are test-sized and some of those reads are long: their segments are k_event's)
-    const bool all_short = ao.multi_lanes && !ao.order && !ao.max_segs;
-    // the tail split's segments take k_event's LAST workgroups (small units into the slots the last whole reads leave
-    // empty), long reads' segments its first (a kernel cannot end before its longest read has)
+    // The segments' kernel.  Long reads' segments start FIRST: they stay on the caller's stream and k_event goes to a
+    // side stream whose start waits for the fork event (the other way round k_event's workgroups -- ten thousand of them
+    // -- take every slot and the chains start late: a ragged batch took 3.81 ms instead of 3.65; stat's long reads taught
+    // the same, stat_kernels.hip launch_beside_long).  The tail split's segments go LAST, behind k_event on the caller's
+    // stream: small units for the slots the last whole reads leave empty.
     const bool tail_only = ao.max_segs && ao.split_seg && !ao.has_long;
-    SideFork multi_side;
-    hipStream_t st_multi = st;
+    auto launch_segs = [&](hipStream_t s_) {
+        ProfScope ps("k_event_seg", s_);
+        if (rna) hipLaunchKernelGGL((k_event_seg<7, T>), dim3(ao.max_segs), dim3(64), 0, s_, ao);
+        else hipLaunchKernelGGL((k_event_seg<3, T>), dim3(ao.max_segs), dim3(64), 0, s_, ao);
+    };
+    // (no dispatch order and packing on: every read is under multi_max.  k_event would have nothing to do -- unless
+    // the segments are test-sized and some of those reads are long: their segments are k_event_seg's)
+    const bool all_short = ao.multi_lanes && !ao.order && !ao.max_segs;
+    SideFork multi_side, whole_side;
+    hipStream_t st_multi = st, st_whole = st;
     if (ao.multi_lanes && !all_short && multi_side.open(0, st)) st_multi = multi_side.stream();
+    if (ao.max_segs && !tail_only && !all_short && whole_side.open(0, st)) st_whole = whole_side.stream();
+    if (ao.max_segs && !tail_only) {
+        launch_segs(st);
+        SGK_HIP_TRY(hipGetLastError());
+    }
     if (ao.multi_lanes) {
         ProfScope ps("k_event_multi", st_multi);
         const uint32_t per_wave = 64u / ao.multi_lanes;
@@ -2220,15 +2384,16 @@ static int launch_event_t(const EvArgs &a, int rna, uint32_t n_fb_blocks, hipStr
         SGK_HIP_TRY(hipGetLastError());
     }
     if (!all_short) {
-        ProfScope ps("k_event", st);
-        ao.seg_blocks = ao.max_segs;
-        ao.seg_last = tail_only ? 1u : 0u;
-        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(ao.seg_blocks + a.n_reads), dim3(64), 0, st, ao);
-        else hipLaunchKernelGGL((k_event<3, T>), dim3(ao.seg_blocks + a.n_reads), dim3(64), 0, st, ao);
+        ProfScope ps("k_event", st_whole);
+        if (rna) hipLaunchKernelGGL((k_event<7, T>), dim3(a.n_reads), dim3(64), 0, st_whole, ao);
+        else hipLaunchKernelGGL((k_event<3, T>), dim3(a.n_reads), dim3(64), 0, st_whole, ao);
     }
+    SGK_HIP_TRY(hipGetLastError());
+    if (tail_only) launch_segs(st);
     SGK_HIP_TRY(hipGetLastError());
     // join: the fallback kernel (and whatever the caller enqueues next) waits for the side streams as well
     multi_side.join();
+    whole_side.join();
     {
         ProfScope ps("k_event_fallback", st);
         if (rna) hipLaunchKernelGGL((k_event_fallback<7, T>), dim3(n_fb_blocks), dim3(64), 0, st, a);

@@ -88,10 +88,14 @@ def test_lanes_for_short_reads(lib):
 
 def test_tail_split(lib):
     """a batch of fewer than 8 rounds of wavefronts (256 CUs x 4 SIMDs x 3 waves with the DNA preset, x 2 with RNA
-    parameters; without a GPU the plan assumes 256 CUs) whose last round is partial: its reads are cut into segments"""
-    p, _ = plan(lib, [100000] * 10000)                  # 10 000 = 3 x 3072 + 784: the last 784 reads, 4 segments each
-    assert (p.tail_split_from, p.tail_segment_len) == (9216, 25600)
-    assert p.max_segments >= 784 * 4 and p.max_long_reads >= 784
+    parameters; without a GPU the plan assumes 256 CUs) whose last round is at most a sixth of a round, or a batch of at
+    most a third of a round: those reads are cut into segments (round 5: a cut read costs 1.5 x a whole one, so the
+    rule is narrower than round 4's -- profiles/r05_tail_split_sweep.txt)"""
+    p, _ = plan(lib, [100000] * 9300)                   # 9 300 = 3 x 3072 + 84: the last 84 reads, 16 384-sample segments
+    assert (p.tail_split_from, p.tail_segment_len) == (9216, 16384)
+    assert p.max_segments >= 84 * 7 and p.max_long_reads >= 84
+    assert plan(lib, [100000] * 10000)[0].tail_segment_len == 0             # 784 reads over: a quarter of a round, not cut
+    assert plan(lib, [100000] * 2000)[0].tail_segment_len == 0              # two thirds of a round: not cut
     p, _ = plan(lib, [100000] * 1000)                   # a third of a round: 3 segments each fill it
     assert p.tail_split_from == 0 and p.tail_segment_len == 33792
     p, _ = plan(lib, [100000] * 160)                    # a CLI-sized batch: at most 8 segments per read
@@ -100,17 +104,17 @@ def test_tail_split(lib):
     assert plan(lib, [100000] * 12000)[0].tail_segment_len == 0             # the last round is nearly full
     assert plan(lib, [100000] * 30000)[0].tail_segment_len == 0             # >= 8 rounds: the tail does not matter
     assert plan(lib, [100000] * 10000, rna=1)[0].tail_segment_len == 0      # 2 048 slots: 4.88 rounds, nearly full
-    assert plan(lib, [100000] * 9000, rna=1)[0].tail_segment_len > 0
+    assert plan(lib, [100000] * 8400, rna=1)[0].tail_segment_len > 0        # 4 x 2048 + 208
     assert plan(lib, [20000] * 10000)[0].tail_segment_len == 0              # short reads: not worth two kernels more
-    assert plan(lib, [100000] * 10000, opt=opts(tail_split=-1))[0].tail_segment_len == 0
+    assert plan(lib, [100000] * 9300, opt=opts(tail_split=-1))[0].tail_segment_len == 0
     p = plan(lib, [100000] * 30000, opt=opts(tail_split=2000))[0]      # the caller's number, whatever the batch
     assert (p.tail_split_from, p.tail_segment_len) == (28000, 50176)
     # the workspace has room for the lists
     from sigtk_amd import api
     lib.sgk_event_workspace_bytes_opt.restype = C.c_size_t
-    a = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts(tail_split=-1)))
-    b = lib.sgk_event_workspace_bytes_opt(10000, 10 ** 9, 100000, C.byref(opts()))
-    assert b >= a + 784 * 4 * 320
+    a = lib.sgk_event_workspace_bytes_opt(9300, 93 * 10 ** 7, 100000, C.byref(opts(tail_split=-1)))
+    b = lib.sgk_event_workspace_bytes_opt(9300, 93 * 10 ** 7, 100000, C.byref(opts()))
+    assert b >= a + 84 * 7 * 320
 
 
 def test_the_0_1_0_plan_call_keeps_its_signature(lib):
