@@ -68,7 +68,7 @@ extern "C" {
  *        wavefront).
  * 0.2.2: the long-read path of stat / jnn / prefix declines a read whose workgroups time out at a barrier and the wave
  *        kernel redoes it (no result depends on the long path having worked; sgk_long_status_t::n_timeouts counts those
- *        reads); sgk_stat_options_t::debug_fault (was reserved[0]); sgk_job_long_declined;
+ *        reads); sgk_stat_options_t::debug_fault (was reserved[0]); sgk_job_long_declined; sgk_inflate, SGK_SIGNAL_ZREC / sgk_job_begin_zrec;
  *        the six-argument plan call is sgk_event_plan_opt; sgk_event_plan is the 0.1.0 five-argument form again (deprecated). */
 #define SGK_VERSION_STRING "0.2.2"
 
@@ -348,6 +348,20 @@ int sgk_svbzd_decode(const uint8_t *blobs, const uint64_t *blob_offsets, const u
                      uint32_t n_reads, int16_t *samples, const uint64_t *offsets, const uint32_t *lengths,
                      uint32_t *status, void *stream);
 
+/* ---- zlib record inflate on the device (round 5; SURVEY 8f-1 / 8f-2 taken to the record layer) ------------------ */
+/* BLOW5 files compress every record as one zlib stream (slow5lib/src/slow5.c:2583-2598); the reference inflates them one
+ * at a time on its one thread, and a pool of host threads is what bounded the drop-in CLI's rate.  sgk_inflate inflates n
+ * zlib streams (RFC 1950: header, DEFLATE blocks of every type, Adler-32), one wavefront per stream.  in: device buffer
+ * readable up to its size rounded up to a multiple of 4 bytes; in_offsets / in_lengths: byte offset and length of every
+ * stream; out: 16-byte aligned device buffer, stream r's bytes go to out + out_offsets[r] (offsets multiples of 16), which
+ * must have room for out_caps[r] bytes >= what the stream inflates to (matches that reach far back read the stream's own
+ * earlier bytes from there); out_lengths[r]: what the stream inflated to; status[r]: 0 ok, 1 bad zlib header / preset
+ * dictionary, 2 bad block type / stored length, 3 bad code lengths, 4 invalid code, 5 distance in front of the stream,
+ * 6 truncated input, 7 Adler-32 mismatch, 8 the stream inflates to more than out_caps[r] (1 - 8: the bytes are undefined). */
+int sgk_inflate(const uint8_t *in, const uint64_t *in_offsets, const uint32_t *in_lengths, uint32_t n, uint8_t *out,
+                const uint64_t *out_offsets, const uint32_t *out_caps, uint32_t *out_lengths, uint32_t *status,
+                void *stream);
+
 /* ---- qts: quantise the raw signal (src/qts.c:27-43, :126-142) and re-encode it ------ */
 #define SGK_QTS_FLOOR 0     /* (raw >> b) << b                                       */
 #define SGK_QTS_ROUND 1     /* round_to_power_of_2(raw, b): the reference's default   */
@@ -444,6 +458,8 @@ typedef struct sgk_job sgk_job_t;
 
 #define SGK_SIGNAL_INT16 0 /* caller stages decoded int16 samples                        */
 #define SGK_SIGNAL_SVBZD 1 /* caller stages svb-zd blobs; decoded on the GPU (8f-1)      */
+#define SGK_SIGNAL_ZREC 2  /* caller stages whole zlib-compressed BLOW5 records (svb-zd signal): inflated and decoded on the
+                            * GPU (sgk_job_begin_zrec) */
 
 #define SGK_JOB_EVENTS_COMPACT 1 /* submit flag: only event start/length are copied back (event -c) */
 
@@ -488,6 +504,16 @@ int sgk_job_device(const sgk_job_t *job);
 /* lengths[r]: samples of read r; blob_bytes[r] (SGK_SIGNAL_SVBZD only): byte length of its blob */
 int sgk_job_begin(sgk_job_t *job, uint32_t n_reads, const uint32_t *lengths, int signal_format,
                   const uint32_t *blob_bytes, sgk_job_input_t *in);
+/* The records as they sit in a BLOW5 file with zlib records and svb-zd signal (0.2.2): the caller stages record r's
+ * rec_bytes[r] on-disk bytes at in->blobs + in->blob_offsets[r] and fills the scaling; the job inflates them on the GPU
+ * (sgk_inflate) and decodes the signal blobs from there.  What the caller must know of a record it knows from its head
+ * (a few hundred inflated bytes): lengths[r] samples, the signal blob at sig_offset[r] of the inflated record and
+ * sig_bytes[r] long, the inflated record rec_room[r] bytes at most (head + signal + auxiliary fields; a record that
+ * inflates to more fails with status 0x108).  sgk_job_wait returns SGK_ERR_FORMAT if a record did not inflate or decode
+ * (decode_status[r]: 0x100 | sgk_inflate's status, or sgk_svbzd_decode's). */
+int sgk_job_begin_zrec(sgk_job_t *job, uint32_t n_reads, const uint32_t *lengths, const uint32_t *rec_bytes,
+                       const uint32_t *sig_offset, const uint32_t *sig_bytes, const uint32_t *rec_room,
+                       sgk_job_input_t *in);
 /* may be called again after sgk_job_wait to run another tool over the same staged batch */
 int sgk_job_submit(sgk_job_t *job, int tool, int rna, int pore, int flags);
 /* qts over the staged batch: quantise (bits in [1,15], method SGK_QTS_*), then hand the signal back as svb-zd blobs

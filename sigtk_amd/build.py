@@ -22,7 +22,7 @@ CLI = os.path.join(PKG, "sigtk-amd")
 CLI_ASAN = os.path.join(PKG, "sigtk-amd-asan")
 
 HIP_SOURCES = ["api.hip", "api_stat.hip", "event_kernels.hip", "stat_kernels.hip", "misc_kernels.hip",
-               "svb_kernels.hip", "ent_kernels.hip", "qts_kernels.hip", "job.hip", "shims.hip"]
+               "svb_kernels.hip", "inflate_kernels.hip", "ent_kernels.hip", "qts_kernels.hip", "job.hip", "shims.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-c++20-extensions", "-Wno-pass-failed"]

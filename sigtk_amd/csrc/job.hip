@@ -87,6 +87,11 @@ struct sgk_job {
     GrowDev d_out[4], d_cnt;
     GrowDev d_dense[4], d_doffs;      // event / jnn: items gathered to dense per-read ranges before the download
     GrowPin h_out[4], h_cnt, h_dstat, h_doffs, h_err, h_long;
+    // SGK_SIGNAL_ZREC: the records as they sit in the file (h_blobs / d_blobs), inflated on the device into d_inflated;
+    // per record: where it goes there, how much room it has, where its signal blob starts (all relative to d_inflated)
+    GrowPin h_ioffs, h_icaps, h_istat, h_soffs, h_slens;
+    GrowDev d_inflated, d_ioffs, d_icaps, d_ilens, d_istat, d_soffs, d_slens;
+    uint64_t inflated_bytes = 0;
     bool long_fetched = false;        // stat / jnn / prefix: the long-read header of the call is on its way to h_long
     uint32_t long_declined = 0;       // ... long reads the long path declined (n_timeouts of sgk_long_status_t), after wait
     int n_dense = 0;                  // arrays to fetch in sgk_job_wait once the dense total is known
@@ -158,11 +163,26 @@ void sgk_job_destroy(sgk_job_t *j) {
 
 int sgk_job_device(const sgk_job_t *j) { return j ? j->device : -1; }
 
+static int job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int signal_format, const uint32_t *blob_bytes,
+                     const uint32_t *sig_offset, const uint32_t *sig_bytes, const uint32_t *rec_room, sgk_job_input_t *in);
+
 int sgk_job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int signal_format,
                   const uint32_t *blob_bytes, sgk_job_input_t *in) {
-    if (!j || !in || (n_reads && !lengths)) return SGK_ERR_ARG;
     if (signal_format != SGK_SIGNAL_INT16 && signal_format != SGK_SIGNAL_SVBZD) return SGK_ERR_ARG;
-    if (signal_format == SGK_SIGNAL_SVBZD && n_reads && !blob_bytes) return SGK_ERR_ARG;
+    return job_begin(j, n_reads, lengths, signal_format, blob_bytes, nullptr, nullptr, nullptr, in);
+}
+
+int sgk_job_begin_zrec(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, const uint32_t *rec_bytes,
+                       const uint32_t *sig_offset, const uint32_t *sig_bytes, const uint32_t *rec_room,
+                       sgk_job_input_t *in) {
+    if (n_reads && (!rec_bytes || !sig_offset || !sig_bytes || !rec_room)) return SGK_ERR_ARG;
+    return job_begin(j, n_reads, lengths, SGK_SIGNAL_ZREC, rec_bytes, sig_offset, sig_bytes, rec_room, in);
+}
+
+static int job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int signal_format, const uint32_t *blob_bytes,
+                     const uint32_t *sig_offset, const uint32_t *sig_bytes, const uint32_t *rec_room, sgk_job_input_t *in) {
+    if (!j || !in || (n_reads && !lengths)) return SGK_ERR_ARG;
+    if (signal_format != SGK_SIGNAL_INT16 && n_reads && !blob_bytes) return SGK_ERR_ARG;
     SGK_HIP_TRY(hipSetDevice(j->device));
     if (j->submitted) return SGK_ERR_ARG;  // previous batch still in flight: sgk_job_wait first
     const size_t nr = n_reads, nr1 = nr ? nr : 1;
@@ -191,7 +211,7 @@ int sgk_job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int s
     j->fmt = signal_format;
     j->blob_bytes = 0;
     memset(in, 0, sizeof *in);
-    if (signal_format == SGK_SIGNAL_SVBZD) {
+    if (signal_format == SGK_SIGNAL_SVBZD || signal_format == SGK_SIGNAL_ZREC) {
         if ((rc = j->h_boffs.ensure(nr1 * 8)) != SGK_OK) return rc;
         if ((rc = j->h_blens.ensure(nr1 * 4)) != SGK_OK) return rc;
         uint64_t *bo = j->h_boffs.as<uint64_t>();
@@ -206,6 +226,26 @@ int sgk_job_begin(sgk_job_t *j, uint32_t n_reads, const uint32_t *lengths, int s
         if ((rc = j->h_blobs.ensure(j->blob_bytes)) != SGK_OK) return rc;
         in->blobs = j->h_blobs.as<uint8_t>();
         in->blob_offsets = bo;
+        if (signal_format == SGK_SIGNAL_ZREC) {
+            // where every record inflates to (16-byte aligned), its room, and -- for the svb-zd decoder --
+            // where its signal blob then lies and how long it is
+            if ((rc = j->h_ioffs.ensure(nr1 * 8)) != SGK_OK) return rc;
+            if ((rc = j->h_icaps.ensure(nr1 * 4)) != SGK_OK) return rc;
+            if ((rc = j->h_soffs.ensure(nr1 * 8)) != SGK_OK) return rc;     // (blob offsets inside d_inflated)
+            if ((rc = j->h_slens.ensure(nr1 * 4)) != SGK_OK) return rc;     // (blob lengths)
+            uint64_t *io = j->h_ioffs.as<uint64_t>(), *so = j->h_soffs.as<uint64_t>();
+            uint32_t *ic = j->h_icaps.as<uint32_t>(), *sl = j->h_slens.as<uint32_t>();
+            uint64_t o2 = 0;
+            for (size_t r = 0; r < nr; ++r) {
+                if ((uint64_t)sig_offset[r] + sig_bytes[r] > rec_room[r]) return SGK_ERR_ARG;
+                io[r] = o2;
+                ic[r] = rec_room[r];
+                so[r] = o2 + sig_offset[r];
+                sl[r] = sig_bytes[r];
+                o2 += round_up(rec_room[r], 16);
+            }
+            j->inflated_bytes = o2 + 16;
+        }
     } else {
         if ((rc = j->h_samples.ensure(j->n_samples * sizeof(int16_t))) != SGK_OK) return rc;
         in->samples = j->h_samples.as<int16_t>();
@@ -242,7 +282,33 @@ static int job_upload(sgk_job_t *j, sgk_batch_t *view) {
     if ((rc = h2d(j->d_dig, j->h_dig, nr * 8, st)) != SGK_OK) return rc;
     if ((rc = h2d(j->d_off, j->h_off, nr * 8, st)) != SGK_OK) return rc;
     if ((rc = h2d(j->d_rng, j->h_rng, nr * 8, st)) != SGK_OK) return rc;
-    if (j->fmt == SGK_SIGNAL_SVBZD) {
+    if (j->fmt == SGK_SIGNAL_ZREC) {
+        // the records as they sit in the file -> inflated on the device -> their svb-zd blobs decoded from there
+        if ((rc = j->d_samples.ensure(j->n_samples * sizeof(int16_t))) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_blobs, j->h_blobs, j->blob_bytes, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_boffs, j->h_boffs, nr * 8, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_blens, j->h_blens, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_ioffs, j->h_ioffs, nr * 8, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_icaps, j->h_icaps, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_soffs, j->h_soffs, nr * 8, st)) != SGK_OK) return rc;
+        if ((rc = h2d(j->d_slens, j->h_slens, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = j->d_inflated.ensure(j->inflated_bytes)) != SGK_OK) return rc;
+        if ((rc = j->d_ilens.ensure(nr * 4)) != SGK_OK) return rc;
+        if ((rc = j->d_istat.ensure(nr * 4)) != SGK_OK) return rc;
+        if ((rc = j->d_dstat.ensure(nr * 4)) != SGK_OK) return rc;
+        rc = sgk_inflate(j->d_blobs.as<uint8_t>(), j->d_boffs.as<uint64_t>(), j->d_blens.as<uint32_t>(), j->n_reads,
+                         j->d_inflated.as<uint8_t>(), j->d_ioffs.as<uint64_t>(), j->d_icaps.as<uint32_t>(),
+                         j->d_ilens.as<uint32_t>(), j->d_istat.as<uint32_t>(), st);
+        if (rc != SGK_OK) return rc;
+        // (a record that did not inflate leaves whatever it leaves: its blob then fails the decoder's own checks or
+        // decodes to garbage nobody reads -- sgk_job_wait refuses the batch on the inflate status)
+        rc = sgk_svbzd_decode(j->d_inflated.as<uint8_t>(), j->d_soffs.as<uint64_t>(), j->d_slens.as<uint32_t>(), j->n_reads,
+                              j->d_samples.as<int16_t>(), j->d_offsets.as<uint64_t>(), j->d_lengths.as<uint32_t>(),
+                              j->d_dstat.as<uint32_t>(), st);
+        if (rc != SGK_OK) return rc;
+        if ((rc = d2h(j->h_dstat, j->d_dstat, nr * 4, st)) != SGK_OK) return rc;
+        if ((rc = d2h(j->h_istat, j->d_istat, nr * 4, st)) != SGK_OK) return rc;
+    } else if (j->fmt == SGK_SIGNAL_SVBZD) {
         if ((rc = j->d_samples.ensure(j->n_samples * sizeof(int16_t))) != SGK_OK) return rc;
         if ((rc = h2d(j->d_blobs, j->h_blobs, j->blob_bytes, st)) != SGK_OK) return rc;
         if ((rc = h2d(j->d_boffs, j->h_boffs, nr * 8, st)) != SGK_OK) return rc;
@@ -515,6 +581,18 @@ int sgk_job_wait(sgk_job_t *j) {
         j->long_declined = reinterpret_cast<const LongHdr *>(j->h_long.p)->n_declined;
         j->long_fetched = false;
     }
+    if (j->fmt == SGK_SIGNAL_ZREC) {
+        // a record that did not inflate (malformed stream, check value, more bytes than its head announced): as the
+        // reference's slow5_get_next error.  decode_status carries 0x100 | the inflate status for such a read.
+        uint32_t *ds = j->h_dstat.as<uint32_t>();
+        const uint32_t *is = j->h_istat.as<uint32_t>();
+        bool bad = false;
+        for (uint32_t r = 0; r < j->n_reads; ++r) {
+            if (is[r] != 0) ds[r] = 0x100u | is[r];
+            bad = bad || ds[r] != 0;
+        }
+        if (bad) return SGK_ERR_FORMAT;
+    }
     if (j->fmt == SGK_SIGNAL_SVBZD) {
         const uint32_t *ds = j->h_dstat.as<uint32_t>();
         for (uint32_t r = 0; r < j->n_reads; ++r)
@@ -562,7 +640,7 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
     out->n_reads = j->n_reads;
     out->offsets = j->h_offsets.as<uint64_t>();
     out->lengths = j->h_lengths.as<uint32_t>();
-    out->decode_status = j->fmt == SGK_SIGNAL_SVBZD ? j->h_dstat.as<uint32_t>() : nullptr;
+    out->decode_status = (j->fmt == SGK_SIGNAL_SVBZD || j->fmt == SGK_SIGNAL_ZREC) ? j->h_dstat.as<uint32_t>() : nullptr;
     switch (j->tool) {
         case SGK_TOOL_PA:
             out->pa = j->h_out[0].as<float>();

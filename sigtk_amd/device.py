@@ -297,3 +297,41 @@ def svbzd_encode(b: DeviceReads):
     torch.cuda.synchronize()
     host = blobs.cpu().numpy()
     return [host[int(offs[r]):int(offs[r]) + int(lens[r])].tobytes() for r in range(n)]
+
+
+def inflate(streams, caps=None, device: Optional[torch.device] = None):
+    """sgk_inflate over a list of zlib streams (bytes) -> (list of inflated bytes as kept: the first caps[r] of each,
+    out_lengths, status) -- the device-side replacement of slow5lib's per-record uncompress()"""
+    L = api.load_library()
+    dev = device or torch.device("cuda", 0)
+    n = len(streams)
+    in_off = np.zeros(n, dtype=np.uint64)
+    in_len = np.asarray([len(s) for s in streams], dtype=np.uint32)
+    pos = 0
+    for r, s in enumerate(streams):
+        in_off[r] = pos
+        pos += len(s) + (r % 3)          # (odd offsets on purpose: the kernel aligns its dword reads itself)
+    blob = np.zeros((pos + 7) // 4 * 4 + 4, dtype=np.uint8)
+    for r, s in enumerate(streams):
+        blob[int(in_off[r]):int(in_off[r]) + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    caps_a = np.asarray(caps if caps is not None else [1 << 20] * n, dtype=np.uint32)
+    out_off = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        out_off[1:] = np.cumsum((caps_a[:-1].astype(np.uint64) + 15) // 16 * 16)
+    total = int(out_off[-1] + (int(caps_a[-1]) + 15) // 16 * 16) if n else 16
+    d_in = torch.from_numpy(blob).to(dev)
+    d_ioff = torch.from_numpy(in_off.view(np.int64)).to(dev)
+    d_ilen = torch.from_numpy(in_len.view(np.int32)).to(dev)
+    d_out = torch.zeros(max(total, 16), dtype=torch.uint8, device=dev)
+    d_ooff = torch.from_numpy(out_off.view(np.int64)).to(dev)
+    d_caps = torch.from_numpy(caps_a.view(np.int32)).to(dev)
+    d_olen = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    d_st = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+    api.check(L.sgk_inflate(_ptr(d_in), _ptr(d_ioff), _ptr(d_ilen), n, _ptr(d_out), _ptr(d_ooff), _ptr(d_caps), _ptr(d_olen),
+                            _ptr(d_st), _stream_ptr()), "sgk_inflate")
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    olen = d_olen.cpu().numpy().view(np.uint32)[:n]
+    st = d_st.cpu().numpy()[:n]
+    kept = [out[int(out_off[r]):int(out_off[r]) + min(int(olen[r]), int(caps_a[r]))].tobytes() for r in range(n)]
+    return kept, olen, st

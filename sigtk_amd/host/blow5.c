@@ -522,6 +522,103 @@ int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t 
     return 0;
 }
 
+int b5_parse_head(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,
+                  b5_view_t *out) {
+    if (f->record_press != 1) return B5_ERR_FORMAT;
+    /* u16 id_len, id, 44 bytes of fields, and the blob's count word: 512 bytes hold an id of up to 462 characters;
+     * a longer one (never seen: ids are UUIDs) goes round again with the room it needs */
+    uint64_t want = *scratch_cap >= 512 ? *scratch_cap : 512;
+    for (;;) {
+        const int rc = grow(scratch, scratch_cap, want);
+        if (rc) return rc;
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit(&z) != Z_OK) return B5_ERR_MEM;
+        z.next_in = (Bytef *)raw;
+        z.avail_in = size > 0xffffffffull ? 0xffffffffu : (uInt)size;
+        z.next_out = *scratch;
+        z.avail_out = (uInt)(*scratch_cap > 0x7fffffffull ? 0x7fffffffull : *scratch_cap);
+        const int zr = inflate(&z, Z_SYNC_FLUSH);
+        const uint64_t got = z.total_out;
+        inflateEnd(&z);
+        if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) return B5_ERR_PRESS;
+        if (got < 2) return B5_ERR_FORMAT;
+        const uint8_t *p = *scratch;
+        uint16_t idl;
+        memcpy(&idl, p, 2);
+        const uint64_t need = 2 + (uint64_t)idl + 44 + (f->signal_press == 1 ? 4 : 0);
+        if (got < need) {
+            if (zr == Z_STREAM_END) return B5_ERR_FORMAT;   /* the record ends inside its own head */
+            if (*scratch_cap >= need) return B5_ERR_PRESS;    /* (room was not the problem) */
+            want = need;
+            continue;
+        }
+        out->rec = NULL;
+        out->rec_len = 0;
+        out->read_id = (const char *)(p + 2);
+        out->id_len = idl;
+        const uint8_t *q = p + 2 + idl;
+        memcpy(&out->read_group, q, 4);
+        memcpy(&out->digitisation, q + 4, 8);
+        memcpy(&out->offset, q + 12, 8);
+        memcpy(&out->range, q + 20, 8);
+        memcpy(&out->sampling_rate, q + 28, 8);
+        uint64_t ln;
+        memcpy(&ln, q + 36, 8);
+        out->signal = NULL;
+        out->signal_offset = 2u + idl + 44u;
+        if (f->signal_press == 1) {
+            if (ln < 4 || ln > 0xffffffffull) return B5_ERR_FORMAT;
+            uint32_t count;
+            memcpy(&count, q + 44, 4);
+            if (count > 0x7fffffffu || 4 + ((uint64_t)count + 3) / 4 + (uint64_t)count > ln) return B5_ERR_FORMAT;
+            out->signal_bytes = ln;
+            out->n_samples = count;
+        } else {
+            if (ln > 0x7fffffffull) return B5_ERR_FORMAT;
+            out->signal_bytes = ln * 2;
+            out->n_samples = (uint32_t)ln;
+        }
+        return 0;
+    }
+}
+
+int64_t b5_aux_fixed_bytes(const b5_file_t *f) {
+    /* the "#char*\tuint32_t\t..." line of the header names the type of every column: the first eight are the primary
+     * fields, what follows are the auxiliary ones (slow5lib/src/slow5.c:794-881) */
+    const char *p = f->hdr_text;
+    const char *line = NULL;
+    while (p && *p) {
+        if (p[0] == '#' && strncmp(p, "#char*", 6) == 0) { line = p; break; }
+        p = strchr(p, '\n');
+        if (p) ++p;
+    }
+    if (!line) return -1;
+    int64_t total = 0;
+    int col = 0;
+    const char *q = line + 1;
+    for (;;) {
+        const char *e = q;
+        while (*e && *e != '\t' && *e != '\n') ++e;
+        const size_t n = (size_t)(e - q);
+        if (col >= 8) {
+            int sz = -1;
+            if (n && q[n - 1] == '*') sz = -1;                                   /* arrays: u64 length + data */
+            else if ((n == 6 && !strncmp(q, "int8_t", 6)) || (n == 7 && !strncmp(q, "uint8_t", 7)) || (n == 4 && !strncmp(q, "char", 4))) sz = 1;
+            else if ((n == 7 && !strncmp(q, "int16_t", 7)) || (n == 8 && !strncmp(q, "uint16_t", 8))) sz = 2;
+            else if ((n == 7 && !strncmp(q, "int32_t", 7)) || (n == 8 && !strncmp(q, "uint32_t", 8)) || (n == 5 && !strncmp(q, "float", 5))) sz = 4;
+            else if ((n == 7 && !strncmp(q, "int64_t", 7)) || (n == 8 && !strncmp(q, "uint64_t", 8)) || (n == 6 && !strncmp(q, "double", 6))) sz = 8;
+            else if (n >= 5 && !strncmp(q, "enum{", 5) && q[n - 1] == '}') sz = 1;  /* enums are stored as uint8_t */
+            if (sz < 0) return -1;
+            total += sz;
+        }
+        ++col;
+        if (*e != '\t') break;
+        q = e + 1;
+    }
+    return col >= 8 ? total : -1;
+}
+
 int b5_svb_zd_decode(const uint8_t *blob, uint64_t nbytes, int16_t *dst, uint32_t count) {
     if (nbytes < 4) return B5_ERR_PRESS;
     uint32_t c;

@@ -80,6 +80,7 @@ typedef struct {
     const uint8_t *signal; /* svb-zd blob (signal_press 1) or little-endian int16 samples */
     uint64_t signal_bytes;
     uint32_t n_samples;    /* from the blob's count word, or signal_bytes / 2 */
+    uint32_t signal_offset; /* of the signal inside the inflated record (b5_parse_head: `rec` / `signal` are NULL there) */
 } b5_view_t;
 
 /* appends the next record's on-disk bytes (without the u64 size) to *buf at *len (realloc'd as needed);
@@ -95,6 +96,15 @@ int b5_next_ref(b5_file_t *f, const uint8_t **ptr, uint64_t *size);
  * into *scratch or into raw.  Re-entrant: touches no state of f besides its compression settings. */
 int b5_parse_raw(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,
                  b5_view_t *out);
+/* The HEAD of a zlib-compressed record only: inflates just far enough (into *scratch) for the id, the scaling, the signal's
+ * byte length and -- svb-zd -- its sample count; the view's read_id points into *scratch, rec / signal are NULL,
+ * signal_offset tells where the signal starts in the inflated record.  A few microseconds per record instead of the
+ * whole inflate: the record itself is inflated on the GPU (sgk_job_begin_zrec).  Files with zlib records only. */
+int b5_parse_head(const b5_file_t *f, const uint8_t *raw, uint64_t size, uint8_t **scratch, uint64_t *scratch_cap,
+                  b5_view_t *out);
+/* bytes of a record's auxiliary fields when all of them are primitive (fixed size), else -1 (an array field, an unknown
+ * type): with a fixed size the inflated length of a record follows from its head */
+int64_t b5_aux_fixed_bytes(const b5_file_t *f);
 /* scalar streamvbyte + zigzag-delta decode of one blob into dst[count] (host-decode fallback path) */
 int b5_svb_zd_decode(const uint8_t *blob, uint64_t nbytes, int16_t *dst, uint32_t count);
 

@@ -16,6 +16,7 @@
  */
 #include <getopt.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -307,7 +308,9 @@ typedef struct batch {
     uint64_t raw_len, raw_cap;
     uint64_t bytes;  /* on-disk bytes gathered so far (the batch limit applies to it) */
     uint32_t *lengths, *blob_bytes;
+    uint32_t *sig_off, *sig_len, *room; /* zrec: where the signal sits in the inflated record, its bytes, the record's inflated size */
     int svb;        /* signal staged as svb-zd blobs (GPU decode) */
+    int zrec;       /* whole zlib records staged: inflated and decoded on the GPU */
     int last;       /* sentinel: no more batches */
     struct batch *next;
 } batch_t;
@@ -356,6 +359,8 @@ static batch_t *q_try_pop(queue_t *q) {
 typedef struct {
     b5_file_t *f;
     int mode, nthreads, host_decode;
+    int zrec;            /* records go to the GPU as they sit in the file (zlib records, svb-zd signal, fixed-size auxiliary fields) */
+    int64_t aux_bytes;   /* ... the bytes of a record's auxiliary fields then */
     opt_t opt;
     queue_t free_q, filled_q, ready_q;
     /* reader thread input */
@@ -385,7 +390,10 @@ static void batch_add_record(batch_t *b, uint64_t size, const uint8_t *ref) {
         b->recs = (lrec_t *)realloc(b->recs, sizeof(lrec_t) * nc);
         b->lengths = (uint32_t *)realloc(b->lengths, sizeof(uint32_t) * nc);
         b->blob_bytes = (uint32_t *)realloc(b->blob_bytes, sizeof(uint32_t) * nc);
-        if (!b->recs || !b->lengths || !b->blob_bytes) die_mem();
+        b->sig_off = (uint32_t *)realloc(b->sig_off, sizeof(uint32_t) * nc);
+        b->sig_len = (uint32_t *)realloc(b->sig_len, sizeof(uint32_t) * nc);
+        b->room = (uint32_t *)realloc(b->room, sizeof(uint32_t) * nc);
+        if (!b->recs || !b->lengths || !b->blob_bytes || !b->sig_off || !b->sig_len || !b->room) die_mem();
         memset(b->recs + b->cap, 0, sizeof(lrec_t) * (nc - b->cap));
         b->cap = nc;
     }
@@ -405,8 +413,12 @@ static void load_parse(void *ctx_, uint32_t i, int tid) {
     (void)tid;
     lctx_t *c = (lctx_t *)ctx_;
     lrec_t *r = &c->b->recs[i];
-    r->err = b5_parse_raw(c->P->f, r->raw_ptr ? r->raw_ptr : c->b->raw + r->raw_off, r->raw_size, &r->scratch,
-                          &r->scratch_cap, &r->v);
+    const uint8_t *raw = r->raw_ptr ? r->raw_ptr : c->b->raw + r->raw_off;
+    /* zrec: the head only (id, scaling, sizes: a few hundred inflated bytes); the record itself is inflated on the GPU */
+    if (c->P->zrec) r->err = b5_parse_head(c->P->f, raw, r->raw_size, &r->scratch, &r->scratch_cap, &r->v);
+    else r->err = b5_parse_raw(c->P->f, raw, r->raw_size, &r->scratch, &r->scratch_cap, &r->v);
+    if (c->P->zrec && !r->err && (r->raw_size > 0xffffffffull || r->v.signal_offset + r->v.signal_bytes + (uint64_t)c->P->aux_bytes > 0xffffffffull))
+        r->err = B5_ERR_FORMAT;
 }
 /* phase 2 (parallel): stage record i's signal and scaling into the job's pinned buffers */
 static void load_stage(void *ctx_, uint32_t i, int tid) {
@@ -417,7 +429,9 @@ static void load_stage(void *ctx_, uint32_t i, int tid) {
     b->in.digitisation[i] = r->v.digitisation;
     b->in.offset[i] = r->v.offset;
     b->in.range[i] = r->v.range;
-    if (b->svb) {
+    if (b->zrec) {
+        memcpy(b->in.blobs + b->in.blob_offsets[i], r->raw_ptr ? r->raw_ptr : b->raw + r->raw_off, r->raw_size);
+    } else if (b->svb) {
         memcpy(b->in.blobs + b->in.blob_offsets[i], r->v.signal, r->v.signal_bytes);
     } else if (c->P->f->signal_press == 1) {
         r->err = b5_svb_zd_decode(r->v.signal, r->v.signal_bytes, b->in.samples + b->in.offsets[i], r->v.n_samples);
@@ -437,15 +451,22 @@ static void batch_launch(pipe_t *P, batch_t *b) {
             die_now();
         }
         b->lengths[i] = b->recs[i].v.n_samples;
-        b->blob_bytes[i] = (uint32_t)b->recs[i].v.signal_bytes;
+        b->blob_bytes[i] = P->zrec ? (uint32_t)b->recs[i].raw_size : (uint32_t)b->recs[i].v.signal_bytes;
+        if (P->zrec) {
+            b->sig_off[i] = b->recs[i].v.signal_offset;
+            b->sig_len[i] = (uint32_t)b->recs[i].v.signal_bytes;
+            b->room[i] = (uint32_t)(b->recs[i].v.signal_offset + b->recs[i].v.signal_bytes + (uint64_t)P->aux_bytes);
+        }
         P->n_samples += b->recs[i].v.n_samples;
     }
     P->n_reads += b->n;
     double t1 = realtime();
     P->t_parse += t1 - t0;
     b->svb = P->f->signal_press == 1 && !P->host_decode;
-    int rc = sgk_job_begin(b->job, b->n, b->lengths, b->svb ? SGK_SIGNAL_SVBZD : SGK_SIGNAL_INT16, b->blob_bytes,
-                           &b->in);
+    b->zrec = P->zrec;
+    int rc;
+    if (b->zrec) rc = sgk_job_begin_zrec(b->job, b->n, b->lengths, b->blob_bytes, b->sig_off, b->sig_len, b->room, &b->in);
+    else rc = sgk_job_begin(b->job, b->n, b->lengths, b->svb ? SGK_SIGNAL_SVBZD : SGK_SIGNAL_INT16, b->blob_bytes, &b->in);
     if (rc != SGK_OK) gpu_fail("sgk_job_begin", rc);
     pfor(P->load_pool, b->n, load_stage, &c);
     for (uint32_t i = 0; i < b->n; i++) {
@@ -732,6 +753,12 @@ static void *writer_main(void *arg) {
         if (b->last) break;
         double t0 = realtime();
         int rc = sgk_job_wait(b->job);
+        if (rc == SGK_ERR_FORMAT && b->zrec) {
+            /* a record that does not inflate (or not to what its head announced), or a blob that does not decode: what the
+             * reference reports for it (slow5_get_next's negative return, src/cmain.c:121-124) */
+            fprintf(stderr, "Error in slow5_get_next. Error code %d\n", B5_ERR_PRESS);
+            die_now();
+        }
         if (rc != SGK_OK) gpu_fail("sgk_job_wait", rc);
         P->n_long_declined += sgk_job_long_declined(b->job);
         wctx_t c;
@@ -909,7 +936,7 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
         for (int i = 0; i < P->n_created; i++) {
             sgk_job_destroy(pool[i].job);
             for (uint32_t k = 0; k < pool[i].cap; k++) free(pool[i].recs[k].scratch);
-            free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes);
+            free(pool[i].recs); free(pool[i].raw); free(pool[i].lengths); free(pool[i].blob_bytes); free(pool[i].sig_off); free(pool[i].sig_len); free(pool[i].room);
         }
         free(pool);
     }
@@ -918,11 +945,38 @@ static void run_pipeline(pipe_t *P, int n_gpus, double t_init) {
 
 /* ------------------------------------------------------------------ cmain (src/cmain.c:40-156) */
 
+/* host threads worth starting: half the online CPUs, but no more than the affinity mask or a cgroup CPU quota allow
+ * (a GPU box may show 256 CPUs and grant a job 16: 64 threads then only throttle each other -- 1e10 samples of `stat`
+ * took 3.7 s with 64 threads and 3.1 s with 16, profiles/r05_k_cli_steady_before.json) */
+static int host_thread_budget(void) {
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    int n = nc > 1 ? (int)(nc / 2) : 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && a < n) n = a;
+    }
+    FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (fp) {
+        char q[64];
+        long period = 0;
+        if (fscanf(fp, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            const int c = (int)((quota + period - 1) / period);
+            if (c > 0 && c < n) n = c;
+        }
+        fclose(fp);
+    }
+    if (n > 64) n = 64;  /* inflate scales to ~64 threads; beyond that thread start-up dominates */
+    return n < 1 ? 1 : n;
+}
+
 static struct option long_options[] = {
     {"verbose", required_argument, 0, 'v'}, {"help", no_argument, 0, 'h'},       {"version", no_argument, 0, 'V'},
     {"output", required_argument, 0, 'o'},  {"print-stat", no_argument, 0, 0},   {"no-header", no_argument, 0, 'n'},
     {"compact", no_argument, 0, 'c'},       {"gpus", required_argument, 0, 0},   {"batch-samples", required_argument, 0, 0},
-    {"threads", required_argument, 0, 't'}, {"host-decode", no_argument, 0, 0},  {0, 0, 0, 0}};
+    {"threads", required_argument, 0, 't'}, {"host-decode", no_argument, 0, 0},  {"host-inflate", no_argument, 0, 0},
+    {0, 0, 0, 0}};
 
 static int cmain(int argc, char *argv[], const char *mode_s) {
     /* `ent` has its own front end in the reference (src/ent.c:63-105): only -h/-V (and --no-header) are options,
@@ -933,7 +987,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     FILE *fp_help = stderr;
     int8_t hdr = 1;
     opt_t opt = {0, 0, 0, 0};
-    int n_gpus = 1, nthreads = 0, host_decode = 0;
+    int n_gpus = 1, nthreads = 0, host_decode = 0, host_inflate = 0, batch_set = 0;
     /* default batch: small (16 M samples) where the GPU stage is short -- a job's buffers are then cheap to set up
      * and the host stages overlap sooner; 64 M for jnn / prefix, whose one-read-per-lane kernels take as long for
      * a small batch as for a large one */
@@ -957,8 +1011,11 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
             n_gpus = atoi(optarg);
         } else if (c == 0 && longindex == 8) {
             batch_samples = strtoull(optarg, NULL, 10);
+            batch_set = 1;
         } else if (c == 0 && longindex == 10) {
             host_decode = 1;
+        } else if (c == 0 && longindex == 11) {
+            host_inflate = 1;
         }
     }
     if (is_ent && (argc - optind != 1 || fp_help == stdout)) {
@@ -978,9 +1035,10 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         fprintf(fp_help, "   -c                         compact output\n");
         fprintf(fp_help, "   --version                  print version\n");
         fprintf(fp_help, "   --gpus INT                 number of GPUs; whole batches go round-robin [1]\n");
-        fprintf(fp_help, "   --batch-samples INT        approximate raw samples per batch [16777216; jnn, prefix: 67108864]\n");
+        fprintf(fp_help, "   --batch-samples INT        approximate raw samples per batch [134217728; with --host-inflate 16777216, jnn / prefix 67108864]\n");
         fprintf(fp_help, "   -t, --threads INT          host threads for inflating records / formatting rows [auto]\n");
         fprintf(fp_help, "   --host-decode              decode svb-zd signals on the host instead of the GPU\n");
+        fprintf(fp_help, "   --host-inflate             inflate zlib records on the host threads instead of the GPU\n");
         exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
     }
 
@@ -1035,11 +1093,7 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
         WARNING("cmain", "--gpus %d requested but %d visible; using %d", n_gpus, ndev, ndev);
         n_gpus = ndev;
     }
-    if (nthreads <= 0) {
-        long nc = sysconf(_SC_NPROCESSORS_ONLN);
-        nthreads = nc > 1 ? (int)(nc / 2) : 1;
-        if (nthreads > 64) nthreads = 64;  /* inflate scales to ~64 threads; beyond that thread start-up dominates */
-    }
+    if (nthreads <= 0) nthreads = host_thread_budget();
 
     pipe_t P;
     memset(&P, 0, sizeof P);
@@ -1047,6 +1101,15 @@ static int cmain(int argc, char *argv[], const char *mode_s) {
     P.mode = mode;
     P.nthreads = nthreads;
     P.host_decode = host_decode;
+    /* Records go to the GPU as they sit in the file when they are zlib streams around an svb-zd signal and their
+     * auxiliary fields have a fixed size (the inflated length of a record then follows from its head); everything else
+     * -- and --host-inflate / --host-decode -- is inflated by the host threads as before. */
+    P.aux_bytes = b5_aux_fixed_bytes(f);
+    P.zrec = !host_inflate && !host_decode && f->record_press == 1 && f->signal_press == 1 && P.aux_bytes >= 0;
+    /* ... in batches of 128 M samples: the inflate kernel is a wavefront per record and takes ~35 ms however many records
+     * it has (up to the ~4 800 the GPU holds at once), so a batch should bring a thousand of them (1e10 samples of `stat`:
+     * 5.2 s with the 16 M-sample batches of the host path, 1.7 s with 128 M, profiles/r05_cli_steady.json) */
+    if (P.zrec && !batch_set) batch_samples = 128ull << 20;
     P.opt = opt;
     P.out_fp = stdout;
     P.limit_bytes = batch_samples;
@@ -1154,11 +1217,7 @@ static int qtsmain(int argc, char *argv[]) {
     }
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > ndev) n_gpus = ndev;
-    if (nthreads <= 0) {
-        long nc = sysconf(_SC_NPROCESSORS_ONLN);
-        nthreads = nc > 1 ? (int)(nc / 2) : 1;
-        if (nthreads > 64) nthreads = 64;
-    }
+    if (nthreads <= 0) nthreads = host_thread_budget();
     pipe_t P;
     memset(&P, 0, sizeof P);
     P.f = f;

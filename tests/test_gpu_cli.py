@@ -191,3 +191,37 @@ def test_synthetic_long_reads(cli, synth_files, name):
     assert out(cli, "prefix", "--print-stat", f) == gold(name + ".prefix_stat.tsv")
     assert hashlib.sha256(out(cli, "event", "-c", f)).hexdigest() == MANIFEST[name + ".event_c.tsv.sha256"]
 
+
+
+def test_records_inflated_on_the_gpu_and_on_the_host_give_the_same_bytes(cli, tmp_path, sp1):
+    """round 5: zlib records with an svb-zd signal go to the GPU as they sit in the file (sgk_inflate); --host-inflate
+    keeps the host threads' zlib.  Same output either way, on the reference's fixture (which carries auxiliary fields
+    behind the signal: their fixed size is read off the header) and on long synthetic reads."""
+    for tool in (["event", "-c"], ["stat"], ["jnn"], ["prefix", "--print-stat"], ["ent"], ["pa"]):
+        a = out(cli, *tool, SP1)
+        b = out(cli, *tool, "--host-inflate", SP1)
+        assert a == b, tool
+    from sigtk_amd import api
+    reads, dig, off, rng = api.synth_reads_host(40, [100000, 250, 1000, 777, 70001, 300000] + [25000] * 34, 5, 0)
+    recs = [blow5.Read("r-%04d" % i, 0, float(dig[i]), float(off[i]), float(rng[i]), 4000.0, reads[i]) for i in range(len(reads))]
+    path = str(tmp_path / "z.blow5")
+    blow5.write_blow5(path, recs, {"experiment_type": "genomic_dna", "sequencing_kit": "sqk-lsk109"})
+    for tool in (["event", "-c"], ["stat"], ["prefix"]):
+        assert out(cli, *tool, path) == out(cli, *tool, "--host-inflate", path), tool
+        assert out(cli, *tool, "--batch-samples", "200000", path) == out(cli, *tool, "--host-inflate", path), tool
+
+
+def test_a_record_that_does_not_inflate_fails_like_a_read_error(cli, tmp_path, sp1):
+    """a flipped byte inside a record's zlib stream: the GPU inflate flags it (bad code / check value) and the CLI
+    fails as the reference does on a slow5_get_next error"""
+    data = bytearray(open(SP1, "rb").read())
+    import struct
+    (hsize,) = struct.unpack_from("<I", data, 64)
+    pos = 68 + hsize
+    (size,) = struct.unpack_from("<Q", data, pos)
+    data[pos + 8 + size // 2] ^= 0x10          # the middle of the first record
+    path = str(tmp_path / "bad.blow5")
+    open(path, "wb").write(bytes(data))
+    for extra in ([], ["--host-inflate"]):
+        p = subprocess.run([cli, "stat", *extra, path], capture_output=True)
+        assert p.returncode != 0 and b"slow5_get_next" in p.stderr, (extra, p.stderr[-300:])
