@@ -113,6 +113,7 @@ def main():
     S = batch.total_samples
     arena = device.EventArena(batch) if args.config in (2, 3, 5) else None
     pa_out = torch.empty(batch.n_samples, dtype=torch.float32, device=dev) if args.config in (4, 5) else None
+    stat_out = torch.zeros(max(batch.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=dev) if args.config == 5 else None
 
     inflight = max(1, args.inflight) if args.config == 2 else 1
     lanes = [(torch.cuda.Stream(device=dev), device.EventArena(batch)) for _ in range(inflight - 1)]
@@ -137,9 +138,8 @@ def main():
         elif args.config == 4:
             device.stat_pa(batch, pa_out)
         else:
-            # pA is written once by the fused stat+pa pass; the event kernels scale on the fly
-            device.stat_pa(batch, pa_out)
-            device.event(batch, arena, rna)
+            # one call (sgk_pipeline): the fused stat + pA pass, then event on the raw samples (it scales on the fly)
+            device.pipeline(batch, arena, rna, pa_out, stat_out)
 
     def barrier():
         torch.cuda.synchronize()

@@ -286,6 +286,15 @@ int sgk_jnn_opt(const sgk_batch_t *batch, int rna, const uint64_t *seg_slots, in
                 uint32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
 int sgk_prefix_opt(const sgk_batch_t *batch, int rna, int pore, sgk_prefix_rec_t *out, void *workspace,
                    size_t workspace_bytes, void *stream, const sgk_stat_options_t *opt);
+/* ---- the pa -> event -> stat pipeline over one batch (BASELINE config 5; src/cfunc.c:72-83, 85-102, 126-159) -------- */
+/* One call for what `pa`, `event` and `stat` print of the same reads: pa_out as sgk_pa, events as sgk_event_opt, stat_out as
+ * sgk_stat_opt -- the fused stat + pA pass, then event on the raw samples; workspaces as for sgk_event_opt and
+ * sgk_stat_pa_opt.  0.2.2. */
+int sgk_pipeline(const sgk_batch_t *batch, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
+                 float *pa_out, sgk_stat_rec_t *stat_out, void *event_workspace, size_t event_workspace_bytes,
+                 void *stat_workspace, size_t stat_workspace_bytes, void *stream, const sgk_event_options_t *event_opt,
+                 const sgk_stat_options_t *stat_opt);
+
 /* What the long-read path of the last stat / jnn / prefix call on `workspace` did (copied from the device: call it when
  * the stream has drained).  A long read's sequential float sums (src/stat.h:17-54, src/jnn.c:106-124, 195-199) are
  * composed from per-tile summaries; n_true_tiles of the n_tiles tile sums had to be evaluated from the true accumulator

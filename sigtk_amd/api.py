@@ -173,7 +173,7 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan", "sgk_event_plan_opt", "sgk_job_long_declined", "sgk_inflate", "sgk_job_begin_zrec",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan", "sgk_event_plan_opt", "sgk_job_long_declined", "sgk_inflate", "sgk_job_begin_zrec", "sgk_pipeline",
     "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
     "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_plan", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",
@@ -253,6 +253,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         getattr(L, f + "_opt").argtypes = getattr(L, f).argtypes + [OS]
     L.sgk_stat_long_status.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(LongStatus)]
     L.sgk_stat_plan.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, OS, C.POINTER(StatPlan)]
+    L.sgk_pipeline.argtypes = [C.POINTER(Batch), C.c_int] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, OE, OS]
     L.sgk_inflate.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 6
     L.sgk_svbzd_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]

@@ -436,6 +436,23 @@ int sgk_event_pa(const float *pa, const uint64_t *offsets, const uint32_t *lengt
                             ws_bytes, stream, nullptr);
 }
 
+// pa -> event -> stat over one resident batch (BASELINE config 5): the fused stat + pA pass (per-read statistics and the pA
+// array: two reads of the samples, one write), then event on the raw samples (it scales on the fly).
+// (Round 5 also had the event BUILDER write the pA -- it converts every sample on its walk anyway -- with stat on the lane
+// path: bit-identical, and not faster: 62.4 ms against 63.1 at 125 000 x 100 000; k_event went from 39 to 52 ms, 15.8 GB
+// of traffic per 1e9 samples make it HBM-bound where it is issue-bound without.  profiles/r05_event_experiments.md.)
+int sgk_pipeline(const sgk_batch_t *b, int rna, const uint64_t *ev_slots, sgk_event_rec_t *events, uint32_t *n_events,
+                 float *pa_out, sgk_stat_rec_t *stat_out, void *event_ws, size_t event_ws_bytes, void *stat_ws,
+                 size_t stat_ws_bytes, void *stream, const sgk_event_options_t *event_opt, const sgk_stat_options_t *stat_opt) {
+    int rc = check_batch(b);
+    if (rc != SGK_OK) return rc;
+    if (!pa_out || !stat_out) return SGK_ERR_ARG;
+    rc = sgk_stat_pa_opt(b, stat_out, pa_out, stat_ws, stat_ws_bytes, stream, stat_opt);
+    if (rc != SGK_OK) return rc;
+    return run_event(b->samples, false, b->offsets, b->lengths, b->digitisation, b->offset, b->range, b->n_reads, b->max_read_len,
+                     b->n_samples, rna, ev_slots, events, n_events, event_ws, event_ws_bytes, stream, event_opt);
+}
+
 int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
     if (!ws || !out) return SGK_ERR_ARG;
     EvHeader h;

@@ -205,6 +205,23 @@ def stat_pa(b: DeviceReads, pa_out: Optional[torch.Tensor] = None):
     return out, pa_out
 
 
+def pipeline(b: DeviceReads, arena: "EventArena", rna: int, pa_out: Optional[torch.Tensor] = None,
+             stat_out: Optional[torch.Tensor] = None):
+    """sgk_pipeline (BASELINE config 5): pa -> event -> stat over one resident batch; the event builder writes the pA.
+    -> (stat record bytes, pa tensor laid out like b.samples); events land in `arena`"""
+    L = api.load_library()
+    if stat_out is None:
+        stat_out = torch.zeros(max(b.n_reads, 1) * api.STAT_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)
+    if pa_out is None:
+        pa_out = torch.empty(b.n_samples, dtype=torch.float32, device=b.samples.device)
+    view = b.view()
+    ws = _workspace(b, "sgk_stat_workspace_bytes")
+    api.check(L.sgk_pipeline(C.byref(view), int(rna), _ptr(arena.slots), _ptr(arena.events), _ptr(arena.n_events), _ptr(pa_out),
+                             _ptr(stat_out), _ptr(arena.ws), arena.ws_bytes, _ptr(ws), ws.numel(), _stream_ptr(),
+                             C.byref(arena.opt), C.byref(api.STAT_OPTIONS)), "sgk_pipeline")
+    return stat_out, pa_out
+
+
 def prefix(b: DeviceReads, rna: int, pore: int) -> torch.Tensor:
     L = api.load_library()
     out = torch.zeros(max(b.n_reads, 1) * api.PREFIX_DTYPE.itemsize, dtype=torch.uint8, device=b.samples.device)

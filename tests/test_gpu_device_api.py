@@ -278,12 +278,16 @@ def test_baseline_config4_and_5_at_their_shard_size(gpu, oracle):
         for name, ev in (("raw_mean", e[0]), ("pa_mean", e[1]), ("raw_std", e[2]), ("pa_std", e[3]), ("pa_median", e[5])):
             assert np.float32(g[name]).view(np.uint32) == np.float32(ev).view(np.uint32), (r, name)
         assert np.array_equal(pa[o:o + N].cpu().numpy().view(np.uint32), oracle.pa(raw, d, of, rg).view(np.uint32))
-    # ---- config 5: event over the same pool
+    # ---- config 5: the pipeline over the same pool (sgk_pipeline: fused stat + pA, then event): the same 50 GB of pA
+    # (checksum) and the same records as config 4's call
+    pa.zero_()
+    arena = device.EventArena(b)
+    rec5, _ = device.pipeline(b, arena, 0, pa)
+    torch.cuda.synchronize()
+    assert cks(pa) == c1
+    assert rec5.cpu().numpy().tobytes() == rec.cpu().numpy().tobytes()
     del pa
     torch.cuda.empty_cache()
-    arena = device.EventArena(b)
-    device.event(b, arena, 0)
-    torch.cuda.synchronize()
     st = arena.status()
     nev = arena.n_events[:R].to(torch.int64)
     assert st.n_capacity_overflow == 0 and int(nev.sum().item()) == st.n_events_total
@@ -304,6 +308,49 @@ def test_baseline_config4_and_5_at_their_shard_size(gpu, oracle):
         assert g.start.size == exp.start.size and np.array_equal(g.start.astype(np.uint64), exp.start)
         assert np.array_equal(g.mean.view(np.uint32), exp.mean.view(np.uint32))
         assert np.array_equal(g.stdv.view(np.uint32), exp.stdv.view(np.uint32))
+
+
+def test_pipeline_gives_what_the_three_calls_give(gpu):
+    """sgk_pipeline: pA (bit-identical to sgk_pa), events (as sgk_event_opt), stat records (as sgk_stat_opt) from one
+    call, over a batch in which every way a read can go through `event` occurs: whole reads, reads cut into segments
+    (long; and the whole batch cut: the tail split of a small batch), packed short reads, reads the exactness guard
+    sends to the fallback kernel (a sample at 0 pA), empty and tiny reads."""
+    torch = _torch()
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    for lens, kind, opts_ in (([100000, 5000, 70001, 300, 0, 1, 2047, 2048, 2049, 33333], 0, {}),
+                              ([300001, 100000, 5000, 140000], 1, {"segment_len": 32768, "long_min": 120000}),
+                              ([5000] * 3000 + [40000, 100000], 0, {}),
+                              ([100000] * 40, 0, {"warmup": 16})):
+        b = device.synth_reads(len(lens), 0, seed=17, kind=kind, device=dev, lengths=np.asarray(lens, dtype=np.int64))
+        # one read that crosses 0 pA (guard fails -> k_event_fallback): offset = -(a sample of it)
+        if lens[0] >= 1000:
+            o0 = int(b.offsets_host[0])
+            b.off[0] = -float(int(b.samples[o0 + 500].item()))
+        gpu.event_configure(opts_.get("segment_len", 0), opts_.get("long_min", 0), opts_.get("warmup", 0))
+        try:
+            want_pa = torch.zeros(b.n_samples, dtype=torch.float32, device=dev)
+            device.pa(b, want_pa)
+            a1 = device.EventArena(b)
+            device.event(b, a1, kind)
+            want_stat = device.stat(b).cpu().numpy().tobytes()
+            a2 = device.EventArena(b)
+            got_pa = torch.full((b.n_samples,), float("nan"), dtype=torch.float32, device=dev)
+            got_stat, _ = device.pipeline(b, a2, kind, got_pa)
+            torch.cuda.synchronize()
+        finally:
+            gpu.event_configure(0, 0, 0)
+        assert a2.status().n_fallback_reads == a1.status().n_fallback_reads
+        if lens[0] >= 1000:
+            assert a1.status().n_fallback_reads >= 1
+        assert got_stat.cpu().numpy().tobytes() == want_stat
+        n1, n2 = a1.n_events.cpu().numpy(), a2.n_events.cpu().numpy()
+        assert (n1 == n2).all()
+        for r, n in enumerate(lens):
+            o = int(b.offsets_host[r])
+            assert torch.equal(got_pa[o:o + n].view(torch.int32), want_pa[o:o + n].view(torch.int32)), "read %d pA" % r
+            s0, k = int(a1.slots_host[r]), int(n1[r])
+            assert torch.equal(a1.events[s0:s0 + k], a2.events[s0:s0 + k]), "read %d events" % r
 
 
 def test_baseline_config3_at_its_size(gpu, oracle):
