@@ -312,6 +312,16 @@ typedef struct sgk_stat_plan {
 } sgk_stat_plan_t;
 int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, const sgk_stat_options_t *opt,
                   sgk_stat_plan_t *out);
+/* The table behind kernels = 0, one row per tool (0 stat, 1 jnn, 3 stat + pA, 4 the region statistics of prefix): a batch
+ * of similar read lengths takes the lane-per-read kernels iff n_reads >= min_reads and its longest read has at most
+ * min(cap, slope_x1024 * n_reads / 1024 + intercept) samples.  Returns the number of rows; fills at most cap of them.
+ * (0.2.2; the guard test times both implementations either side of that line.) */
+typedef struct sgk_stat_lane_rule {
+    uint32_t tool, min_reads, slope_x1024;
+    int32_t intercept;
+    uint32_t cap, reserved;
+} sgk_stat_lane_rule_t;
+int sgk_stat_lane_rules(sgk_stat_lane_rule_t *out, int cap);
 typedef struct sgk_long_status {
     uint32_t n_long_reads, n_tiles, n_true_tiles;
     uint32_t n_timeouts;  /* long reads DECLINED by the long path: a workgroup of the read gave up at a barrier (after

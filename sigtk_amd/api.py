@@ -68,6 +68,11 @@ class StatPlan(C.Structure):      # sgk_stat_plan_t
                 ("reserved", C.c_uint32), ("workspace_bytes", C.c_uint64)]
 
 
+class StatLaneRule(C.Structure):  # sgk_stat_lane_rule_t
+    _fields_ = [("tool", C.c_uint32), ("min_reads", C.c_uint32), ("slope_x1024", C.c_uint32), ("intercept", C.c_int32),
+                ("cap", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class LongStatus(C.Structure):    # sgk_long_status_t
     _fields_ = [("n_long_reads", C.c_uint32), ("n_tiles", C.c_uint32), ("n_true_tiles", C.c_uint32),
                 ("n_timeouts", C.c_uint32)]
@@ -89,6 +94,19 @@ EVENT_OPTIONS = EventOptions(_env_int("SGK_EVENT_SEG"), _env_int("SGK_EVENT_LONG
                              _env_int("SGK_EVENT_MULTI"), _env_int("SGK_EVENT_MULTI_MAX"),
                              {"0": -1, "1": 0}.get(os.environ.get("SGK_EVENT_TAIL", "1"), _env_int("SGK_EVENT_TAIL")))
 STAT_OPTIONS = StatOptions({"1": 1, "0": 2}.get(os.environ.get("SGK_LANE_PER_READ", ""), 0), _env_int("SGK_STAT_LONG_MIN"))
+
+
+def stat_lane_rules():
+    """the table behind sgk_stat_options_t::kernels = 0 (sgk_stat_lane_rules) -> list of (tool, min_reads, max_len(n_reads))"""
+    L = load_library()
+    out = (StatLaneRule * 32)()
+    n = L.sgk_stat_lane_rules(out, 32)
+    rows = []
+    for k in range(n):
+        q = out[k]
+        s_, i_, c_ = int(q.slope_x1024), int(q.intercept), int(q.cap)
+        rows.append((int(q.tool), int(q.min_reads), (lambda nr, s_=s_, i_=i_, c_=c_: max(0, min(c_, s_ * nr // 1024 + i_)))))
+    return rows
 
 
 def event_configure(segment_len: int = 0, long_min: int = 0, warmup: int = 0) -> None:
@@ -173,7 +191,7 @@ PREFIX_DTYPE = np.dtype([("adapt_x", "<i4"), ("adapt_y", "<i4"), ("polya_x", "<i
 #: every symbol include/sigtk_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sgk_strerror", "sgk_version", "sgk_last_hip_error", "sgk_device_count", "sgk_set_device",
-    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan", "sgk_event_plan_opt", "sgk_job_long_declined", "sgk_inflate", "sgk_job_begin_zrec", "sgk_pipeline",
+    "sgk_pa", "sgk_event_workspace_bytes", "sgk_event", "sgk_event_pa", "sgk_event_status", "sgk_event_plan", "sgk_event_plan_opt", "sgk_job_long_declined", "sgk_inflate", "sgk_job_begin_zrec", "sgk_pipeline", "sgk_stat_lane_rules",
     "sgk_event_workspace_bytes_opt", "sgk_event_opt", "sgk_event_pa_opt", "sgk_event_host_opt",
     "sgk_stat_workspace_bytes", "sgk_stat", "sgk_stat_pa", "sgk_jnn_workspace_bytes", "sgk_jnn",
     "sgk_prefix_workspace_bytes", "sgk_prefix", "sgk_stat_opt", "sgk_stat_long_status", "sgk_stat_plan", "sgk_stat_pa_opt", "sgk_jnn_opt", "sgk_prefix_opt",

@@ -131,6 +131,18 @@ int sgk_stat_plan(int tool, uint32_t n_reads, uint64_t n_samples, uint32_t max_r
     return SGK_OK;
 }
 
+int sgk_stat_lane_rules(sgk_stat_lane_rule_t *out, int cap) {
+    for (int k = 0; k < N_LANE_RULES && k < cap && out; ++k) {
+        out[k].tool = (uint32_t)LANE_RULES[k].tool;
+        out[k].min_reads = LANE_RULES[k].min_reads;
+        out[k].slope_x1024 = LANE_RULES[k].slope_x1024;
+        out[k].intercept = LANE_RULES[k].intercept;
+        out[k].cap = LANE_RULES[k].cap;
+        out[k].reserved = 0;
+    }
+    return N_LANE_RULES;
+}
+
 int sgk_stat_long_status(const void *ws, size_t ws_bytes, uint32_t n_reads, sgk_long_status_t *out) {
     if (!out) return SGK_ERR_ARG;
     memset(out, 0, sizeof *out);

@@ -80,7 +80,41 @@ size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
 // the threshold a call uses: the option if positive, else max(LC_LONG_MIN, n_samples / auto_div)
 uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, uint32_t auto_div);
 constexpr uint32_t LC_AUTO_DIV_STAT = 2048, LC_AUTO_DIV_JNN = 3072, LC_AUTO_DIV_PREFIX = 2048;
-// which implementation a batch takes (sgk_stat_options_t::kernels)
+// Which of the two implementations a batch of SIMILAR read lengths (the longest at most 1.5 x the mean) takes when the
+// caller leaves the choice to the library.  The lane-per-read kernels have 64 reads per wavefront and none of the wave
+// kernels' per-read costs, so they win where there are MANY reads for their length; measured over a grid of batch shapes
+// (profiles/r05_lane_vs_wave_sweep.jsonl: 120 shapes, both implementations of every tool) the line on which the two
+// cost the same is close to straight in (reads, samples per read).  One row per tool:
+//     one read per lane  iff  n_reads >= min_reads  and  max_read_len <= min(cap, slope_x1024 * n_reads / 1024 + intercept)
+// (min_reads: where that line reaches ~500 samples -- below it a batch is a few microseconds either way)
+// One table: sgk_stat_plan, the launchers and the guard test (tests/test_gpu_stat.py::test_each_cut_of_the_choice_is_no_cliff,
+// which times both implementations either side of the line at several batch sizes) read the same numbers.
+// Tool: 0 stat, 1 jnn, 2 prefix' finders (no row: the wave finders win at every shape), 3 stat + pA, 4 the statistics of
+// the regions prefix finds.  (Round 4 had five hand-placed steps instead; the guard test's first run found a batch
+// 64 reads under one of them on the 30 % slower implementation.)
+struct LaneRule {
+    int tool;
+    uint32_t min_reads;
+    uint32_t slope_x1024;   // samples per read, per read of the batch, x 1024
+    int32_t intercept;
+    uint32_t cap;
+};
+constexpr LaneRule LANE_RULES[] = {
+    {0, 1024u, 0u, 2048, 2048u},             // stat: tiny reads (the wave kernels' per-read costs: native heads, tile set-up) from 1 024 reads on
+    {0, 5248u, 1178u, -5500, 131072u},       // stat: 16 384 reads of up to 13 300 samples, 32 768 of 32 200, 65 536 of 69 800
+    {0, 81920u, 0u, 131072, 131072u},        // ... and from 81 920 reads on, where the medians come out of k_moments' second pass
+                                             // (a real step in that implementation: 82 000 x 100 000 8.0 against 9.2 ms), up to 131 072
+    {3, 2048u, 768u, -1000, 49152u},         // stat + pA (the wave kernel's fused pass carries the pA stores better)
+    {1, 4096u, 133u, 0, 15000u},             // jnn: 65 536 reads of up to 8 500 samples
+    {4, 49152u, 0u, 0x7fffffff, 0x7fffffffu},  // prefix: the statistics of the (short) regions the finders return, whatever the reads' length
+};
+constexpr int N_LANE_RULES = (int)(sizeof(LANE_RULES) / sizeof(LANE_RULES[0]));
+constexpr uint32_t STAT_MOMENTS_MEDIAN_MIN_READS = LANE_RULES[2].min_reads;   // lane path of plain stat: from here on the medians come out of k_moments' second pass
+static_assert(LANE_RULES[2].tool == 0 && LANE_RULES[2].slope_x1024 == 0u && LANE_RULES[2].min_reads == 81920u, "the step row of plain stat");
+inline uint32_t lane_rule_max_len(const LaneRule &q, uint32_t n_reads) {
+    const long long v = (long long)q.slope_x1024 * n_reads / 1024 + q.intercept;
+    return v <= 0 ? 0u : (v > (long long)q.cap ? q.cap : (uint32_t)v);
+}
 bool stat_lane_per_read(int tool /* 0 stat, 1 jnn, 2 prefix, 3 stat + pA */, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
 // clears the header and lists the long reads; auto_div: long_min = max(262 144, n_samples / auto_div) when the option is 0

@@ -2841,14 +2841,12 @@ int prepare_order(StatArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
 bool stat_lane_per_read(int tool, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len) {
     if (kernels == 1) return true;
     if (kernels == 2) return false;
-    if ((uint64_t)max_read_len * n_reads > n_samples + n_samples / 2) return false;  // not of similar length
-    // (plain stat on very large batches as well, where the median comes out of k_moments' second pass: 82 000 x 100 000
-    // 8.0 against 9.2 ms, 125 000 x 100 000 10.0 against 14.1, 250 000 x 50 000 10.5 against 16.2; with the pA output --
-    // tool 3 -- the wave kernel's fused pass stays ahead there: 22.9 against 24.6)
-    if (tool == 0 && n_reads >= 81920u && max_read_len <= 131072u) return true;
-    if (tool == 0 || tool == 3) return (n_reads >= 49152u && max_read_len <= 32768u) || (n_reads >= 16384u && max_read_len <= 16384u);
-    if (tool == 2) return false;  // (prefix: the wave finders win at every shape; its region statistics: launch_prefix)
-    return n_reads >= 65536u && max_read_len <= 12288u;
+    if (tool != 4 && (uint64_t)max_read_len * n_reads > n_samples + n_samples / 2) return false;  // not of similar length
+    for (int k = 0; k < N_LANE_RULES; ++k) {
+        const LaneRule &q = LANE_RULES[k];
+        if (q.tool == tool && n_reads >= q.min_reads && max_read_len <= lane_rule_max_len(q, n_reads)) return true;
+    }
+    return false;   // (prefix' finders, tool 2: the wave kernels win at every shape)
 }
 static bool lane_per_read(int tool, const StatArgs &a) {
     return stat_lane_per_read(tool, a.kernels, a.b.n_reads, a.b.n_samples, a.b.max_read_len);
@@ -2902,7 +2900,7 @@ int launch_stat(const StatArgs &a, hipStream_t st) {
             SGK_LAUNCH("k_moments", (k_moments<REG_WHOLE>), (nr + 63) / 64, 64, a);
             SGK_HIP_TRY(hipGetLastError());
             SGK_LAUNCH("k_median_pa", (k_median<REG_WHOLE, true>), nr, 256, a);
-        } else if (nr >= 81920u) {
+        } else if (nr >= STAT_MOMENTS_MEDIAN_MIN_READS) {
             // the medians come out of the moments' second pass; k_median only for the reads it flagged.  (With fewer reads
             // k_moments has too few wavefronts -- 64 reads each -- to hide what the counting adds, and k_median, a
             // workgroup per read, fills the GPU: 61 035 x 32 768 fused 2.70, apart 2.33 ms; 100 000 x 20 000 2.00 / 2.24.)
@@ -2990,7 +2988,7 @@ int launch_prefix(const StatArgs &a, int rna, int pore, hipStream_t st) {
     // reads to fill the lanes (64 per wavefront) the lane kernels do them in 1.0 ms where k_stat_wave takes 2.4 (400 000 x
     // 5 000), 0.9 + 1.2 against 1.1 + 1.4 (50 000 x 100 000 RNA, adaptor + polyA), a tie at 125 000 x 100 000.
     const bool lanes = lane_per_read(2, a);
-    const bool lane_regions = lanes || (a.kernels == 0 && nr >= 49152u);
+    const bool lane_regions = lanes || lane_per_read(4, a);
     if (lanes) SGK_LAUNCH("k_adaptor", k_adaptor, gw, 64, a, adaptor_preset(pore));
     else {
         // (joined inside: the kernels behind read every read's adapt_x / adapt_y)

@@ -71,9 +71,28 @@ def main():
             for r in bad[:3]:
                 stats["mismatches"].append("%s %s read %d len %d: default %r wave %r" % (tag, what, r, lens[r], x[r], y[r]))
                 print("MISMATCH", stats["mismatches"][-1], flush=True)
+        # the ORACLE on 50 reads of the batch, the hostile ones first (the default's records at the size the choice is made at)
+        from oracle.oracle import Oracle
+        orc = stats.setdefault("_oracle", Oracle())
+        got = np.frombuffer(out[0][0].tobytes(), dtype=api.STAT_DTYPE)[:n]
+        dig_h, off_h = b.dig.cpu().numpy(), b.off.cpu().numpy()
+        for r in [int(x) for x in hostile[:30]] + [int(x) for x in rs.randint(0, n, size=20)]:
+            m = int(lens[r])
+            if m == 0:
+                continue
+            o = int(b.offsets_host[r])
+            e = orc.stat(host[o:o + m], dig_h[r], off_h[r], rng[r])
+            g = got[r]
+            ok = int(g["raw_median"]) == e[4] and all(np.float32(g[k]).view(np.uint32) == np.float32(v).view(np.uint32) for k, v in
+                                                      (("raw_mean", e[0]), ("pa_mean", e[1]), ("raw_std", e[2]), ("pa_std", e[3]), ("pa_median", e[5])))
+            stats["oracle_checked"] = stats.get("oracle_checked", 0) + 1
+            if not ok:
+                stats["mismatches"].append("%s stat read %d len %d against the oracle: %r vs %r" % (tag, r, m, g, e))
+                print("MISMATCH", stats["mismatches"][-1], flush=True)
         stats["batches"] += 1
         stats["reads"] += n
         stats["samples"] += int(lens.sum())
+    stats.pop("_oracle", None)
     print(json.dumps(stats))
     sys.exit(1 if stats["mismatches"] else 0)
 

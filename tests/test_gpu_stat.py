@@ -343,10 +343,12 @@ def test_stat_negative_raw_sum_is_exact_and_not_slow(gpu, oracle):
 
 
 @pytest.mark.parametrize("kind", [0, 1])
-def test_large_batch_choices_match_the_wave_kernels(gpu, kind):
+def test_large_batch_choices_match_the_wave_kernels(gpu, oracle, kind):
     """what kernels = 0 picks for a large batch (stat: one read per lane with the median out of k_moments' second pass;
     prefix: the wave finders + the lane kernels for the region statistics, medians likewise) against the wave kernels
-    alone, record for record; reads that defeat the 32-value median window (constant, two-valued, wide) included"""
+    alone, record for record; reads that defeat the 32-value median window (constant, two-valued, wide) included --
+    and against the ORACLE on 64 of the reads, the hostile ones first (VERDICT r04 task 8a: the default for >= 81 920
+    reads was only compared GPU against GPU at that size)"""
     import torch
     from sigtk_amd import device
     rs = np.random.RandomState(17 + kind)
@@ -359,7 +361,8 @@ def test_large_batch_choices_match_the_wave_kernels(gpu, kind):
     rng[rs.randint(0, n, size=2000)] *= -1.0                              # negative unit: the pA median mirrors the raw ranks
     b.rng.copy_(torch.from_numpy(rng).to(dev))
     host = b.samples.cpu().numpy().copy()
-    for r in rs.randint(0, n, size=400):
+    hostile = [int(r) for r in rs.randint(0, n, size=400)]
+    for r in hostile:
         o, m = int(b.offsets_host[r]), int(lens[r])
         u = rs.rand()
         if m == 0: continue
@@ -380,3 +383,66 @@ def test_large_batch_choices_match_the_wave_kernels(gpu, kind):
     assert gpu.stat_plan("stat", n, int(lens.sum()), int(lens.max())).kernels == 1
     assert out[0][0].tobytes() == out[2][0].tobytes()
     assert out[0][1].tobytes() == out[2][1].tobytes()
+    # the oracle at the size the choice is made at: 44 hostile reads + 20 others
+    pick = hostile[:44] + [int(r) for r in rs.randint(0, n, size=20)]
+    got = np.frombuffer(out[0][0].tobytes(), dtype=gpu.STAT_DTYPE)[:n]
+    dig, off = b.dig.cpu().numpy(), b.off.cpu().numpy()
+    reads = [host[int(b.offsets_host[r]):int(b.offsets_host[r]) + int(lens[r])] for r in pick]
+    _check_stat(oracle, [x for x in reads if x.size], [dig[r] for r in pick if lens[r]], [off[r] for r in pick if lens[r]],
+                [rng[r] for r in pick if lens[r]], [got[r] for r in pick if lens[r]])
+
+
+def test_each_cut_of_the_choice_is_no_cliff(gpu):
+    """VERDICT r04 task 8b/c: kernels = 0 chooses between two implementations by ONE table (sgk_stat_lane_rules =
+    LANE_RULES in csrc/stat_args.h, the numbers sgk_stat_plan and the launchers read): a line in (reads, samples per
+    read) per tool.  Either side of that line -- 8 % under and over it at several batch sizes, and 64 reads under / at
+    min_reads -- both implementations are timed and the one the library picks may be at most 1.12 x the other (+ 50 us:
+    batches of a few thousand tiny reads are a tenth of a millisecond either way).
+    A line that drifts with a kernel change shows up here instead of as a cliff in somebody's batch.  (Its first run, on
+    round 4's five hand-placed steps, found stat at 49 088 x 32 768 on the 30 % slower implementation.)"""
+    import torch
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    names = {0: "stat", 1: "jnn", 3: "stat_pa"}
+    pa_buf = torch.empty(int(7e9), dtype=torch.float32, device=dev)
+
+    def timed(fn, kernels):
+        gpu.stat_configure(kernels)
+        try:
+            fn(); fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+        finally:
+            gpu.stat_configure(0)
+
+    report = []
+    for tool, min_reads, max_len in gpu.stat_lane_rules():
+        if tool not in names:
+            continue     # (tool 4, the region statistics inside prefix, has no kernels switch of its own)
+        shapes = [(min_reads - 64, max(512, max_len(min_reads) // 2)), (min_reads, max(512, max_len(min_reads) // 2))]
+        for n in (min_reads, 2 * min_reads, 4 * min_reads, 8 * min_reads):
+            line = max_len(n)
+            if line * 1.08 * n > 6.5e9 or line < 1024:
+                continue
+            shapes += [(n, int(line * 0.92) // 64 * 64), (n, int(line * 1.08) // 64 * 64 + 64)]
+        for n_reads, length in shapes:
+            b = device.synth_reads(n_reads, length, seed=5, kind=0, device=dev)
+            if tool == 0: fn = lambda: device.stat(b)
+            elif tool == 3: fn = lambda: device.stat_pa(b, pa_buf[:b.n_samples])
+            else:
+                ar = device.SegArena(b)
+                fn = lambda: device.jnn(b, ar, 0)
+            tl, tw = timed(fn, 1), timed(fn, 2)
+            picked = gpu.stat_plan(names[tool], n_reads, b.total_samples, length).kernels
+            t_pick, t_other = (tl, tw) if picked == 1 else (tw, tl)
+            report.append((names[tool], n_reads, length, round(tl, 3), round(tw, 3), picked))
+            assert t_pick <= 1.12 * t_other + 0.05, report[-1]
+            del b
+            torch.cuda.empty_cache()
+    print(report)

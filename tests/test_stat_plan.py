@@ -23,15 +23,25 @@ def test_uniform_batches_have_no_long_reads_and_take_the_wave_kernels():
 def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 400000, 5000).kernels == 1
     assert plan("stat", 400000, 5000, kernels=2).kernels == 2
-    assert plan("stat", 40000, 5000).kernels == 1            # >= 16 384 reads of up to 16 384 samples
-    assert plan("stat", 40000, 20000).kernels == 2           # ... longer reads need 49 152
-    assert plan("stat", 10000, 5000).kernels == 2
-    assert plan("stat", 100000, 20000).kernels == 1          # stat: up to 32 768 samples
-    assert plan("stat", 80000, 40000).kernels == 2
-    assert plan("stat_pa", 100000, 40000).kernels == 2
+    # round 5: one line per tool in (reads, samples per read) -- stat: max_read_len <= 1.15 n_reads - 5 500 from 8 192 reads
+    # on (LANE_RULES, csrc/stat_args.h; the sweep behind it: profiles/r05_lane_vs_wave_sweep.jsonl)
+    assert plan("stat", 40000, 5000).kernels == 1
+    assert plan("stat", 40000, 20000).kernels == 1           # (32 768 x 16 384: 0.76 of the wave kernels' time)
+    assert plan("stat", 40000, 60000).kernels == 2
+    assert plan("stat", 10000, 5000).kernels == 1
+    assert plan("stat", 10000, 9000).kernels == 2
+    assert plan("stat", 5000, 2000).kernels == 2             # under 5 248 reads the wave kernels
+    assert plan("stat", 100000, 20000).kernels == 1
+    assert plan("stat", 80000, 40000).kernels == 1           # (81 920 x 49 152: 0.76)
+    assert plan("stat", 60000, 80000).kernels == 2
+    assert plan("stat_pa", 100000, 40000).kernels == 1       # stat + pA: <= 0.75 n_reads - 1 000, at most 49 152
+    assert plan("stat_pa", 100000, 60000).kernels == 2
     assert plan("stat", 400000, 5000, longest=16000).kernels == 2   # not of similar length: the longest is 3.2 x the mean
-    assert plan("jnn", 400000, 5000).kernels == 1            # jnn: >= 65 536 reads of up to 12 288 samples
-    assert plan("jnn", 60000, 5000).kernels == 2
+    assert plan("jnn", 400000, 5000).kernels == 1            # jnn: from 16 384 reads on, <= 0.13 n_reads, at most 15 000
+    assert plan("jnn", 60000, 5000).kernels == 1             # (49 152 x 4 096: 0.64)
+    assert plan("jnn", 60000, 9000).kernels == 2
+    assert plan("jnn", 10000, 1000).kernels == 1
+    assert plan("jnn", 3000, 300).kernels == 2
     assert plan("jnn", 100000, 16384).kernels == 2
     assert plan("prefix", 400000, 5000).kernels == 2         # prefix: the wave finders at every shape
     assert plan("prefix", 400000, 5000, kernels=1).kernels == 1
