@@ -311,7 +311,7 @@ __device__ __attribute__((noinline)) void detect_pass(const ReadCtx<T> &rc, int 
 
 // ================================================================ fast detector pass (round 2: "LazyPass")
 // Same semantics as detect_pass, restructured around what the instruction stream costs on gfx950
-// (tools/valu_rate.hip, profiles/r02_valu_rate.txt: plain f32 add/mul/fma, logic and int add issue in 2.3 cycles per
+// (tools/valu_rate.hip, profiles/archive/r02_valu_rate.txt: plain f32 add/mul/fma, logic and int add issue in 2.3 cycles per
 // wave64 instruction; everything f64, conversions, v_cmp, v_cndmask, v_max/min and packed f32 take 4.45):
 //  * window sums are differences of a RUNNING double prefix sum kept in a register ring (P(i) .. P(i+W2+1)): one
 //    conversion and one addition per sample for the sums and for the float squares, one subtraction per window;
@@ -1904,7 +1904,7 @@ __device__ __forceinline__ void seg_span(uint32_t seg_len, uint32_t g, int64_t n
 //    3.26 rounds of work took the time of 3.75).  The reads of that round are cut into split_seg-sample segments -- as
 //    many units as fill a round, each a fraction of a read long -- and run FIRST; every other read keeps the fused
 //    detector + builder of its own wave (cutting every read costs more than the balance returns: the builder of a
-//    cut read is a kernel of its own, profiles/r04_event_experiments.md).
+//    cut read is a kernel of its own, profiles/archive/r04_event_experiments.md).
 __device__ __forceinline__ uint32_t seg_len_of(const EvArgs &a, uint32_t pos, uint32_t n) {
     if (a.max_segs == 0) return 0u;
     if (n >= a.long_min) return a.seg_len;

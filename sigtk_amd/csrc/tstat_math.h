@@ -179,7 +179,7 @@ SGK_TM void sgk_tstat_try_pair(double A1, double A1q, double B1, double B1q, dou
 }
 
 // ================================================================ round-2 forms (event_kernels.hip: LazyPass)
-// Measured issue costs on gfx950 (tools/valu_rate.hip, profiles/r02_valu_rate.txt): plain f32 add/sub/mul/fma,
+// Measured issue costs on gfx950 (tools/valu_rate.hip, profiles/archive/r02_valu_rate.txt): plain f32 add/sub/mul/fma,
 // logic and int add run at 2.3 cycles per wave64 instruction; everything f64, every conversion, v_cmp, v_cndmask,
 // v_max/min and the packed f32 forms take 4.45; v_rsq_f32 8.5; v_rsq_f64 16.2.  The forms below keep the f64 work to
 // what exactness needs (window sums, the two constant divisions of the A side, the three-term accumulation) and do

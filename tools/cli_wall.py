@@ -2,7 +2,7 @@
 """CLI wall times on the GPU box: every subtool RUNS times over one synthetic BLOW5 (default 4 000 x 100 000-sample DNA
 reads, 4e8 samples), median / min / max of the wall and of the stages the CLI reports (SGK_CLI_TIMING=1); the reference
 binary once per subtool beside it (byte-compare of stdout).  One committed number per subtool = the median.
-    python tools/cli_wall.py [--reads 4000] [--runs 9] > profiles/r04_cli_wall.json"""
+    python tools/cli_wall.py [--reads 4000] [--runs 9] > profiles/<round>_cli_wall.json"""
 import argparse
 import json
 import os

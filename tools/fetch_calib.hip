@@ -7,7 +7,7 @@
 //                          64 different lines, each line is consumed over 4 steps (the detector's sample prefetch)
 // Run:  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./fetch_calib   (and a second pass
 // with --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum); the program prints the true byte count of every kernel.
-// tools/pmc_kernels.py summarises the counters; profiles/r03_fetch_calibration.json keeps the factors.
+// tools/pmc_kernels.py summarises the counters; profiles/archive/r03_fetch_calibration.json keeps the factors.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -56,7 +56,7 @@ def main():
     rd_raw = sum(v["FETCH_SIZE_KiB"] for v in raw.values()) * 1024
     wr = sum(v["WRITE_SIZE_KiB"] for v in raw.values()) * 1024
     # FETCH_SIZE tallies every 128-byte fabric request at 64 bytes, whatever the shape of the access
-    # (tools/fetch_calib.hip, profiles/r03_fetch_calibration.json: coalesced 16 / 32 / 64 bytes per lane, and 32 bytes
+    # (tools/fetch_calib.hip, profiles/archive/r03_fetch_calibration.json: coalesced 16 / 32 / 64 bytes per lane, and 32 bytes
     # per lane with every lane on its own stream as in the detector -- the request count changes with the shape, the
     # bytes per request do not): the bytes that crossed the fabric are 2 x the counter.  Nothing is priced.
     rd = 2 * rd_raw
@@ -70,7 +70,7 @@ def main():
                     "collected in separate passes (tools/refresh_profiles.sh + tools/pmc_summary.py; mean over the "
                     "dispatches of the run).  Counter unit is KiB.  FETCH_SIZE tallies 128-byte requests at 64 bytes "
                     "(MI355X_MICROARCH.md, HBM); calibrated for this kernel's access shapes by tools/fetch_calib.hip "
-                    "(profiles/r03_fetch_calibration.json): the factor is 2 for all of them, so read bytes = 2 x the "
+                    "(profiles/archive/r03_fetch_calibration.json): the factor is 2 for all of them, so read bytes = 2 x the "
                     "counter -- measured, not priced.  WRITE_SIZE is exact for wide stores.",
         "recorded_for": {"commit": commit, "source": tag, "kernel": main_k},
         "raw": raw,
