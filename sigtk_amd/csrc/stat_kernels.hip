@@ -538,6 +538,9 @@ __device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
 constexpr int WH_BINS = 2048;
 static_assert(WH_BINS == (int)LC_HIST_BINS, "the long reads' histograms in the workspace");
 
+#ifndef SGK_WT_NT
+#define SGK_WT_NT 0  // 1: the tile loads of the streaming passes carry the non-temporal hint (development, round 5)
+#endif
 struct WaveTile {
     uint32_t w[SS_SPL / 2];
     template <int E>
@@ -557,8 +560,14 @@ __device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int
     const char *tb = reinterpret_cast<const char *>(samples + t0);
     const uint32_t lo = (uint32_t)lane_id() * (uint32_t)(SS_SPL * sizeof(int16_t));
     const uint32_t o0 = lo < room ? lo : room, o1 = lo + 16u < room ? lo + 16u : room;
+#if SGK_WT_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 q0 = __builtin_nontemporal_load(static_cast<const u32x4 *>(__builtin_assume_aligned(tb + o0, 16)));
+    const u32x4 q1 = __builtin_nontemporal_load(static_cast<const u32x4 *>(__builtin_assume_aligned(tb + o1, 16)));
+#else
     const uint4 q0 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o0, 16));
     const uint4 q1 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o1, 16));
+#endif
     t.w[0] = q0.x; t.w[1] = q0.y; t.w[2] = q0.z; t.w[3] = q0.w;
     t.w[4] = q1.x; t.w[5] = q1.y; t.w[6] = q1.z; t.w[7] = q1.w;
 }
@@ -730,6 +739,39 @@ __device__ __forceinline__ void pa_write_tile(const WaveRead &wr, int t, const S
         }
     }
 }
+// The same from the tile the wave already holds (round 5): the re-read above missed the L2 on 60 % of its lines at
+// 125 000 x 100 000 (15 of 65 GB fetched; the 50 GB of pA stores go through the same L2), so the wave turns its tile into
+// the stores' layout through 2 KB of LDS instead -- `tl`, the wave's histogram, which pass 1 does not use yet.
+__device__ __forceinline__ void pa_write_tile_lds(const WaveRead &wr, int t, const Scale &sc, float *pa_dst, const WaveTile &cur,
+                                                  uint32_t *tl) {
+    const int lane = lane_id();
+    int q_lo, q_hi;
+    wr.range(t, 0, q_lo, q_hi);
+    const bool pa_interior = q_lo == 0 && q_hi == SS_TILE;
+    uint4 *row = reinterpret_cast<uint4 *>(tl) + lane * 2;
+    row[0] = make_uint4(cur.w[0], cur.w[1], cur.w[2], cur.w[3]);
+    row[1] = make_uint4(cur.w[4], cur.w[5], cur.w[6], cur.w[7]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int sub = 0; sub < SS_TILE / 256; ++sub) {
+        const int qs = sub * 256 + lane * 4;
+        const uint2 rw = *reinterpret_cast<const uint2 *>(tl + sub * 128 + lane * 2);
+        const float4 o = make_float4(to_pa((int16_t)(rw.x & 0xffffu), sc), to_pa((int16_t)(rw.x >> 16), sc),
+                                     to_pa((int16_t)(rw.y & 0xffffu), sc), to_pa((int16_t)(rw.y >> 16), sc));
+        float *dst = pa_dst + (int64_t)t * SS_TILE + qs;
+        if (pa_interior || (qs >= q_lo && qs + 4 <= q_hi)) *reinterpret_cast<float4 *>(dst) = o;
+        else {
+            if (qs >= q_lo && qs < q_hi) dst[0] = o.x;
+            if (qs + 1 >= q_lo && qs + 1 < q_hi) dst[1] = o.y;
+            if (qs + 2 >= q_lo && qs + 2 < q_hi) dst[2] = o.z;
+            if (qs + 3 >= q_lo && qs + 3 < q_hi) dst[3] = o.w;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's rows are written behind these reads
+    __builtin_amdgcn_wave_barrier();
+}
 // the histogram window of a read: WH_BINS raw values around its mean
 __device__ __forceinline__ int hist_window_lo(float mraw) {
     const int c = (mraw == mraw) ? (int)fminf(fmaxf(mraw, -32768.0f), 32767.0f) : 0;
@@ -809,7 +851,7 @@ __device__ inline void stat_finish(const StatArgs &a, uint32_t r, const Region &
 #endif
 template <int MODE, bool PA>
 __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
-    __shared__ uint32_t hist_all[4][WH_BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][WH_BINS];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t widx = blockIdx.x * 4 + wv;  // wave-uniform, and known to be: everything derived from it is scalar
     uint32_t r;
@@ -850,7 +892,7 @@ __global__ __launch_bounds__(256, SGK_STAT_WAVES) void k_stat_wave(StatArgs a) {
         for (int t = 0; t < wr.ntiles; ++t) {
             if (t + 1 < wr.ntiles) wr.load(nxt, t + 1);
             const Scale so = {sc.offf, sc.unit * sg};
-            if (PA) pa_write_tile(wr, t, sc, pa_dst);
+            if (PA) pa_write_tile_lds(wr, t, sc, pa_dst, cur, hist);
             ss_tile2<true>(
                 m_raw, m_pa, wr, cur, t, [&](auto b) { return TermRaw<decltype(b)::interior>{b, sraw}; },
                 [&](auto b) { return TermPa<decltype(b)::interior>{b, so}; }, SS_CNT(0), SS_CNT(1));
