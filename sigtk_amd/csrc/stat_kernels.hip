@@ -538,9 +538,6 @@ __device__ __forceinline__ s16x2 clamp_raw2(uint32_t w) {
 constexpr int WH_BINS = 2048;
 static_assert(WH_BINS == (int)LC_HIST_BINS, "the long reads' histograms in the workspace");
 
-#ifndef SGK_WT_NT
-#define SGK_WT_NT 0  // 1: the tile loads of the streaming passes carry the non-temporal hint (development, round 5)
-#endif
 struct WaveTile {
     uint32_t w[SS_SPL / 2];
     template <int E>
@@ -550,8 +547,11 @@ struct WaveTile {
 };
 // This lane's 16 samples of the tile that starts at base-relative index `tile0` (wave-uniform, >= 0, a multiple of 8, as
 // is n_total >= 8).  Both 16-byte loads are unconditional, so that the load of tile t + 1 stays in flight under tile t,
-// and addressed as uniform base + 32-bit lane offset (scalar address arithmetic).  Near the end of the buffer the
-// offsets are clamped to its last 16 bytes: such samples are outside the region and masked by the term functors.
+// and addressed as uniform base + 32-bit lane offset (scalar address arithmetic).  (Round 5: with the non-temporal hint
+// on these loads every wave kernel is slower -- stat+pa 19.2 -> 20.5 ms, jnn 15.5 -> 16.7, jnnv2 13.1 -> 18.7: the
+// second 16-byte load of a lane and jnnv2's trailing tile live on the line staying where the first load put it.)
+// Near the end of the buffer the offsets are clamped to its last 16 bytes: such samples are outside the region and
+// masked by the term functors.
 __device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int64_t n_total, int64_t tile0) {
     const int64_t last = n_total - 8;
     const int64_t t0 = tile0 < last ? tile0 : last;
@@ -560,14 +560,8 @@ __device__ __forceinline__ void wt_load(WaveTile &t, const int16_t *samples, int
     const char *tb = reinterpret_cast<const char *>(samples + t0);
     const uint32_t lo = (uint32_t)lane_id() * (uint32_t)(SS_SPL * sizeof(int16_t));
     const uint32_t o0 = lo < room ? lo : room, o1 = lo + 16u < room ? lo + 16u : room;
-#if SGK_WT_NT
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 q0 = __builtin_nontemporal_load(static_cast<const u32x4 *>(__builtin_assume_aligned(tb + o0, 16)));
-    const u32x4 q1 = __builtin_nontemporal_load(static_cast<const u32x4 *>(__builtin_assume_aligned(tb + o1, 16)));
-#else
     const uint4 q0 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o0, 16));
     const uint4 q1 = *static_cast<const uint4 *>(__builtin_assume_aligned(tb + o1, 16));
-#endif
     t.w[0] = q0.x; t.w[1] = q0.y; t.w[2] = q0.z; t.w[3] = q0.w;
     t.w[4] = q1.x; t.w[5] = q1.y; t.w[6] = q1.z; t.w[7] = q1.w;
 }
