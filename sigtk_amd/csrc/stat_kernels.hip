@@ -694,8 +694,11 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
         wa = ss_walk<NEG>(ma, mka(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
         wb = ss_walk<NEG>(mb, mkb(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
     } else {
-        wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
-        wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+        // (q0 through an opaque copy made HERE: the 32 validity compares of an edge tile were otherwise evaluated in
+        // front of the branch, on every tile -- a third of the vector time of an interior tile's walk, round 5)
+        const int q0e = q0 + (int)ss_opaque_zero();
+        wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0e, q_lo, q_hi, 0u}));
+        wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0e, q_lo, q_hi, 0u}));
     }
     if (ca) { ++ca->tiles; ++cb->tiles; }
     int ska, skb;
@@ -1120,7 +1123,7 @@ __device__ __forceinline__ void ss_tile1(float &m, const WaveRead &wr, const Wav
     wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
     SsWalk w;
     if (wr.interior(t)) w = ss_walk<NEG>(m, mk(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
-    else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+    else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0 + (int)ss_opaque_zero(), q_lo, q_hi, 0u}));  // (see ss_tile2)
     int sk;
     if (ss_fast<NEG>(m, w, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), sk))
         m = ss_finish<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), w, sk);
@@ -1208,74 +1211,100 @@ __device__ __forceinline__ void jnn_chunks(const WaveRead &wr, int64_t n, int hi
         return (uint32_t)(x >> 32);
     };
 
-    // Every lane streams its own chunk with 16-byte loads, the next block in flight under the current one.  (Measured
-    // alternatives, both slower at 4-5 waves per SIMD: whole 128-byte lines per lane -- 64 more registers; the LDS row
-    // stager of the lane-per-read kernels -- its barriers and the LDS round trip.  Round 5 tried the whole line once
-    // more, from a line boundary, two 32-sample blocks per step with the unchanged 32-bit mask logic: 115 registers
-    // instead of 89, four waves per SIMD instead of five, 16.4 ms instead of 15.6 at 125 000 x 100 000 although the pass
-    // then reads every line once.)
-    uint32_t w[JW_BLOCK / 2], wn[JW_BLOCK / 2];
-    auto load_block = [&](uint32_t (&x)[JW_BLOCK / 2], int64_t q) {
+    // Every lane streams its own chunk, a whole 128-byte line (two blocks) per step, from a line boundary: the masks of
+    // both blocks are formed first, the next line is requested into the registers that frees, and is in flight under
+    // the automaton's two blocks.  (Round 5.  Until then a lane took 64 bytes per step with the next 64 in flight: the
+    // two halves of a line were requested a whole step apart, 3.6 us during which 4 MB pass through an XCD's 4 MB L2,
+    // and 60 % of the lines were fetched twice -- 15 of the kernel's 90 GB at 125 000 x 100 000, in a kernel that runs
+    // at 5.8 TB/s.  Earlier attempts kept two whole lines per lane in registers: 115 registers instead of 89, four waves
+    // per SIMD instead of five, 16.4 ms against 15.6; the LDS row stager of the lane-per-read kernels lost to its
+    // barriers.)
+    // lo_r < v < hi_r  <=>  lp1 <= v <= hm1 on int16 samples (thresholds beyond the int16 range: always / never)
+    const bool never = hi_r <= -32768 || lo_r >= 32767;
+    const int hm1_i = hi_r - 1 > 32767 ? 32767 : hi_r - 1, lp1_i = lo_r + 1 < -32768 ? -32768 : lo_r + 1;
+    const s16x2 hm1 = {(short)hm1_i, (short)hm1_i}, lp1 = {(short)lp1_i, (short)lp1_i};
+    auto spread16 = [](uint32_t x) {  // bit k -> bit 2k
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    constexpr int JW_LINE = 2 * JW_BLOCK;  // samples per 128-byte line
+    qb -= (wr.rb + qb) & (int64_t)(JW_LINE - 1);  // (starting earlier only adds to what the sync search knows)
+    uint32_t ln[JW_LINE / 2];
+    auto load_line = [&](int64_t q) {
         const int64_t last = wr.n_total - 8;
 #pragma unroll
-        for (int v = 0; v < JW_BLOCK / 8; ++v) {
+        for (int v = 0; v < JW_LINE / 8; ++v) {
             int64_t pp = wr.rb + q + 8 * v;
             pp = pp < last ? pp : last;
             pp = pp < 0 ? 0 : pp;
             const uint4 u = *reinterpret_cast<const uint4 *>(wr.samples + pp);
-            x[4 * v] = u.x; x[4 * v + 1] = u.y; x[4 * v + 2] = u.z; x[4 * v + 3] = u.w;
+            ln[4 * v] = u.x; ln[4 * v + 1] = u.y; ln[4 * v + 2] = u.z; ln[4 * v + 3] = u.w;
         }
     };
-    load_block(w, qb);
-    for (;;) {
-        const bool busy = active && (srchm | runm) && qb < nq;
-        if (!__any(busy)) break;
-        load_block(wn, qb + JW_BLOCK);
-        if (busy) {
-            uint32_t inm = 0u;
+    // bit e of the result: lo_r < sample e < hi_r of the block in ln[16 h ..].  Two samples per instruction (one by one
+    // this was 18 issue cycles per sample): saturating packed subtractions leave the sign of (hi_r - 1) - v and of
+    // v - (lo_r + 1) in bits 15 / 31 of a word -- either set: out of range --, the words' flags are collected by
+    // shifting (even samples in the low half, odd ones in the high half) and the two halves interleaved at the end.
+    auto block_mask = [&](int h) -> uint32_t {
+        uint32_t acc = 0u;
 #pragma unroll
-            for (int e = 0; e < JW_BLOCK; ++e) {
-                const int iv = (e & 1) ? (int)(int16_t)(w[e / 2] >> 16) : (int)(int16_t)(w[e / 2] & 0xffffu);
-                inm |= ((uint32_t)((iv - hi_r) & (lo_r - iv)) >> 31) << e;
-            }
-            uint32_t vmask = 0xffffffffu;
-            if (qb < wr.skip || qb + JW_BLOCK > nq) {  // a block on the read's edge
-                const int64_t a0 = wr.skip - qb, a1 = nq - qb;
-                const int lo = a0 < 0 ? 0 : (a0 > 32 ? 32 : (int)a0), hi = a1 > 32 ? 32 : (a1 < 0 ? 0 : (int)a1);
-                vmask = (lo >= 32 ? 0u : (0xffffffffu >> lo) << lo) & (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u));
-            }
-            inm &= vmask;
-            const uint32_t outm = ~inm & vmask;
-            int lo = 0, hi = 32;
-            bool ends_here = false;
-            if (srchm || qb + JW_BLOCK >= ce) {  // the sync logic is in play (the block holds sample ce - 1 or lies behind it)
-                const uint32_t sy = sync_bits(outm, oc);
-                if (srchm) {  // the run starts behind the first sync sample at position >= cs - 1
-                    const int64_t f = cs - qb - 1;
-                    const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
-                    if (m) {
-                        lo = __ffs((int)m);  // position behind that sample
-                        srchm = 0;
-                        runm = qb + lo >= ce ? 0 : -1;
-                    } else lo = 32;
-                }
-                if (runm && qb + JW_BLOCK >= ce) {  // ... and ends with the first sync sample at position >= ce - 1
-                    int64_t f = ce - qb - 1;
-                    if (f < lo) f = lo;
-                    const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
-                    if (m) { hi = __ffs((int)m); ends_here = true; }  // (hi can be 32: the sync sample is the block's last)
-                }
-            }
-            if (runm && lo < hi) run_block(inm, outm, (int)(qb - wr.skip), lo, hi);
-            if (ends_here) runm = 0;  // done
-            const uint32_t stop = inm | ~vmask;  // samples that are not out of range
-            oc = stop ? __clz((int)stop) : oc + 32;
+        for (int k = 0; k < JW_BLOCK / 2; ++k) {
+            const s16x2 v = __builtin_bit_cast(s16x2, ln[h * (JW_BLOCK / 2) + k]);
+            const uint32_t d = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(hm1, v)) |
+                               __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(v, lp1));
+            acc = (d & 0x80008000u) | ((acc >> 1) & 0x7fff7fffu);
         }
-        qb += JW_BLOCK;
-#pragma unroll
-        for (int k = 0; k < JW_BLOCK / 2; ++k) w[k] = wn[k];
+        return never ? 0u : ~(spread16(acc & 0xffffu) | (spread16(acc >> 16) << 1));
+    };
+    // the automaton over the block of 32 samples at q
+    auto step = [&](uint32_t inm, int64_t q) {
+        const bool busy = active && (srchm | runm) && q < nq;
+        if (!busy) return;
+        uint32_t vmask = 0xffffffffu;
+        if (q < wr.skip || q + JW_BLOCK > nq) {  // a block on the read's edge
+            const int64_t a0 = wr.skip - q, a1 = nq - q;
+            const int lo = a0 < 0 ? 0 : (a0 > 32 ? 32 : (int)a0), hi = a1 > 32 ? 32 : (a1 < 0 ? 0 : (int)a1);
+            vmask = (lo >= 32 ? 0u : (0xffffffffu >> lo) << lo) & (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u));
+        }
+        inm &= vmask;
+        const uint32_t outm = ~inm & vmask;
+        int lo = 0, hi = 32;
+        bool ends_here = false;
+        if (srchm || q + JW_BLOCK >= ce) {  // the sync logic is in play (the block holds sample ce - 1 or lies behind it)
+            const uint32_t sy = sync_bits(outm, oc);
+            if (srchm) {  // the run starts behind the first sync sample at position >= cs - 1
+                const int64_t f = cs - q - 1;
+                const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
+                if (m) {
+                    lo = __ffs((int)m);  // position behind that sample
+                    srchm = 0;
+                    runm = q + lo >= ce ? 0 : -1;
+                } else lo = 32;
+            }
+            if (runm && q + JW_BLOCK >= ce) {  // ... and ends with the first sync sample at position >= ce - 1
+                int64_t f = ce - q - 1;
+                if (f < lo) f = lo;
+                const uint32_t m = f >= 32 ? 0u : (f <= 0 ? sy : (sy >> f) << f);
+                if (m) { hi = __ffs((int)m); ends_here = true; }  // (hi can be 32: the sync sample is the block's last)
+            }
+        }
+        if (runm && lo < hi) run_block(inm, outm, (int)(q - wr.skip), lo, hi);
+        if (ends_here) runm = 0;  // done
+        const uint32_t stop = inm | ~vmask;  // samples that are not out of range
+        oc = stop ? __clz((int)stop) : oc + 32;
+    };
+    load_line(qb);
+    for (;;) {
+        if (!__any(active && (srchm | runm) && qb < nq)) break;
+        const uint32_t m0 = block_mask(0), m1 = block_mask(1);
+        load_line(qb + JW_LINE);
+        step(m0, qb);
+        step(m1, qb + JW_BLOCK);
+        qb += JW_LINE;
     }
-
 }
 
 // integer form of jnn_core's range test for thresholds top / bot (JnnAuto::init above), on the UNCLAMPED sample:
@@ -1424,7 +1453,10 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
         // a long read is k_long_chains' (sums, automaton and merge) if its slots have room for 4 096 chunks' headers
         const LongSums *lg = a.long_redo ? nullptr : find_long(a, r, n);
         if (lg && lg->rec_off != LC_NO_REC && jnn_long_cap(a, r, wr.skip + n) >= 4u) return;
-        {
+#ifndef SGK_JNN_ABL
+#define SGK_JNN_ABL 0  // development: 1 / 2 / 4 leave out the pass of the sum / of the deviations / of the automaton
+#endif
+        if (!(SGK_JNN_ABL & 1)) {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1432,9 +1464,9 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
                 ss_tile1<false>(s, wr, cur, t, [&](auto b) { return TermClamp<decltype(b)::interior>{b}; });
                 cur = nxt;
             }
-        }
+        } else s = nf * 480.0f;
         const float mn = s / nf;
-        {
+        if (!(SGK_JNN_ABL & 2)) {
             WaveTile cur, nxt;
             wr.load(cur, 0);
             for (int t = 0; t < wr.ntiles; ++t) {
@@ -1442,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
                 ss_tile1<false>(q, wr, cur, t, [&](auto b) { return TermDevClamp<decltype(b)::interior>{b, mn}; });
                 cur = nxt;
             }
-        }
+        } else q = nf * 2500.0f;
         const float band = sqrtf(q / nf) * p.std_scale;
         top = mn + band;
         bot = mn - band;
@@ -1473,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_jnn_wave(StatArgs a, JnnP p) {
             ++cnt;  // (more than capL: jnn_merge_round reports the overflow)
         }
     };
-    jnn_chunks(wr, n, th.hi_r, th.lo_r, p.error, th.keep_min, candidate, C, 0);
+    if (!(SGK_JNN_ABL & 4)) jnn_chunks(wr, n, th.hi_r, th.lo_r, p.error, th.keep_min, candidate, C, 0);
 
     // A lane's staging part is sized for chunks that end where they should; a read with too few sync points (a lane ran
     // on through many chunks and kept more segments than its part holds) is handed to the lane-per-read kernel instead
@@ -2043,27 +2075,63 @@ __device__ __forceinline__ void roll_chain_tile(float &acc, const WaveRead &wr, 
 #pragma unroll
         for (int e = 0; e < SS_SPL; ++e) x[e] = term(tot[e]);
     } else {
+        const int q0e = q0 + (int)ss_opaque_zero();  // (keeps the compares inside this branch, see ss_tile2)
 #pragma unroll
-        for (int e = 0; e < SS_SPL; ++e) x[e] = (q0 + e >= q_lo && q0 + e < q_hi) ? term(tot[e]) : 0.0f;
+        for (int e = 0; e < SS_SPL; ++e) x[e] = (q0e + e >= q_lo && q0e + e < q_hi) ? term(tot[e]) : 0.0f;
     }
     const SsWalk w = ss_walk<false>(acc, TermArr{x});
     int sk;
     if (ss_fast<false>(acc, w, TermArr{x}, sk)) acc = ss_finish<false>(acc, TermArr{x}, w, sk);
 }
 
-// one sweep over the rolling totals of the windows of wr: f(t, tot) per tile; stops when f returns true
+// one sweep over the rolling totals of the windows of wr: f(t, tot) per tile; stops when f returns true.
+// `ring` (round 5; nullptr: every trailing tile is loaded from memory): 3 x 2 KB of LDS of this wave's.  The trailing tile
+// of window tile t + 1 is what the wave loaded as LEADING tiles t - 1 and t (ADW = 2 000 = 2 x 1 024 - 48 samples: lane l's
+// 16 trailing samples are lane l + 3's of leading tile t - 1, the last three lanes' are lanes 0 .. 2's of tile t), so the
+// leading tiles go through a ring and the trailing ones come out of it: at 125 000 x 100 000 the second read missed the L2
+// for 36 % of its lines (67.9 GB fetched for two passes of 25 GB and a partial third).
+constexpr int ROLL_RING_TILES = 3;
+constexpr int ROLL_RING_BYTES = ROLL_RING_TILES * SS_TILE * (int)sizeof(int16_t);
+static_assert(2 * SS_TILE - ADW == 3 * SS_SPL && ADW > SS_TILE, "the lane shift of the trailing tile");
 template <typename F>
-__device__ __forceinline__ void roll_sweep(const WaveRead &wr, int first_total, F f) {
+__device__ __forceinline__ void roll_sweep(const WaveRead &wr, int first_total, F f, uint4 *ring = nullptr) {
     int T0 = first_total;
+    const int lane = lane_id();
     WaveTile tr, ld, trn, ldn;
     roll_load(wr, tr, ld, 0);
     for (int t = 0; t < wr.ntiles; ++t) {
-        if (t + 1 < wr.ntiles) roll_load(wr, trn, ldn, t + 1);
+        const bool more = t + 1 < wr.ntiles;
+        const bool from_ring = ring != nullptr && t + 1 >= 2;
+        if (ring) {
+            uint4 *row = ring + (t % ROLL_RING_TILES) * (SS_TILE / 8) + lane * 2;
+            row[0] = make_uint4(ld.w[0], ld.w[1], ld.w[2], ld.w[3]);
+            row[1] = make_uint4(ld.w[4], ld.w[5], ld.w[6], ld.w[7]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (more) {
+            const int64_t tile0 = wr.rb + (int64_t)(t + 1) * SS_TILE;
+            if (!from_ring) wt_load(trn, wr.samples, wr.n_total, tile0);
+            wt_load(ldn, wr.samples, wr.n_total, tile0 + ADW);
+        }
         int tot[SS_SPL];
         if (t == 0 && wr.skip > 0) roll_tile<true>(tr, ld, wr.skip, T0, tot);
         else roll_tile<false>(tr, ld, 0, T0, tot);
         if (f(t, tot)) break;
+        if (more && from_ring) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int src = lane + 3;
+            const uint4 *row = src < 64 ? ring + ((t + 2) % ROLL_RING_TILES) * (SS_TILE / 8) + src * 2   // tile t - 1
+                                        : ring + (t % ROLL_RING_TILES) * (SS_TILE / 8) + (src - 64) * 2;  // tile t
+            const uint4 q0 = row[0], q1 = row[1];
+            trn.w[0] = q0.x; trn.w[1] = q0.y; trn.w[2] = q0.z; trn.w[3] = q0.w;
+            trn.w[4] = q1.x; trn.w[5] = q1.y; trn.w[6] = q1.z; trn.w[7] = q1.w;
+        }
         tr = trn; ld = ldn;
+    }
+    if (ring) {  // the next sweep's rows are written behind this one's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 // what find_adaptor leaves in a read's record before anything is found (lane 0)
@@ -2077,7 +2145,7 @@ __device__ __forceinline__ void adaptor_init_rec(sgk_prefix_rec_t *o, int64_t n)
 // jnnv2's thresholds from the two sums over the m rolling means (src/jnn.c:106-124) and its run finder (RunFinder above,
 // src/jnn.c:126-167) from flip to flip, by one wave; writes adapt_x / adapt_y
 __device__ inline void adaptor_find(const WaveRead &wr, int first_total, float s, float q, float mf, const AdaptP &ap,
-                                    sgk_prefix_rec_t *o) {
+                                    sgk_prefix_rec_t *o, uint4 *ring = nullptr) {
     const int lane = lane_id(), q0 = lane * SS_SPL;
     const float mn = s / mf;
     const float sd = sqrtf(q / mf);
@@ -2123,7 +2191,7 @@ __device__ inline void adaptor_find(const WaveRead &wr, int first_total, float s
             }
         }
         return found != 0;
-    });
+    }, ring);
     if (nseg > 0) settle();
     if (lane == 0) {
         if (found) { o->adapt_x = ans_x + ADW / 2 - 1; o->adapt_y = ans_y + ADW / 2 - 1; }
@@ -2141,6 +2209,8 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
         if (widx >= a.b.n_reads) return;
         r = a.order ? a.order[widx] : widx;
     }
+    __shared__ uint4 ring_all[4][ROLL_RING_BYTES / 16];
+    uint4 *ring = ring_all[wv];
     const Region g = get_region(REG_WHOLE, a.b, nullptr, r);
     const int64_t n = g.len;
     // a long read is k_long_chains' (which runs beside this kernel): its sums, thresholds, run finder and record
@@ -2163,14 +2233,14 @@ __global__ __launch_bounds__(256) void k_adaptor_wave(StatArgs a, AdaptP ap) {
     roll_sweep(wr, first_total, [&](int t, const int (&tot)[SS_SPL]) {
         roll_chain_tile(s, wr, t, tot, [](int v) { return roll_mean(v); });
         return false;
-    });
+    }, ring);
     const float mn = s / mf;
     float q = 0.0f;
     roll_sweep(wr, first_total, [&](int t, const int (&tot)[SS_SPL]) {
         roll_chain_tile(q, wr, t, tot, [&](int v) { const float d = roll_mean(v) - mn; return d * d; });
         return false;
-    });
-    adaptor_find(wr, first_total, s, q, mf, ap, o);
+    }, ring);
+    adaptor_find(wr, first_total, s, q, mf, ap, o, ring);
 }
 
 // ---------------------------------------------------------------- long reads: the sequential sums on 64 wavefronts

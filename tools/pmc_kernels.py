@@ -28,7 +28,7 @@ def main():
            for k, cs in acc.items()}
     if samples:
         for k, v in out.items():
-            if "SQ_INSTS_VALU" in v and "SQ_BUSY_CYCLES" in v:
+            if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
                 v["valu_lane_instructions_per_sample"] = round(v["SQ_INSTS_VALU"] * 64 / samples, 1)
                 v["salu_instructions_per_64_samples"] = round(v["SQ_INSTS_SALU"] * 64 / samples, 1)
                 v["valu_busy_fraction"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (v["SQ_BUSY_CYCLES"] / 32 * 1024), 3)
