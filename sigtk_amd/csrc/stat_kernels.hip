@@ -671,6 +671,10 @@ struct TermDevPa {   // (pA - mean)^2, src/stat.h:36-44
     }
 };
 
+#ifndef SGK_SS_EDGE_OPAQUE
+#define SGK_SS_EDGE_OPAQUE 1
+#endif
+__device__ __forceinline__ int ss_edge_zero() { return SGK_SS_EDGE_OPAQUE ? (int)ss_opaque_zero() : 0; }
 // the signed value of an oriented accumulator (a zero accumulator stands for +0)
 __device__ __forceinline__ float ss_signed(float m, bool negated) { return m == 0.0f ? 0.0f : (negated ? -m : m); }
 
@@ -694,11 +698,11 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
         wa = ss_walk<NEG>(ma, mka(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
         wb = ss_walk<NEG>(mb, mkb(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
     } else {
-        // (q0 through an opaque copy made HERE: the 32 validity compares of an edge tile were otherwise evaluated in
-        // front of the branch, on every tile -- a third of the vector time of an interior tile's walk, round 5)
-        const int q0e = q0 + (int)ss_opaque_zero();
-        wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0e, q_lo, q_hi, 0u}));
-        wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0e, q_lo, q_hi, 0u}));
+        // (The 32 validity compares of an edge tile are evaluated in front of the branch, on every tile.  Round 5 kept
+        // them inside it with an opaque copy of q0, as ss_tile1 does: two registers more, which k_stat_wave does not
+        // have -- 127 and 2 spilled, 20.05 against 19.72 ms for stat+pa at 125 000 x 100 000.)
+        wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
+        wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
     }
     if (ca) { ++ca->tiles; ++cb->tiles; }
     int ska, skb;
@@ -1121,9 +1125,11 @@ __device__ __forceinline__ void ss_tile1(float &m, const WaveRead &wr, const Wav
         if (qh > q_lo) m = ss_serial(m, mk(TermBase<false>{cur, q0, q_lo, qh, 0u}), q_lo / SS_SPL, (qh - 1) / SS_SPL);
     }
     wr.range(t, t == 0 ? wr.head() : 0, q_lo, q_hi);
+    // (q0 of the edge branch through an opaque copy made there: its 32 validity compares were otherwise evaluated in
+    // front of the branch, on every tile -- a third of the vector time of an interior tile's walk, round 5)
     SsWalk w;
     if (wr.interior(t)) w = ss_walk<NEG>(m, mk(TermBase<true>{cur, q0, q_lo, q_hi, 0u}));
-    else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0 + (int)ss_opaque_zero(), q_lo, q_hi, 0u}));  // (see ss_tile2)
+    else w = ss_walk<NEG>(m, mk(TermBase<false>{cur, q0 + ss_edge_zero(), q_lo, q_hi, 0u}));
     int sk;
     if (ss_fast<NEG>(m, w, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), sk))
         m = ss_finish<NEG>(m, mk(TermBase<false>{cur, q0, q_lo, q_hi, 0u}), w, sk);
@@ -2075,7 +2081,7 @@ __device__ __forceinline__ void roll_chain_tile(float &acc, const WaveRead &wr, 
 #pragma unroll
         for (int e = 0; e < SS_SPL; ++e) x[e] = term(tot[e]);
     } else {
-        const int q0e = q0 + (int)ss_opaque_zero();  // (keeps the compares inside this branch, see ss_tile2)
+        const int q0e = q0 + ss_edge_zero();  // (keeps the compares inside this branch, see ss_tile1)
 #pragma unroll
         for (int e = 0; e < SS_SPL; ++e) x[e] = (q0e + e >= q_lo && q0e + e < q_hi) ? term(tot[e]) : 0.0f;
     }
