@@ -2014,13 +2014,15 @@ __global__ __launch_bounds__(64, 2) void k_adaptor(StatArgs a, AdaptP ap) {
 // masks and stops at the first qualifying segment that can no longer change.
 // rolling totals of this lane's 16 window indices.  T0: total of the tile's first index (wave-uniform), advanced to
 // the next tile's.  d_lo: tile-local indices below it have no difference (they lie in front of the read).
-template <bool MASKED>
+// (CLAMPED: the tiles hold rm_outlier of the samples already, roll_sweep)
+template <bool MASKED, bool CLAMPED = false>
 __device__ __forceinline__ void roll_tile(const WaveTile &trail, const WaveTile &lead, int d_lo, int &T0, int (&tot)[SS_SPL]) {
     const int q0 = lane_id() * SS_SPL;
     int run = 0;
 #pragma unroll
     for (int k = 0; k < SS_SPL / 2; ++k) {
-        const s16x2 d = clamp_raw2(lead.w[k]) - clamp_raw2(trail.w[k]);
+        const s16x2 d = CLAMPED ? __builtin_bit_cast(s16x2, lead.w[k]) - __builtin_bit_cast(s16x2, trail.w[k])
+                                : clamp_raw2(lead.w[k]) - clamp_raw2(trail.w[k]);
         int d0 = (int)d.x, d1 = (int)d.y;
         if (MASKED) {
             d0 = (q0 + 2 * k >= d_lo) ? d0 : 0;
@@ -2103,8 +2105,15 @@ template <typename F>
 __device__ __forceinline__ void roll_sweep(const WaveRead &wr, int first_total, F f, uint4 *ring = nullptr) {
     int T0 = first_total;
     const int lane = lane_id();
+    // the tiles are kept clamped (rm_outlier, two samples per instruction): a tile is clamped once, as a leading tile
+    auto clamp_tile = [](WaveTile &x) {
+#pragma unroll
+        for (int k = 0; k < SS_SPL / 2; ++k) x.w[k] = __builtin_bit_cast(uint32_t, clamp_raw2(x.w[k]));
+    };
     WaveTile tr, ld, trn, ldn;
     roll_load(wr, tr, ld, 0);
+    clamp_tile(tr);
+    clamp_tile(ld);
     for (int t = 0; t < wr.ntiles; ++t) {
         const bool more = t + 1 < wr.ntiles;
         const bool from_ring = ring != nullptr && t + 1 >= 2;
@@ -2121,9 +2130,13 @@ __device__ __forceinline__ void roll_sweep(const WaveRead &wr, int first_total, 
             wt_load(ldn, wr.samples, wr.n_total, tile0 + ADW);
         }
         int tot[SS_SPL];
-        if (t == 0 && wr.skip > 0) roll_tile<true>(tr, ld, wr.skip, T0, tot);
-        else roll_tile<false>(tr, ld, 0, T0, tot);
+        if (t == 0 && wr.skip > 0) roll_tile<true, true>(tr, ld, wr.skip, T0, tot);
+        else roll_tile<false, true>(tr, ld, 0, T0, tot);
         if (f(t, tot)) break;
+        if (more) {
+            clamp_tile(ldn);
+            if (!from_ring) clamp_tile(trn);
+        }
         if (more && from_ring) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int src = lane + 3;
