@@ -700,7 +700,8 @@ __device__ __forceinline__ void ss_tile2(float &ma, float &mb, const WaveRead &w
     } else {
         // (The 32 validity compares of an edge tile are evaluated in front of the branch, on every tile.  Round 5 kept
         // them inside it with an opaque copy of q0, as ss_tile1 does: two registers more, which k_stat_wave does not
-        // have -- 127 and 2 spilled, 20.05 against 19.72 ms for stat+pa at 125 000 x 100 000.)
+        // have -- 127 and 2 spilled, 20.05 against 19.72 ms for stat+pa at 125 000 x 100 000; opaque copies of the
+        // scalars q_lo / q_hi instead cost no register and are slower all the same, 19.7 against 19.4.)
         wa = ss_walk<NEG>(ma, mka(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
         wb = ss_walk<NEG>(mb, mkb(TermBase<false>{cur, q0, q_lo, q_hi, 0u}));
     }
