@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/${1:-r04}
+O=gpurun_out/${1:-r05_z}
 mkdir -p $O
 timeout -s KILL 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout -s KILL 600 python bench.py --rna 1 --cpu-reads 0 > $O/bench_rna.json 2>> $O/bench.err
@@ -20,10 +20,6 @@ timeout -s KILL 600 python bench.py --read-len 30000 --reads 33333 --rna 1 --cpu
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 20000 --reads 50000 --rna 1 --cpu-reads 0 > $O/bench_ragged_20k_rna.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_ragged_5k.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_ragged_5k_rna.json 2>> $O/bench.err
-SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_5k_one_read_per_wave.json 2>> $O/bench.err
-SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_5k_rna_one_read_per_wave.json 2>> $O/bench.err
-SGK_EVENT_MULTI=-1 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 20000 --reads 50000 --rna 1 --cpu-reads 0 > $O/bench_ragged_20k_rna_one_read_per_wave.json 2>> $O/bench.err
-SGK_EVENT_LONG_MIN=4000000000 timeout -s KILL 600 python bench.py --ragged 0.8 --cpu-reads 0 > $O/bench_ragged_one_wave_per_read.json 2>> $O/bench.err
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 > $O/prof.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
@@ -33,11 +29,9 @@ timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CY
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_5k -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --read-len 5000 --reads 200000 > $O/pmc_sq_5k.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_ragged -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 --ragged 0.8 > $O/pmc_sq_ragged.log 2>&1
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ragged -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 --ragged 0.8 > $O/prof_ragged.log 2>&1
-# the tail split off / small and odd batch sizes
-SGK_EVENT_TAIL=0 timeout -s KILL 600 python bench.py --cpu-reads 0 > $O/bench_no_tail_split.json 2>> $O/bench.err
+# small and odd batch sizes
 for n in 1000 4000 9300; do
 timeout -s KILL 600 python bench.py --reads $n --cpu-reads 0 > $O/bench_${n}.json 2>> $O/bench.err
-SGK_EVENT_TAIL=0 timeout -s KILL 600 python bench.py --reads $n --cpu-reads 0 > $O/bench_${n}_no_tail_split.json 2>> $O/bench.err
 done
 if [ "$2" != "nosub" ]; then
 timeout -s KILL 900 python bench.py --config 3 > $O/bench_c3.json 2>> $O/bench.err
@@ -47,6 +41,14 @@ timeout -s KILL 600 python tools/bench_subtools.py --reads 125000 --rna 0 > $O/s
 timeout -s KILL 600 python tools/bench_subtools.py --reads 50000 --rna 1 > $O/subtools_c3.json 2>> $O/bench.err
 timeout -s KILL 600 python tools/bench_subtools.py --ragged 0.8 > $O/subtools_ragged.json 2>> $O/bench.err
 timeout -s KILL 900 python -m pytest tests/test_gpu_device_api.py -q -k config3 > $O/test_config3.txt 2>&1; tail -3 $O/test_config3.txt
+# the subtool kernels at 125 000 x 100 000: kernel stats, HBM traffic, SQ counters
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sub -- python3 tools/bench_subtools.py --reads 125000 --rna 0 --steps 3 > $O/prof_sub.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_sub_fetch -- python3 tools/bench_subtools.py --reads 125000 --rna 0 --steps 1 > $O/pmc_sub_fetch.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_sub_write -- python3 tools/bench_subtools.py --reads 125000 --rna 0 --steps 1 > $O/pmc_sub_write.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/pmc_sub_sq -- python3 tools/bench_subtools.py --reads 125000 --rna 0 --steps 1 > $O/pmc_sub_sq.log 2>&1
+python tools/pmc_kernels.py $O/pmc_sub_fetch > $O/pmc_sub_fetch.json 2>> $O/bench.err
+python tools/pmc_kernels.py $O/pmc_sub_write > $O/pmc_sub_write.json 2>> $O/bench.err
+python tools/pmc_kernels.py $O/pmc_sub_sq "" 12500000000 > $O/pmc_sub_sq.json 2>> $O/bench.err
 fi
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
