@@ -110,11 +110,18 @@ static uint32_t event_wave_slots(int rna) {
 // themselves), not for reads under 32 768 samples on average.
 // A cut read costs ~1.5 x a whole one (every lane of every segment warms up, the chain waits for the segment in front,
 // the builder starts from the last boundary in front of it), so cutting pays only where FEW reads would otherwise keep
-// the whole GPU waiting: measured on the round-5 kernel (profiles/r05_tail_split_sweep.txt, 100 000-sample reads, off /
-// on): 500 reads 0.69 / 0.42 ms, 1 000 0.69 / 0.62, 9 300 (84 reads over 3 rounds) 3.56 / 3.35; but 2 000 0.89 / 1.14,
-// 4 000 1.58 / 1.76, 5 000 1.82 / 2.22, 10 000 (784 over) 3.52 / 3.69, 20 000 6.75 / 7.02 -- round 4's rule (any last
-// round under 7 / 8 full) was tuned on a kernel whose whole reads were 6 % slower.  Now: the last round at most a sixth
-// of a round (six or more segments per read), or a batch of at most a third of a round.
+// the whole GPU waiting.  The rule is fitted to whole-call times of the shipped kernels with the split forced on / off
+// over 50 batch sizes per preset (tools/tail_sweep.py -> profiles/r05_tail_split_sweep.txt, 100 000-sample reads), and
+// tests/test_gpu_event_long.py::test_tail_split_rule_is_no_cliff times both either side of every cut of it:
+//   a batch of less than one round of waves: DNA preset up to 0.55 of a round (1 536 reads 0.88 -> 0.65 ms; a tie from
+//     0.58 on), RNA preset up to 7 / 8 of one (1 024 reads 1.12 -> 0.78 ms, 1 877 reads 1.31 -> 1.25);
+//   a longer batch, DNA preset: the last round at most a quarter of a round behind ONE full round (3 840 reads 1.54 ->
+//     1.48 ms), a sixth behind more (9 728 reads 3.56 -> 3.42; 9 984 reads 3.54 -> 3.60);
+//   a longer batch, RNA preset: never -- at two waves per SIMD the first waves of a round are done at half time and a
+//     small surplus runs in their slots (2 218 reads 1.55 ms whole, 1.72 split); the best case gains 6 %, most lose.
+// (Round 4's rule -- any last round under 7 / 8 full -- was tuned on a kernel whose whole reads were 6 % slower; the
+// first rule of round 5, a sixth / a third, came from a sweep of an instrumented build and left 25 % on the table for
+// batches of 1 100 - 1 600 reads: the guard test's first run found that.)
 void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
                      bool packed, uint32_t &split_from, uint32_t &split_seg) {
     split_from = n_reads;
@@ -125,7 +132,9 @@ void event_tail_plan(const EvSegConfig &sc, uint32_t n_reads, uint64_t n_samples
     if (mean < 32768 || (sc.tail_split == 0 && n_reads >= 8ull * slots)) return;
     uint32_t rem = n_reads % slots;
     if (sc.tail_split > 0) rem = (uint32_t)sc.tail_split < n_reads ? (uint32_t)sc.tail_split : n_reads;   // the caller's number
-    else if (rem == 0 || rem * (n_reads < slots ? 3u : 6u) > slots) return;
+    else if (n_reads < slots) {
+        if (rna ? (uint64_t)n_reads * 8u > (uint64_t)slots * 7u : (uint64_t)n_reads * 20u > (uint64_t)slots * 11u) return;
+    } else if (rem == 0 || rna || rem * (n_reads < 2u * slots ? 4u : 6u) > slots) return;
     // (the number of segments per read hardly matters: 2 .. 16 per read, one or two rounds of them: 3.77 - 3.89 ms)
     uint32_t G = (slots - slots / 16 + rem - 1) / rem;   // units of the split reads ~ one round
     if (G < 2) G = 2;

@@ -2306,12 +2306,24 @@ __global__ __launch_bounds__(64) void k_event_fallback(EvArgs a) {
 constexpr int SIDE_POOL = 4;
 static SideStream g_side[64][3][SIDE_POOL];
 static std::atomic<unsigned> g_side_next[64][3];
+static SideStream *side_acquire_slot(int dev, int kind, int slot, int priority);
 // returns a locked side stream (unlock with x->mu.unlock()), or null
 SideStream *side_acquire(int priority) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     const int kind = priority < 0 ? 1 : (priority > 0 ? 2 : 0);
-    SideStream &x = g_side[dev][kind][g_side_next[dev][kind].fetch_add(1u) % SIDE_POOL];
+    // the whole pool of this device and kind is made by the first call that needs one (stream creation takes
+    // milliseconds: made one by one, the first SIDE_POOL launches each paid for one -- a two-step warm-up was not enough)
+    static std::atomic<bool> g_side_made[64][3];
+    if (!g_side_made[dev][kind].exchange(true))
+        for (int k = 1; k < SIDE_POOL; ++k) {
+            SideStream *y = side_acquire_slot(dev, kind, k, priority);
+            if (y) y->mu.unlock();
+        }
+    return side_acquire_slot(dev, kind, (int)(g_side_next[dev][kind].fetch_add(1u) % SIDE_POOL), priority);
+}
+static SideStream *side_acquire_slot(int dev, int kind, int slot, int priority) {
+    SideStream &x = g_side[dev][kind][slot];
     x.mu.lock();
     if (!x.s && !x.tried) {
         x.tried = true;

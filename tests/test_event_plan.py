@@ -88,9 +88,10 @@ def test_lanes_for_short_reads(lib):
 
 def test_tail_split(lib):
     """a batch of fewer than 8 rounds of wavefronts (256 CUs x 4 SIMDs x 3 waves with the DNA preset, x 2 with RNA
-    parameters; without a GPU the plan assumes 256 CUs) whose last round is at most a sixth of a round, or a batch of at
-    most a third of a round: those reads are cut into segments (round 5: a cut read costs 1.5 x a whole one, so the
-    rule is narrower than round 4's -- profiles/r05_tail_split_sweep.txt)"""
+    parameters; without a GPU the plan assumes 256 CUs): the reads of its last, partial round are cut into segments where
+    that was measured to pay (api.hip: event_tail_plan, profiles/r05_tail_split_sweep.txt) -- a batch of at most 0.55 of a
+    round (RNA preset: 7 / 8), a last round of at most a quarter of a round behind one full round, a sixth behind more
+    (RNA preset: never); a cut read costs 1.5 x a whole one"""
     p, _ = plan(lib, [100000] * 9300)                   # 9 300 = 3 x 3072 + 84: the last 84 reads, 16 384-sample segments
     assert (p.tail_split_from, p.tail_segment_len) == (9216, 16384)
     assert p.max_segments >= 84 * 7 and p.max_long_reads >= 84
@@ -104,7 +105,14 @@ def test_tail_split(lib):
     assert plan(lib, [100000] * 12000)[0].tail_segment_len == 0             # the last round is nearly full
     assert plan(lib, [100000] * 30000)[0].tail_segment_len == 0             # >= 8 rounds: the tail does not matter
     assert plan(lib, [100000] * 10000, rna=1)[0].tail_segment_len == 0      # 2 048 slots: 4.88 rounds, nearly full
-    assert plan(lib, [100000] * 8400, rna=1)[0].tail_segment_len > 0        # 4 x 2048 + 208
+    assert plan(lib, [100000] * 8400, rna=1)[0].tail_segment_len == 0       # 4 x 2048 + 208: RNA preset, more than a round
+    assert plan(lib, [100000] * 1700, rna=1)[0].tail_segment_len > 0        # 0.83 of a round of the RNA preset
+    assert plan(lib, [100000] * 1900, rna=1)[0].tail_segment_len == 0
+    assert plan(lib, [100000] * 1600)[0].tail_segment_len > 0               # 0.52 of a round
+    assert plan(lib, [100000] * 1800)[0].tail_segment_len == 0
+    assert plan(lib, [100000] * 3800)[0].tail_segment_len > 0               # 728 reads behind ONE round: a quarter
+    assert plan(lib, [100000] * 3900)[0].tail_segment_len == 0
+    assert plan(lib, [100000] * 6900)[0].tail_segment_len == 0              # 756 behind two: a sixth
     assert plan(lib, [20000] * 10000)[0].tail_segment_len == 0              # short reads: not worth two kernels more
     assert plan(lib, [100000] * 9300, opt=opts(tail_split=-1))[0].tail_segment_len == 0
     p = plan(lib, [100000] * 30000, opt=opts(tail_split=2000))[0]      # the caller's number, whatever the batch

@@ -419,13 +419,13 @@ def test_baseline_config3_at_its_size(gpu, oracle):
         if e.polya_y > 0:
             for name in ("polya_mean", "polya_std", "polya_median"):
                 assert np.float32(g[name]).view(np.uint32) == np.float32(getattr(e, name)).view(np.uint32), (r, name)
-    # the tail split: the first 8 400 reads of the same batch are 4.1 rounds of RNA wavefronts (208 reads over)
+    # the tail split: the first 1 700 reads of the same batch are 0.83 of a round of RNA wavefronts -- every read is cut
     del arena
     torch.cuda.empty_cache()
-    b9 = device.synth_reads(8400, N, seed=2, kind=1, device=dev)
+    b9 = device.synth_reads(1700, N, seed=2, kind=1, device=dev)
     a9 = device.EventArena(b9)
     device.event(b9, a9, 1)
     torch.cuda.synchronize()
     s9 = a9.status()
-    assert s9.n_split_reads == 8400 % 2048 and s9.n_fallback_reads == 0
-    assert bool((a9.n_events[:8400].to(torch.int64) == snap_n[:8400]).all())
+    assert s9.n_split_reads == 1700 and s9.n_fallback_reads == 0
+    assert bool((a9.n_events[:1700].to(torch.int64) == snap_n[:1700]).all())

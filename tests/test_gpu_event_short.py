@@ -125,3 +125,47 @@ def test_a_read_that_is_short_and_long_belongs_to_its_segments(gpu, oracle, lane
             got, st = gpu.event(reads, dig, off, rng, rna)
             _check_events(oracle, reads, dig, off, rng, rna, got)
             assert st.n_split_reads == sum(1 for n in lens if n >= 1025)
+
+
+@pytest.mark.parametrize("rna", [0, 1])
+def test_packing_threshold_is_no_cliff(gpu, rna):
+    """VERDICT r04 task 8b: reads under short_max samples (16 384; 65 536 with the RNA preset) share wavefronts in large
+    batches (api.hip: event_multi_plan).  Just under and just over that length the batch is timed packed and one read
+    per wavefront: what the rule picks may be at most 1.10 x the other (+ 30 us)."""
+    import torch
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+    short_max = 65536 if rna else 16384
+
+    def timed(b, lanes, smax):
+        o = gpu.EVENT_OPTIONS
+        old = (o.lanes_per_short_read, o.short_max)
+        o.lanes_per_short_read, o.short_max = lanes, smax
+        try:
+            arena = device.EventArena(b)
+        finally:
+            o.lanes_per_short_read, o.short_max = old
+        for _ in range(3):
+            device.event(b, arena, rna)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); device.event(b, arena, rna); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    report = []
+    for length in (short_max - 384, short_max + 64):
+        n = max(int(1.0e9 // length), 26000)   # (packing also wants >= 4 rounds of wavefronts: 24 576 reads at 32 lanes each)
+        b = device.synth_reads(n, length, seed=11, kind=rna, device=dev)
+        packed = gpu.event_plan(n, b.total_samples, length, rna).lanes_per_short_read != 0
+        t_whole, t_packed = timed(b, -1, 0), timed(b, 0, 2 * short_max)
+        t_rule, t_other = (t_packed, t_whole) if packed else (t_whole, t_packed)
+        report.append((length, "packed" if packed else "whole", round(t_packed, 3), round(t_whole, 3)))
+        assert t_rule <= 1.10 * t_other + 0.03, report
+        del b
+        torch.cuda.empty_cache()
+    assert [r[1] for r in report] == ["packed", "whole"], report
+    print(report)
