@@ -30,7 +30,8 @@ def test_large_batches_of_short_similar_reads_take_the_lane_kernels():
     assert plan("stat", 40000, 60000).kernels == 2
     assert plan("stat", 10000, 5000).kernels == 1
     assert plan("stat", 10000, 9000).kernels == 2
-    assert plan("stat", 5000, 2000).kernels == 2             # under 5 248 reads the wave kernels
+    assert plan("stat", 5000, 4000).kernels == 2             # under 5 248 reads the wave kernels ...
+    assert plan("stat", 5000, 2000).kernels == 1             # ... except for reads of at most 2 048 samples, from 1 024 reads on
     assert plan("stat", 100000, 20000).kernels == 1
     assert plan("stat", 80000, 40000).kernels == 1           # (81 920 x 49 152: 0.76)
     assert plan("stat", 60000, 80000).kernels == 2
