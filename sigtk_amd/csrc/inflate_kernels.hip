@@ -64,13 +64,17 @@ struct InfTables {
     uint32_t count[16];            // codes per length
     uint16_t first[16];            // canonical first code of each length
     uint16_t offs[16];             // index of the first symbol of each length in sym[]
+    uint32_t longw[16];            // per length: (first + count) << 16 | (offs - first) & 0xffff -- a code of that length
+                                   // is `code` iff code < first + count, and its symbol sym[code + (offs - first)]
     uint16_t sym[NS];              // symbols ordered by (length, symbol)
 };
 struct InfLds {
     uint8_t win[INF_WIN];
     InfTables<INF_LB, 288> lit;
-    InfTables<INF_DB, 32> dist;
-    InfTables<7, 20> cl;           // the code length code
+    union {
+        InfTables<INF_DB, 32> dist;
+        InfTables<7, 20> cl;       // the code length code: done with before the distance table is built
+    };
     uint8_t lens[320];             // code lengths of the current block
 };
 static_assert(sizeof(InfLds) <= 8448, "19 streams per compute unit");
@@ -104,6 +108,14 @@ struct InfBits {
         }
         return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(k & 63u));
     }
+    // dword k without moving the window (k in the current chunk or the one behind it, else 0: the caller stays within
+    // four dwords of the bit buffer)
+    __device__ __forceinline__ uint32_t peek_dword(uint32_t k) const {
+        const uint32_t c = k >> 6;
+        const uint32_t v = c == chunk ? win : nxt;
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(k & 63u));
+        return (c == chunk || c == chunk + 1u) ? x : 0u;
+    }
     __device__ __forceinline__ void refill() {   // at least 32 valid bits afterwards
         if (cnt <= 32u) {
             buf |= (unsigned long long)dword(next_dw) << cnt;
@@ -120,6 +132,14 @@ struct InfBits {
     }
     __device__ __forceinline__ uint32_t bit_pos() const { return next_dw * 32u - cnt; }
     __device__ __forceinline__ bool overrun() const { return bit_pos() > end_bit; }
+    __device__ __forceinline__ void seek_bit(uint32_t bit) {
+        next_dw = bit >> 5;
+        buf = 0ull;
+        cnt = 0u;
+        refill();
+        drop(bit & 31u);
+        refill();
+    }
     __device__ __forceinline__ void seek_byte(uint32_t byte) {
         next_dw = byte >> 2;
         buf = 0ull;
@@ -147,7 +167,11 @@ __device__ bool inf_build(InfTables<TB, NS> *t, const uint8_t *lens, int nsym) {
         const int c = (int)uni(t->count[len]);
         left = (left << 1) - c;
         if (left < 0) ok = false;
-        if (l == 0) { t->first[len] = (uint16_t)code; t->offs[len] = (uint16_t)off; }
+        if (l == 0) {
+            t->first[len] = (uint16_t)code;
+            t->offs[len] = (uint16_t)off;
+            t->longw[len] = ((uint32_t)(code + c) << 16) | ((uint32_t)(off - code) & 0xffffu);
+        }
         code = (code + c) << 1;
         off += c;
     }
@@ -189,19 +213,22 @@ __device__ __forceinline__ int inf_decode(const InfTables<TB, NS> *t, InfBits &b
         b.drop(e & 15u);
         return (int)(e >> 4);
     }
-    // a code longer than the table: walk the canonical code (puff.c)
-    int code = 0, first = 0, index = 0;
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)((b.buf >> (len - 1)) & 1ull);
-        const int c = (int)uni(t->count[len]);
-        if (code - c < first) {
-            b.drop((uint32_t)len);
-            return (int)uni(t->sym[index + (code - first)]);
+    // a code longer than the table (round 5: one word per length, all of them requested at once, instead of puff.c's
+    // bit-by-bit walk with an LDS round trip per length -- 1 800 cycles for the 6 % of a record's literals whose codes
+    // are longer than 10 bits, a third of a block's time).  A canonical code of `len` bits is the first len bits read
+    // most significant first; codes of a length are consecutive from first[len] and greater than every shorter code
+    // extended to that length.
+    const uint32_t rv = __brev(b.peek(15)) >> 17;
+    uint32_t w[15 - TB];
+#pragma unroll
+    for (int k = 0; k < 15 - TB; ++k) w[k] = t->longw[TB + 1 + k];
+#pragma unroll
+    for (int k = 0; k < 15 - TB; ++k) {
+        const uint32_t len = (uint32_t)(TB + 1 + k), code = rv >> (15u - len), wk = uni(w[k]);
+        if (code < (wk >> 16)) {
+            b.drop(len);
+            return (int)uni(t->sym[(int)code + (int)(int16_t)(wk & 0xffffu)]);
         }
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
     }
     return -1;
 }
@@ -241,6 +268,58 @@ __device__ __forceinline__ void inf_flush(InfLds *L, InfOut &o, uint32_t m) {
         }
     }
     o.flushed += m;
+}
+
+// ---- a run of literals, decoded by the lanes together (round 5)
+// A BLOW5 record is svb-zd bytes: 95 % of its DEFLATE symbols are literals, in runs of 18 (median 9) with codes of 6.4 bits
+// on average, and the symbol loop above costs ~45 SCALAR instructions per symbol on the one scalar unit a compute unit's
+// 19 streams share.  Here lane l looks up the code that would start at bit P + l of the stream (the 96 bits behind P are
+// wave-uniform; one table read per lane), which gives every bit offset of the next 64 its successor; the offsets the
+// stream really visits from P are found by pointer doubling across the lanes (symbol k's offset on lane k, four rounds
+// of two ds_bpermute: up to 16 symbols), the leading run of literals among them is written to the ring by as many lanes
+// at once, and the bit reader moves behind it.  A match, the end of the block, a code longer than the look-up table or
+// the end of the 64-bit window ends the run; the symbol loop takes it from there.  ~45 scalar and ~60 vector / LDS
+// instructions per run of typically 9 literals.  Returns the number of literals written.
+constexpr int INF_RUN = 16;
+#ifndef SGK_INF_RUN
+#define SGK_INF_RUN 1   // 0: the symbol loop alone (development: A/B)
+#endif
+template <int TB, int NS>
+__device__ __forceinline__ uint32_t inf_literal_run(InfLds *L, const InfTables<TB, NS> *t, InfBits &b, InfOut &o, bool &hit) {
+    const int l = lane_id();
+    const uint32_t P = b.bit_pos(), k0 = P >> 5, sh = P & 31u;
+    if ((k0 >> 6) != b.chunk) return ~0u;   // (the input window has just moved on: these few bits are the symbol loop's)
+    const uint32_t w0 = b.peek_dword(k0), w1 = b.peek_dword(k0 + 1u), w2 = b.peek_dword(k0 + 2u), w3 = b.peek_dword(k0 + 3u);
+    const uint32_t a0 = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh);
+    const uint32_t a1 = (uint32_t)((((unsigned long long)w2 << 32) | w1) >> sh);
+    const uint32_t a2 = (uint32_t)((((unsigned long long)w3 << 32) | w2) >> sh);
+    const uint32_t lo = l < 32 ? a0 : a1, hi = l < 32 ? a1 : a2;
+    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)l & 31u);   // the bits from P + l on
+    const uint32_t e = t->fast[x & ((1u << TB) - 1u)];                         // (symbol << 4) | length, 0: not in the table
+    // successor of every offset (64: outside the window or unknown)
+    int jp = e ? l + (int)(e & 15u) : 64;
+    jp = jp > 64 ? 64 : jp;
+    int pos = 0;   // lane k: the offset of the k-th symbol behind P
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = __builtin_amdgcn_ds_bpermute((pos & 63) << 2, jp);
+        if ((l >> i) & 1) pos = pos >= 64 ? 64 : g;
+        const int gg = __builtin_amdgcn_ds_bpermute((jp & 63) << 2, jp);
+        jp = jp >= 64 ? 64 : gg;
+    }
+    const uint32_t ek = (uint32_t)__builtin_amdgcn_ds_bpermute((pos & 63) << 2, (int)e);
+    const bool lit = l < INF_RUN && pos < 64 && ek != 0u && (ek >> 4) < 256u;
+    const unsigned long long bad = __ballot(!lit);   // (never zero: lanes from INF_RUN on)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)bad) - 1);
+    // hit: the run ended at a symbol that is no table literal (a match, the end of the block, a long code) -- the symbol
+    // loop's next; otherwise at the end of the window or after INF_RUN literals, and another run may follow
+    hit = n < (uint32_t)INF_RUN && __builtin_amdgcn_readlane(pos, (int)n) < 64;
+    if (n == 0u) return 0u;
+    if ((uint32_t)l < n) L->win[(o.pos + (uint32_t)l) & (INF_WIN - 1)] = (uint8_t)(ek >> 4);
+    const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane(pos + (int)(ek & 15u), (int)(n - 1u));
+    o.pos += n;
+    b.seek_bit(P + adv);
+    return n;
 }
 
 __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
@@ -357,8 +436,50 @@ __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
         if (!inf_build(&L.lit, L.lens, nlit)) { st = INF_ERR_LENGTHS; break; }
         if (!inf_build(&L.dist, L.lens + nlit, ndist)) { st = INF_ERR_LENGTHS; break; }
         // ---- the symbols of the block
+        uint32_t misses = 0u, pause = 0u;   // the literal runs pause where matches follow each other
+        bool try_run = true;
+#ifdef SGK_INF_STATS
+        uint32_t st_runs = 0, st_lits = 0, st_zero = 0, st_moved = 0, st_serial = 0, st_paused = 0;
+        unsigned long long st_trun = 0, st_tser = 0, st_t0 = 0, st_tblock = __builtin_amdgcn_s_memtime();
+#define INF_T0() (st_t0 = __builtin_amdgcn_s_memtime())
+#define INF_T1(acc) (acc += __builtin_amdgcn_s_memtime() - st_t0)
+#define INF_STAT(x) (++x)
+#define INF_STAT_ADD(x, v) (x += (v))
+#else
+#define INF_STAT(x)
+#define INF_STAT_ADD(x, v)
+#define INF_T0()
+#define INF_T1(acc)
+#endif
         for (;;) {
             b.refill();
+            if (SGK_INF_RUN && pause == 0u && try_run) {
+                bool hit = false;
+                INF_T0();
+                const uint32_t nrun = inf_literal_run(&L, &L.lit, b, o, hit);
+                INF_T1(st_trun);
+                if (nrun == ~0u) {
+                    INF_STAT(st_moved);
+                } else if (nrun) {
+                    INF_STAT(st_runs);
+                    INF_STAT_ADD(st_lits, nrun);
+                    misses = 0u;
+                    if (o.pos - o.flushed >= (uint32_t)INF_FLUSH) {
+                        if (o.pos > o.cap) { st = INF_ERR_ROOM; break; }
+                        if (b.overrun()) { st = INF_ERR_TRUNCATED; break; }
+                        __syncthreads();
+                        while (o.pos - o.flushed >= (uint32_t)INF_FLUSH) inf_flush(&L, o, INF_FLUSH);
+                    }
+                    if (!hit) continue;   // (else the symbol loop takes the symbol that ended the run, without another try)
+                }
+                else {
+                    INF_STAT(st_zero);
+                    if (++misses >= 4u) { pause = 32u; misses = 0u; }
+                }
+            } else if (pause) { --pause; INF_STAT(st_paused); }
+            try_run = true;
+            INF_STAT(st_serial);
+            INF_T0();
             const int s = inf_decode(&L.lit, b);
             if (s < 256) {
                 if (s < 0) { st = INF_ERR_CODE; break; }
@@ -414,6 +535,7 @@ __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
                 __syncthreads();
                 o.pos += len;
             }
+            INF_T1(st_tser);
             if (o.pos - o.flushed >= (uint32_t)INF_FLUSH) {
                 // (once per KB of output: the room and the input's end are looked at here, not per symbol.  Behind the
                 // input's end the reader yields zero bits: at most a KB of output is decoded from them before this
@@ -424,6 +546,11 @@ __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
                 while (o.pos - o.flushed >= (uint32_t)INF_FLUSH) inf_flush(&L, o, INF_FLUSH);
             }
         }
+#ifdef SGK_INF_STATS
+        if (r == 0 && l == 0)
+            printf("block: runs %u literals-in-runs %u zero-runs %u window-moved %u serial %u (paused %u); 100 MHz ticks: runs %llu serial %llu block %llu\n", st_runs, st_lits,
+                   st_zero, st_moved, st_serial, st_paused, st_trun, st_tser, (unsigned long long)__builtin_amdgcn_s_memtime() - st_tblock);
+#endif
         if (st == INF_OK && b.overrun()) st = INF_ERR_TRUNCATED;
         if (st == INF_OK && o.pos > o.cap) st = INF_ERR_ROOM;
     }
