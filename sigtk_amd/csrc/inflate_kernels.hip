@@ -285,9 +285,10 @@ constexpr int INF_RUN = 16;
 #define SGK_INF_RUN 1   // 0: the symbol loop alone (development: A/B)
 #endif
 template <int TB, int NS>
-__device__ __forceinline__ uint32_t inf_literal_run(InfLds *L, const InfTables<TB, NS> *t, InfBits &b, InfOut &o, bool &hit) {
+__device__ __forceinline__ uint32_t inf_literal_run_at(InfLds *L, const InfTables<TB, NS> *t, const InfBits &b, InfOut &o,
+                                                       uint32_t &P, bool &hit) {
     const int l = lane_id();
-    const uint32_t P = b.bit_pos(), k0 = P >> 5, sh = P & 31u;
+    const uint32_t k0 = P >> 5, sh = P & 31u;
     if ((k0 >> 6) != b.chunk) return ~0u;   // (the input window has just moved on: these few bits are the symbol loop's)
     const uint32_t w0 = b.peek_dword(k0), w1 = b.peek_dword(k0 + 1u), w2 = b.peek_dword(k0 + 2u), w3 = b.peek_dword(k0 + 3u);
     const uint32_t a0 = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh);
@@ -318,8 +319,26 @@ __device__ __forceinline__ uint32_t inf_literal_run(InfLds *L, const InfTables<T
     if ((uint32_t)l < n) L->win[(o.pos + (uint32_t)l) & (INF_WIN - 1)] = (uint8_t)(ek >> 4);
     const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane(pos + (int)(ek & 15u), (int)(n - 1u));
     o.pos += n;
-    b.seek_bit(P + adv);
+    P += adv;
     return n;
+}
+// runs one behind the other from the bit reader's position, while they end at the window's end and the ring has room; the
+// bit reader is moved once, behind the last.  Returns the literals written, ~0u: none, because the input window is moving.
+template <int TB, int NS>
+__device__ __forceinline__ uint32_t inf_literal_run(InfLds *L, const InfTables<TB, NS> *t, InfBits &b, InfOut &o, bool &hit) {
+    uint32_t P = b.bit_pos(), total = 0u;
+    for (;;) {
+        const uint32_t n = inf_literal_run_at(L, t, b, o, P, hit);
+        if (n == ~0u) {
+            if (total == 0u) return ~0u;
+            hit = false;
+            break;
+        }
+        total += n;
+        if (n == 0u || hit || o.pos - o.flushed >= (uint32_t)INF_FLUSH) break;
+    }
+    if (total) b.seek_bit(P);
+    return total;
 }
 
 __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
