@@ -1,9 +1,8 @@
 """TSV grammar of sigtk's per-record subtools (reference: src/cfunc.c, src/jnn.c:309-350).
 
-Python mirror of the printers so that results coming back through the C-ABI (or from
-the test oracle) can be compared byte-for-byte with the reference CLI's stdout.  The
-product CLI (sigtk_amd/host) prints from C; this module is the same grammar for the
-Python host API and the parity tests.
+TEST INFRASTRUCTURE.  Python mirror of the printers so that results coming back through the
+C-ABI (or from the test oracle) can be compared byte-for-byte with the reference CLI's
+stdout.  The product CLI (sigtk_amd/host) prints from C; nothing of the product imports this.
 
 ``%f`` of a float32 is printed by C after promotion to double; Python's ``'%f' % float(x)``
 formats the identical double with correct rounding, so the bytes agree with glibc.
