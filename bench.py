@@ -219,7 +219,7 @@ def main():
                     "limiter": {2: "vector instruction issue (bit-exact f64/f32 expression tree; DESIGN.md 3.1), not "
                                    "HBM: `bound` names the roofline the contract prices against",
                                 3: "vector instruction issue (k_event, RNA parameters: 2 waves per SIMD)",
-                                4: "HBM (k_stat_wave with pA output: 100 GB in 21.7 ms, 57 % VALU busy)",
+                                4: "HBM (k_stat_wave with pA output: 100 GB in 19.7 ms = 5.1 TB/s, 0.76 VALU busy)",
                                 5: "vector instruction issue (k_event) after the HBM-bound stat+pa pass"}[args.config],
                     "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
                     "dominant_kernel": dominant, "path_ms": round(path_ms, 4), "recorded_pmc": recorded}

@@ -12,7 +12,7 @@ import sys
 
 
 def kname(name):
-    for k in ("k_event_multi", "k_event_fallback", "k_event_rec", "k_seg_plan", "k_order", "k_event"):
+    for k in ("k_event_multi", "k_event_seg", "k_event_fallback", "k_event_rec", "k_seg_plan", "k_order", "k_event"):
         if k in name:
             return k
     return None
