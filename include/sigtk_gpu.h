@@ -173,7 +173,8 @@ typedef struct sgk_event_status {
  *                            lanes lanes each (a power of two, 1 .. 32)           (0: chosen per batch, -1: off)
  *   short_max                (0: 16 384, 65 536 with RNA parameters; a power of two >= 1024)
  *   tail_split               a batch of fewer than 8 rounds of wavefronts: the reads of its last, partial round are cut
- *                            into segments so that the GPU drains on small units  (0: chosen per batch, -1: off,
+ *                            into segments so that the GPU drains on small units  (0: chosen per batch -- where it
+ *                            was measured to pay: a small batch, a small last round, DESIGN.md 3.1 --, -1: off,
  *                            n > 0: the last n reads are cut whatever the batch -- tuning / tests) */
 typedef struct sgk_event_options {
     uint32_t segment_len, long_min;
