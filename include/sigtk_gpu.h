@@ -155,8 +155,8 @@ typedef struct sgk_event_status {
     uint32_t n_long_replays;     /* lanes (chunks) in which a run of the lazily evaluated long detector could not be
                                   * proven silent and was re-played exactly (diagnostic)  */
     uint64_t n_events_total;
-    uint32_t n_split_reads;      /* reads taken by several wavefronts: long reads (segments of 131 072 samples, reads
-                                  * of at least 262 144) and the reads of the tail split    */
+    uint32_t n_split_reads;      /* reads taken by several wavefronts: long reads (from long_min samples on, in
+                                  * segments of segment_len) and the reads of the tail split */
     uint32_t n_segments;         /* their segments                                         */
     uint32_t n_seam_reruns;      /* segments whose speculative start was wrong and that were run again */
     uint32_t reserved;
@@ -166,7 +166,9 @@ typedef struct sgk_event_status {
  * process-wide configuration and reads no environment variable: two callers in one process may use different options
  * at the same time; size a workspace with the options the call will use.  Results do not depend on any of them.
  *   segment_len / long_min   a read of at least long_min samples is cut into segments of segment_len samples (a multiple
- *                            of 1024), one wavefront each                         (0: 131 072 / 262 144)
+ *                            of 1024), one wavefront each      (both 0: chosen per batch -- long_min = 0.9 x the
+ *                            batch's samples per wavefront slot, between 131 072 and 262 144, segments of half of it;
+ *                            sgk_event_plan_opt tells)
  *   warmup                   speculative warm-up in samples, a multiple of 16, <= 512  (0: the presets' own; tests use
  *                            16 to make speculation fail at every few chunk boundaries)
  *   lanes_per_short_read     short reads (< short_max samples) in large batches: a wavefront takes 64 / lanes reads,

@@ -65,6 +65,7 @@ EvSegConfig event_config(const sgk_event_options_t *o) {
     c.multi = 0;
     c.multi_max = 0;
     c.tail_split = 0;
+    c.auto_geometry = !o || (o->segment_len == 0 && o->long_min == 0);
     if (!o) return c;
 #ifdef SGK_DEV
     c.dev = o->reserved[0];
@@ -102,6 +103,25 @@ static uint32_t event_wave_slots(int rna) {
         cus[dev] = v;
     }
     return (uint32_t)cus[dev] * 4u * (rna ? 2u : 3u);
+}
+
+// From what length on a read is shared by several wavefronts, per batch (round 5).  A read should be cut when its one
+// wavefront would outlast the rest of the batch -- which depends on the batch: at 10 000 x 100 000 samples (a third of
+// a millisecond per 100 000 samples and wave, 3.6 ms per batch) reads up to 262 144 samples finish inside it and cutting
+// them only costs (log-normal lengths around 100 000, 10^9 samples: 3.59 ms with 131 072-sample segments from 262 144 on,
+// 3.72 with 65 536 from 131 072 on); at 3 000 such reads the same geometry leaves the GPU waiting for a few 200 000-sample
+// reads (1.85 ms against 1.49; 3 000 x 100 000 + 16 x 250 000: 1.65 against 1.15).  The batch's samples per wave slot are
+// what a wave's share of it is: long_min = 0.9 of that, between 131 072 and 262 144; segments of half of it.
+// tests/test_gpu_event_long.py::test_long_read_threshold_is_no_cliff times both ends of the range on both kinds of batch.
+EvSegConfig event_config_for(const EvSegConfig &c0, uint64_t n_samples, int rna) {
+    EvSegConfig c = c0;
+    if (!c.auto_geometry) return c;
+    uint64_t lm = n_samples / event_wave_slots(rna) * 9u / 10u;
+    lm = (lm + 2047u) / 2048u * 2048u;
+    lm = lm < 131072u ? 131072u : (lm > 262144u ? 262144u : lm);
+    c.long_min = (uint32_t)lm;
+    c.seg_len = (uint32_t)(lm / 2u);
+    return c;
 }
 
 // The tail split (event_kernels.hip: seg_len_of).  A batch of fewer than 8 rounds of waves whose last round is a SMALL
@@ -195,8 +215,9 @@ EvWorkspace event_workspace_layout(const EvSegConfig &c, uint32_t n_reads, uint6
     // (the layout does not know the preset: the larger of the two presets' capacities)
     {
         uint32_t s0 = 0, l0 = 0, s1 = 0, l1 = 0;
-        event_seg_capacity(c, n_reads, n_samples, max_read_len, 0, event_batch_packed(c, n_reads, n_samples, max_read_len, 0), s0, l0);
-        event_seg_capacity(c, n_reads, n_samples, max_read_len, 1, event_batch_packed(c, n_reads, n_samples, max_read_len, 1), s1, l1);
+        const EvSegConfig c0 = event_config_for(c, n_samples, 0), c1 = event_config_for(c, n_samples, 1);
+        event_seg_capacity(c0, n_reads, n_samples, max_read_len, 0, event_batch_packed(c0, n_reads, n_samples, max_read_len, 0), s0, l0);
+        event_seg_capacity(c1, n_reads, n_samples, max_read_len, 1, event_batch_packed(c1, n_reads, n_samples, max_read_len, 1), s1, l1);
         w.max_segs = s0 > s1 ? s0 : s1;
         w.max_long = l0 > l1 ? l0 : l1;
     }
@@ -270,8 +291,8 @@ static int run_event(const void *samples, bool float_input, const uint64_t *offs
     if (reinterpret_cast<uintptr_t>(samples) & 15u) return SGK_ERR_ALIGN;
     if (reinterpret_cast<uintptr_t>(events) & 15u) return SGK_ERR_ALIGN;
     if (reinterpret_cast<uintptr_t>(ws) & 63u) return SGK_ERR_ALIGN;
-    const EvSegConfig sc = event_config(opt);
-    const EvWorkspace w = event_workspace_layout(sc, n_reads, n_samples, max_read_len, ws_bytes);
+    const EvSegConfig sc0 = event_config(opt), sc = event_config_for(sc0, n_samples, rna);
+    const EvWorkspace w = event_workspace_layout(sc0, n_reads, n_samples, max_read_len, ws_bytes);
     if (w.n_fb_blocks == 0 || w.total > ws_bytes) return SGK_ERR_WORKSPACE;
     char *base = static_cast<char *>(ws);
     EvArgs a;
@@ -484,7 +505,7 @@ int sgk_event_status(const void *ws, sgk_event_status_t *out, void *stream) {
 int sgk_event_plan_opt(uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna, const sgk_event_options_t *opt,
                        sgk_event_plan_t *out) {
     if (!out) return SGK_ERR_ARG;
-    const sgk::EvSegConfig sc = sgk::event_config(opt);
+    const sgk::EvSegConfig sc = sgk::event_config_for(sgk::event_config(opt), n_samples, rna);
     uint32_t max_segs = 0, max_long = 0, lanes = 0, mmax = 0, sf = n_reads, ss = 0;
     const bool sorted = n_reads >= sgk::ORDER_MIN_READS && (uint64_t)max_read_len * n_reads > n_samples + n_samples / 4;
     sgk::event_multi_plan(sc, n_reads, n_samples, max_read_len, rna, sorted, lanes, mmax);

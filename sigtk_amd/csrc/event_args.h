@@ -127,8 +127,11 @@ struct EvSegConfig {
     int multi;  // lanes per short read: 0 = chosen per batch, -1 = off (64 lanes per read), 1 .. 32 = forced
     uint32_t multi_max;  // 0 = default; reads shorter than this (a power of two) count as short
     int tail_split;      // 0 = chosen per batch, -1 = off
+    bool auto_geometry;  // neither segment_len nor long_min was given: event_config_for picks them per batch
 };
 EvSegConfig event_config(const sgk_event_options_t *opt);  // null: the defaults
+// the configuration with the long reads' geometry resolved for a batch of these totals and this preset
+EvSegConfig event_config_for(const EvSegConfig &c, uint64_t n_samples, int rna);
 void event_multi_plan(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,
                       bool sorted, uint32_t &multi_lanes, uint32_t &multi_max);
 void event_tail_plan(const EvSegConfig &c, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len, int rna,

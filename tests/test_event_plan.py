@@ -40,7 +40,13 @@ def test_defaults_and_no_long_reads(lib):
     # a null options pointer is the defaults
     from sigtk_amd import api
     q = api.EventPlan()
-    assert lib.sgk_event_plan_opt(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0 and q.segment_len == 131072
+    assert lib.sgk_event_plan_opt(10, 10 * 5000, 5000, 0, None, C.byref(q)) == 0 and q.segment_len == 65536
+    # the long reads' geometry follows the batch (api.hip: event_config_for): long_min = 0.9 x the batch's samples per
+    # wavefront slot, between 131 072 and 262 144, segments of half of it; an explicit segment_len / long_min is kept
+    assert [(plan(lib, [100000] * n)[0].long_min, plan(lib, [100000] * n)[0].segment_len) for n in (3000, 6000, 10000)] == \
+        [(131072, 65536), (176128, 88064), (262144, 131072)]
+    assert plan(lib, [100000] * 10000, rna=1)[0].long_min == 262144 and plan(lib, [100000] * 3000, rna=1)[0].long_min == 133120
+    assert plan(lib, [100000] * 3000, opt=opts(long_min=200000))[0].long_min == 200000
 
 
 def test_segment_capacities_cover_any_batch_with_these_totals(lib):

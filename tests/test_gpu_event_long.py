@@ -28,9 +28,10 @@ def test_long_reads_default_segments(gpu, oracle, rna):
     reads, dig, off, rng = gpu.synth_reads_host(len(lens), lens, seed=21 + rna, kind=rna)
     got, st = gpu.event(reads, dig, off, rng, rna)
     _check_events(oracle, reads, dig, off, rng, rna, got)
-    # (a batch of seven reads is a partial round of waves: the tail split cuts the 262 143- and the 100 000-sample read
-    # as well, into segments of 82 944 samples = ceil(mean / 8) rounded up to 1024)
-    assert st.n_split_reads == 6 and st.n_segments == 6 + 3 + 2 + 23 + 4 + 2
+    # (a batch this small: reads from 131 072 samples on are cut into segments of 65 536, api.hip: event_config_for; and it
+    # is a partial round of waves: the tail split cuts the 100 000-sample read as well, into segments of 82 944 samples =
+    # ceil(mean / 8) rounded up to 1024)
+    assert st.n_split_reads == 6 and st.n_segments == 11 + 5 + 4 + 4 + 2 + 46
     assert st.n_capacity_overflow == 0 and st.n_fallback_reads == 0
     assert st.n_events_total == sum(g.start.size for g in got)
 
@@ -206,4 +207,51 @@ def test_tail_split_rule_is_no_cliff(gpu):
         del b
         torch.cuda.empty_cache()
     assert [r[1] for r in report] == ["split", "whole"] * 3, report
+    print(report)
+
+
+def test_long_read_threshold_is_no_cliff(gpu):
+    """From what length on a read is shared by several wavefronts follows the batch (api.hip: event_config_for): 262 144
+    samples (segments of 131 072) in a batch of 10^9 samples, 131 072 (65 536) in one of 3 x 10^8.  Both geometries are
+    timed on both kinds of batch: what the rule picks may be at most 1.10 x the other (+ 30 us)."""
+    import torch
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+
+    def timed(b, seg, lmin):
+        o = gpu.EVENT_OPTIONS
+        old = (o.segment_len, o.long_min)
+        o.segment_len, o.long_min = seg, lmin
+        try:
+            arena = device.EventArena(b)
+        finally:
+            o.segment_len, o.long_min = old
+        for _ in range(3):
+            device.event(b, arena, 0)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); device.event(b, arena, 0); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    rs = np.random.RandomState(5)
+    ragged = np.clip(100000 * np.exp(rs.normal(-0.32, 0.8, size=10000)), 200, 1600000).astype(np.int64)
+    few_long = np.full(3016, 100000, dtype=np.int64)
+    few_long[:16] = 250000
+    report = []
+    for name, lens, want in (("10 000 log-normal reads", ragged, 262144), ("3 000 reads + 16 of 250 000", few_long, 131072),
+                             ("3 000 log-normal reads", ragged[:3000], 131072)):
+        b = device.synth_reads(len(lens), 100000, seed=13, kind=0, device=dev, lengths=lens)
+        plan = gpu.event_plan(len(lens), b.total_samples, int(lens.max()), 0)
+        t_rule = timed(b, 0, 0)
+        other = (65536, 131072) if plan.long_min > 200000 else (131072, 262144)
+        t_other = timed(b, *other)
+        report.append((name, plan.long_min, round(t_rule, 3), round(t_other, 3)))
+        assert abs(int(plan.long_min) - want) <= 8192, report
+        assert t_rule <= 1.10 * t_other + 0.03, report
+        del b
+        torch.cuda.empty_cache()
     print(report)
