@@ -272,7 +272,8 @@ typedef struct sgk_stat_options {
     int32_t kernels;
     int32_t long_min;   /* reads of at least this many samples get 16 workgroups (64 wavefronts) of their own before
                          * the wave-per-read kernel runs (sequential float sums composed from tile summaries, stat's
-                         * histogram and pA output, jnn's automaton): 0 = chosen per batch, max(262 144, n_samples / 2048) (jnn: / 3072)
+                         * histogram and pA output, jnn's automaton): 0 = chosen per batch and tool, max(n_samples / 2048 (jnn: / 3072),
+                         * a floor between 131 072 and 262 144 by the size of the batch; sgk_stat_plan tells)
                          * -- the reads one wavefront would still be busy with when the rest of the batch is done (and
                          * none if that still lists more than 128 reads: a batch of similar long reads balances itself);
                          * -1 = never; else the threshold (>= 8 192).  Results do not depend on it.  Needs the workspace

@@ -80,8 +80,8 @@ int stat_f32(const float *x, int n, float *out3) {
 
 // a per-read call on a long read takes the long-read path of the batch API as well (a 3 000 001-sample read: 1 ms instead
 // of 10): the workspace it needs, sized for this one read
-static int shim_long(StatArgs &a, DevBuf &ws, uint32_t auto_div) {
-    if (a.b.max_read_len < LC_LONG_MIN) return SGK_OK;
+static int shim_long(StatArgs &a, DevBuf &ws, LongRule auto_div) {
+    if (a.b.max_read_len < LC_LONG_MIN / 2) return SGK_OK;   // (the lowest per-batch threshold, stat_args.h: LongRule)
     const size_t bytes = order_workspace_bytes(a.b.n_reads) + long_workspace_bytes(a.b.n_samples, a.b.max_read_len);
     int rc = ws.alloc(bytes);
     if (rc != SGK_OK) return rc;

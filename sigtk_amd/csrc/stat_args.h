@@ -77,9 +77,21 @@ constexpr uint32_t LC_LONG_MIN = 262144;      // default long_min
 constexpr uint32_t LC_AUTO_MAX_READS = 128;   // with the per-batch threshold: more long reads than this and none is treated as long
 constexpr uint32_t LC_LONG_MIN_FLOOR = 8192;  // smallest long_min an option can ask for
 size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len);
-// the threshold a call uses: the option if positive, else max(LC_LONG_MIN, n_samples / auto_div)
-uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, uint32_t auto_div);
-constexpr uint32_t LC_AUTO_DIV_STAT = 2048, LC_AUTO_DIV_JNN = 3072, LC_AUTO_DIV_PREFIX = 2048;
+// The threshold a call uses: the option if positive, else per batch and tool
+//     max(n_samples / div, clamp(n_samples / floor_div, floor_lo, 262 144))       (floor_div 0: floor_lo as it is)
+// -- a read is long when its one wavefront would outlast the rest of the batch (the first term, large batches), and never
+// under what the long path's barriers cost (the second: 262 144 samples in a batch of 3 x 10^8 samples, less in a smaller
+// one, where fewer reads hide a long one.  Round 5, measured with 4 - 8 reads of 150 000 - 800 000 samples among 1 000 /
+// 3 000 / 10 000 / 20 000 of 100 000: with the floor at 262 144 everywhere a batch of 1 000 reads with four of 200 000
+// took 0.49 / 0.65 / 0.48 ms (stat / jnn / prefix) against 0.33 / 0.41 / 0.42 with those four on the long path, while
+// 3 000 reads with eight of 150 000 are better off without it for stat and prefix (0.50 against 0.62, 0.57 against 0.59).
+// tests/test_gpu_stat_long.py::test_long_read_threshold_is_no_cliff times both choices either side of the threshold.)
+struct LongRule {
+    uint32_t div, floor_lo, floor_div;
+};
+uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, LongRule rule);
+constexpr LongRule LC_AUTO_DIV_STAT = {2048, 131072, 1024}, LC_AUTO_DIV_JNN = {3072, 131072, 0},
+                   LC_AUTO_DIV_PREFIX = {2048, 196608, 512};
 // Which of the two implementations a batch of SIMILAR read lengths (the longest at most 1.5 x the mean) takes when the
 // caller leaves the choice to the library.  The lane-per-read kernels have 64 reads per wavefront and none of the wave
 // kernels' per-read costs, so they win where there are MANY reads for their length; measured over a grid of batch shapes
@@ -117,8 +129,8 @@ inline uint32_t lane_rule_max_len(const LaneRule &q, uint32_t n_reads) {
 }
 bool stat_lane_per_read(int tool /* 0 stat, 1 jnn, 2 prefix, 3 stat + pA */, int kernels, uint32_t n_reads, uint64_t n_samples, uint32_t max_read_len);
 // fills a.long_* from the workspace behind the dispatch order (when the batch has a long read and there is room),
-// clears the header and lists the long reads; auto_div: long_min = max(262 144, n_samples / auto_div) when the option is 0
-int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st);
+// clears the header and lists the long reads; rule: the tool's threshold when the option is 0 (long_threshold)
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, LongRule rule, hipStream_t st);
 
 // workspace layout of stat / jnn / prefix: [0, 64) counters (jnn: overflow count), then the dispatch order of the
 // wave-per-read kernels (n_reads x 4 bytes) and the 2 x 128 words of its counting sort

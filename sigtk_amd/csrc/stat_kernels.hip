@@ -2886,13 +2886,17 @@ size_t long_workspace_bytes(uint64_t n_samples, uint32_t max_read_len) {
     return sizeof(LongHdr) + (size_t)LC_CAP * (4 + sizeof(LongSums) + sizeof(LongWork) + LC_HIST_BINS * 4) +
            (size_t)long_pool_tiles(n_samples, max_read_len) * 16;
 }
-uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, uint32_t auto_div) {
-    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : n_samples / auto_div;
-    if (opt_long_min <= 0 && lm64 < LC_LONG_MIN) lm64 = LC_LONG_MIN;
+uint32_t long_threshold(uint64_t n_samples, int32_t opt_long_min, LongRule rule) {
+    uint64_t lm64 = opt_long_min > 0 ? (uint64_t)opt_long_min : n_samples / rule.div;
+    if (opt_long_min <= 0) {
+        uint64_t fl = rule.floor_div ? n_samples / rule.floor_div : rule.floor_lo;
+        fl = fl < rule.floor_lo ? rule.floor_lo : (fl > LC_LONG_MIN ? LC_LONG_MIN : fl);
+        if (lm64 < fl) lm64 = fl;
+    }
     if (lm64 < LC_LONG_MIN_FLOOR) lm64 = LC_LONG_MIN_FLOOR;
     return lm64 > 0xffffffffull ? 0xffffffffu : (uint32_t)lm64;
 }
-int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, uint32_t auto_div, hipStream_t st) {
+int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, LongRule auto_div, hipStream_t st) {
     a.long_hdr = nullptr;
     a.long_list = nullptr;
     a.longs = nullptr;
@@ -2904,7 +2908,8 @@ int prepare_long(StatArgs &a, void *ws, size_t ws_bytes, int32_t opt_long_min, u
     // By default a read is long when one wavefront would still be busy with it after the rest of the batch is done:
     // a wave takes 2 - 4 ns per sample, the full GPU ~1.3 ps, and the batch's longest reads are dispatched first, so a
     // read of more than n_samples / 2048 samples (jnn, whose wave is slower on a long read: / 3072) decides when the
-    // kernel ends (and one of less than 262 144 samples costs less than the long path's barriers).  Measured on 20 000
+    // kernel ends (and one of less than 131 072 - 262 144 samples, by the size of the batch, costs less than the long
+    // path's barriers: stat_args.h, LongRule).  Measured on 20 000
     // log-normal reads (1 081 of 262 144 samples or more): with all of those on the long path stat takes 6.8 ms
     // instead of 3.9 -- the wave kernels balance them.
     const uint32_t lm = long_threshold(a.b.n_samples, opt_long_min, auto_div);

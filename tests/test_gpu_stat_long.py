@@ -264,3 +264,49 @@ def test_a_job_reports_the_reads_its_long_path_declined(gpu, oracle, fault):
             assert L.sgk_job_long_declined(job.h) == want
     finally:
         job.close()
+
+
+def test_long_read_threshold_is_no_cliff(gpu):
+    """The length from which a read gets 16 workgroups follows the batch and the tool (csrc/stat_args.h: LongRule).  A few
+    reads just over and just under that length among 1 000 / 3 000 / 10 000 reads of 100 000 samples are timed on the path
+    the library picks and on the other (long_min = -1: never; long_min = their length: all of them): the pick may be at
+    most 1.12 x the other (+ 30 us)."""
+    import torch
+    from sigtk_amd import device
+    dev = torch.device("cuda", 0)
+
+    def timed(fn, lm):
+        gpu.stat_configure(0, lm)
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+        finally:
+            gpu.stat_configure(0, 0)
+
+    report = []
+    for n in (1000, 3000, 10000):
+        for tool in ("stat", "jnn", "prefix"):
+            thr = int(gpu.stat_plan(tool, n + 6, (n + 6) * 100000 + 6 * 400000, 500000).long_min)
+            assert thr > 0
+            for L in (int(thr * 0.9) // 64 * 64, int(thr * 1.12) // 64 * 64 + 64):
+                lens = np.full(n + 6, 100000, dtype=np.int64)
+                lens[n // 2:n // 2 + 6] = L
+                b = device.synth_reads(n + 6, 100000, seed=17, kind=0, device=dev, lengths=lens)
+                ar = device.SegArena(b)
+                fn = {"stat": lambda: device.stat(b), "jnn": lambda: device.jnn(b, ar, 0), "prefix": lambda: device.prefix(b, 0, 0)}[tool]
+                picked_long = int(gpu.stat_plan(tool, n + 6, b.total_samples, L).long_min) != 0
+                t_never, t_long = timed(fn, -1), timed(fn, L)
+                t_pick, t_other = (t_long, t_never) if picked_long else (t_never, t_long)
+                report.append((tool, n, L, "long" if picked_long else "wave", round(t_never, 3), round(t_long, 3)))
+                assert t_pick <= 1.12 * t_other + 0.03, report[-1]
+                del b, ar
+                torch.cuda.empty_cache()
+    print(report)

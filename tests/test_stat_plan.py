@@ -58,10 +58,19 @@ def test_the_threshold_follows_the_batch():
     assert plan("prefix", 20000, 100000, longest=3000001).long_min == p.long_min
     # ... among 125 000 it is not long (6.1e6), among 2 000 the floor of the default applies
     assert plan("stat", 125000, 100000, longest=3000001).long_min == 0
-    assert plan("stat", 2000, 100000, longest=3000001).long_min == 262144
+    # (round 5: the floor follows the batch and the tool, stat_args.h LongRule -- stat clamp(n_samples / 1024, 131 072,
+    # 262 144), jnn 131 072, prefix clamp(n_samples / 512, 196 608, 262 144))
+    assert plan("stat", 3000, 100000, longest=3000001).long_min == 262144
+    assert plan("stat", 2000, 100000, longest=3000001).long_min == (2000 * 100000 + 2900001) // 1024
+    assert plan("stat", 1000, 100000, longest=200000).long_min == 131072
+    assert plan("jnn", 3000, 100000, longest=200000).long_min == 131072
+    assert plan("prefix", 1000, 100000, longest=200000).long_min == 196608
+    assert plan("prefix", 1000, 100000, longest=150000).long_min == 0
+    assert plan("prefix", 3000, 100000, longest=250000).long_min == 0
     # a single read
-    assert plan("stat", 1, 3000001).long_min == 262144
-    assert plan("stat", 1, 262143).long_min == 0
+    assert plan("stat", 1, 3000001).long_min == 131072
+    assert plan("stat", 1, 262143).long_min == 131072
+    assert plan("stat", 1, 131071).long_min == 0
 
 
 def test_explicit_thresholds():
