@@ -13,9 +13,6 @@ namespace sgk {
 #ifndef SGK_PA_UNROLL
 #define SGK_PA_UNROLL 4
 #endif
-#ifndef SGK_PA_MODE
-#define SGK_PA_MODE 0
-#endif
 constexpr int PA_SLAB = SGK_PA_SLAB;
 constexpr int PA_UNROLL = SGK_PA_UNROLL;
 
@@ -42,33 +39,6 @@ __global__ __launch_bounds__(256) void k_pa(const int16_t *samples, const uint64
         const int16_t *src = samples + o0;
         float *dst = out + o0;
         const bool vec = ((reinterpret_cast<uintptr_t>(src + b) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + b) & 15u) == 0);
-#if SGK_PA_MODE == 1
-        if (vec) {
-            // (development variant: 8-byte loads, one 16-byte store per lane -- every store instruction a contiguous KB)
-            constexpr int UN = 2 * PA_UNROLL;
-            for (uint64_t p0 = b + (uint64_t)threadIdx.x * 4; p0 < e; p0 += (uint64_t)UN * 256 * 4) {
-                uint2 q[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const uint64_t p = p0 + (uint64_t)u * 256 * 4;
-                    q[u] = (p + 4 <= e) ? *reinterpret_cast<const uint2 *>(src + p) : make_uint2(0u, 0u);
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const uint64_t p = p0 + (uint64_t)u * 256 * 4;
-                    if (p + 4 <= e) {
-                        int16_t s[4];
-                        __builtin_memcpy(s, &q[u], 8);
-                        float4 a;
-                        a.x = to_pa(s[0], sc); a.y = to_pa(s[1], sc); a.z = to_pa(s[2], sc); a.w = to_pa(s[3], sc);
-                        *reinterpret_cast<float4 *>(dst + p) = a;
-                    } else if (p < e) {
-                        for (uint64_t k = p; k < e; ++k) dst[k] = to_pa(src[k], sc);
-                    }
-                }
-            }
-        } else
-#endif
         if (vec) {
             // four 16-byte loads in flight per lane before the first store (the loads of a plain loop wait behind the
             // previous iteration's stores: the compiler cannot know that src and dst do not alias).  (Round 5: 8-byte
