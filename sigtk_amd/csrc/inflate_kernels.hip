@@ -530,12 +530,15 @@ __global__ __launch_bounds__(64) void k_inflate(InfArgs a) {
                 // out[pos + i] = out[pos - dist + (i mod dist)]: every source byte lies in front of pos
                 __syncthreads();   // (the literals lane 0 wrote are in the ring before other lanes read them)
                 if (dist <= (uint32_t)INF_NEAR) {
-                    for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
-                        const uint32_t i = i0 + (uint32_t)l;
-                        if (i < len) {
-                            const uint32_t k = dist >= len ? i : i % dist;
-                            const uint8_t v = L.win[(o.pos - dist + k) & (INF_WIN - 1)];
-                            L.win[(o.pos + i) & (INF_WIN - 1)] = v;
+                    if (dist >= len) {   // (wave-uniform: the usual match, no lane needs i mod dist -- an integer division)
+                        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+                            const uint32_t i = i0 + (uint32_t)l;
+                            if (i < len) L.win[(o.pos + i) & (INF_WIN - 1)] = L.win[(o.pos - dist + i) & (INF_WIN - 1)];
+                        }
+                    } else {
+                        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+                            const uint32_t i = i0 + (uint32_t)l;
+                            if (i < len) L.win[(o.pos + i) & (INF_WIN - 1)] = L.win[(o.pos - dist + i % dist) & (INF_WIN - 1)];
                         }
                     }
                 } else {
