@@ -221,8 +221,11 @@ constexpr uint32_t FLAG_MEDIAN_WHOLE = 1u, FLAG_MEDIAN_ADAPT = 1u, FLAG_MEDIAN_P
 // (16 KB of LDS per wave) lose the occupancy the kernel streams with (16.5 ms), 64 16-bit counters packed two to a word
 // cost more instructions than they save (12.6 ms).
 constexpr int MH_BINS = 32;
+#ifndef SGK_MOM_WAVES
+#define SGK_MOM_WAVES 1
+#endif
 template <int MODE, bool HIST = false>
-__global__ __launch_bounds__(64) void k_moments(StatArgs a) {
+__global__ __launch_bounds__(64, SGK_MOM_WAVES) void k_moments(StatArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[Stream1::LDS_BYTES];
     __shared__ uint32_t mh[HIST ? (MH_BINS + 1) * 64 : 1];  // (+ a row nobody reads: samples outside the window)
     const int lane = lane_id();
