@@ -20,7 +20,7 @@ timeout -s KILL 600 python bench.py --read-len 30000 --reads 33333 --rna 1 --cpu
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 20000 --reads 50000 --rna 1 --cpu-reads 0 > $O/bench_ragged_20k_rna.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --cpu-reads 0 > $O/bench_ragged_5k.json 2>> $O/bench.err
 timeout -s KILL 600 python bench.py --ragged 0.8 --read-len 5000 --reads 200000 --rna 1 --cpu-reads 0 > $O/bench_ragged_5k_rna.json 2>> $O/bench.err
-timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 > $O/prof.log 2>&1
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --cpu-reads 0 > $O/prof.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_write.log 2>&1
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --cpu-reads 0 > $O/pmc_sq.log 2>&1
