@@ -69,8 +69,9 @@ extern "C" {
  * 0.2.2: the long-read path of stat / jnn / prefix declines a read whose workgroups time out at a barrier and the wave
  *        kernel redoes it (no result depends on the long path having worked; sgk_long_status_t::n_timeouts counts those
  *        reads); sgk_stat_options_t::debug_fault (was reserved[0]); sgk_job_long_declined; sgk_inflate, SGK_SIGNAL_ZREC / sgk_job_begin_zrec;
- *        the six-argument plan call is sgk_event_plan_opt; sgk_event_plan is the 0.1.0 five-argument form again (deprecated). */
-#define SGK_VERSION_STRING "0.2.2"
+ *        the six-argument plan call is sgk_event_plan_opt; sgk_event_plan is the 0.1.0 five-argument form again (deprecated).
+ * 0.2.3: SGK_JOB_EVENTS_LENGTHS (additive submit flag). */
+#define SGK_VERSION_STRING "0.2.3"
 
 /* ---- error codes --------------------------------------------------------------- */
 #define SGK_OK 0
@@ -485,6 +486,10 @@ typedef struct sgk_job sgk_job_t;
                             * GPU (sgk_job_begin_zrec) */
 
 #define SGK_JOB_EVENTS_COMPACT 1 /* submit flag: only event start/length are copied back (event -c) */
+#define SGK_JOB_EVENTS_LENGTHS 2 /* submit flag (0.2.3): only the event lengths are copied back -- ev_start, ev_mean and
+                                  * ev_stdv are NULL.  The events of a read are contiguous from sample 0
+                                  * (src/events.c:491-501), so start_i is the sum of the lengths in front of event i: half
+                                  * of SGK_JOB_EVENTS_COMPACT's bytes over PCIe, which is what `event -c` waits for */
 
 typedef struct sgk_job_input {
     int16_t *samples;             /* pinned host (SGK_SIGNAL_INT16): read r at samples + offsets[r] */
@@ -504,7 +509,7 @@ typedef struct sgk_job_output {
     const uint64_t *slots;          /* event / jnn: arena slot of read r's first item (n_reads+1) */
     const uint32_t *counts;         /* event / jnn: items of read r */
     const uint32_t *ev_start, *ev_length;
-    const float *ev_mean, *ev_stdv; /* NULL with SGK_JOB_EVENTS_COMPACT */
+    const float *ev_mean, *ev_stdv; /* NULL with SGK_JOB_EVENTS_COMPACT / _LENGTHS (_LENGTHS: ev_start as well) */
     const int32_t *seg_x, *seg_y;
     const sgk_stat_rec_t *stat;
     const sgk_prefix_rec_t *prefix;

@@ -180,6 +180,7 @@ TOOL_PA, TOOL_EVENT, TOOL_STAT, TOOL_JNN, TOOL_PREFIX, TOOL_ENT, TOOL_QTS = rang
 ENT_HIST_BYTES = 4 * (4 + 8192 + 4096 + 512)   # sizeof(sgk_ent_hist_t)
 SIGNAL_INT16, SIGNAL_SVBZD = 0, 1
 JOB_EVENTS_COMPACT = 1
+JOB_EVENTS_LENGTHS = 2   # only the lengths come back; the starts are their running sums (events are contiguous from 0)
 
 STAT_DTYPE = np.dtype([("raw_mean", "<f4"), ("pa_mean", "<f4"), ("raw_std", "<f4"), ("pa_std", "<f4"),
                        ("raw_median", "<i4"), ("pa_median", "<f4"), ("n", "<u4"), ("reserved", "<u4")])
@@ -247,7 +248,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.sgk_event_status.argtypes = [C.c_void_p, C.POINTER(EventStatus), C.c_void_p]
     ver = L.sgk_version().decode()
     old_ok = os.environ.get("SIGTK_AMD_LIB_ANY") == "1"   # development: an A/B build of an earlier round under the event calls
-    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 2) and not old_ok:
+    if tuple(int(x) for x in ver.split(".")[:3]) < (0, 2, 3) and not old_ok:
         raise SigtkGpuError("%s is version %s: these bindings need the per-call options of 0.2, the long-read status of "
                             "0.2.1 and sgk_event_plan_opt / sgk_job_long_declined of 0.2.2" % (path, ver))
     OE, OS = C.POINTER(EventOptions), C.POINTER(StatOptions)
@@ -637,7 +638,12 @@ class Job:
                 base = C.addressof(ptr.contents) + 4 * o.slots[r]
                 return _np_from(C.cast(base, C.POINTER(C.c_uint32)), k, np.uint32).view(dtype).copy()
             if self._tool == TOOL_EVENT:
-                res["events"] = [Events(seg(o.ev_start, np.uint32, r), seg(o.ev_length, np.uint32, r),
+                def starts(r):
+                    if o.ev_start:
+                        return seg(o.ev_start, np.uint32, r)
+                    ln = seg(o.ev_length, np.uint32, r).astype(np.uint64)
+                    return (np.cumsum(ln) - ln).astype(np.uint32)
+                res["events"] = [Events(starts(r), seg(o.ev_length, np.uint32, r),
                                         seg(o.ev_mean, np.float32, r), seg(o.ev_stdv, np.float32, r))
                                  for r in range(n)]
                 res["status"] = o.event_status

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, int narr, const ui
 }
 
 // events of read r: records src[slots[r] .. +counts[r]) -> the four dense arrays dst[k][doffs[r] ..), k < narr
-// (start, length, mean, stdv as 4-byte items; narr = 2 for `event -c`, which prints lengths only)
+// (start, length, mean, stdv as 4-byte items; narr = 2 for SGK_JOB_EVENTS_COMPACT; narr = 1: the lengths alone)
 __global__ __launch_bounds__(256) void k_gather_events(const sgk_event_rec_t *src, GatherArgs g, int narr,
                                                        const uint64_t *slots, const uint32_t *counts,
                                                        const uint64_t *doffs) {
@@ -394,6 +394,10 @@ __global__ __launch_bounds__(256) void k_gather_events(const sgk_event_rec_t *sr
     const uint32_t c = counts[r] < cap ? counts[r] : (uint32_t)cap;  // an overflowing read keeps what fitted
     for (uint32_t i = threadIdx.x; i < c; i += 256) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + s + i);
+        if (narr == 1) {
+            g.dst[0][d + i] = v.y;
+            continue;
+        }
         g.dst[0][d + i] = v.x;
         g.dst[1][d + i] = v.y;
         if (narr > 2) {
@@ -462,7 +466,7 @@ int sgk_job_submit(sgk_job_t *j, int tool, int rna, int pore, int flags) {
             if ((rc = d2h(j->h_cnt, j->d_cnt, nr * 4, st)) != SGK_OK) return rc;
             // the arena is capacity-sized (sgk_event_slots_for(n) slots per read): gather what was produced into dense ranges on the
             // device and download only that (sgk_job_wait fetches the arrays once the total is known)
-            const int ncopy = (ev && (flags & SGK_JOB_EVENTS_COMPACT)) ? 2 : narr;
+            const int ncopy = (ev && (flags & SGK_JOB_EVENTS_LENGTHS)) ? 1 : ((ev && (flags & SGK_JOB_EVENTS_COMPACT)) ? 2 : narr);
             if ((rc = j->d_doffs.ensure((nr + 1) * 8)) != SGK_OK) return rc;
             hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, j->d_cnt.as<uint32_t>(), j->d_slots.as<uint64_t>(),
                                j->n_reads, 1u, j->d_doffs.as<uint64_t>());
@@ -648,6 +652,11 @@ int sgk_job_output(const sgk_job_t *j, sgk_job_output_t *out) {
         case SGK_TOOL_EVENT:
             out->slots = j->h_doffs.as<uint64_t>();
             out->counts = j->h_cnt.as<uint32_t>();
+            if (j->flags & SGK_JOB_EVENTS_LENGTHS) {
+                out->ev_length = j->h_out[0].as<uint32_t>();
+                out->event_status = j->ev_status;
+                break;
+            }
             out->ev_start = j->h_out[0].as<uint32_t>();
             out->ev_length = j->h_out[1].as<uint32_t>();
             if (!(j->flags & SGK_JOB_EVENTS_COMPACT)) {

@@ -477,7 +477,7 @@ static void batch_launch(pipe_t *P, batch_t *b) {
     }
     int tool = SGK_TOOL_PA, flags = 0;
     switch (P->mode) {
-        case MODE_EVENT: tool = SGK_TOOL_EVENT; flags = P->opt.compact ? SGK_JOB_EVENTS_COMPACT : 0; break;
+        case MODE_EVENT: tool = SGK_TOOL_EVENT; flags = P->opt.compact ? SGK_JOB_EVENTS_LENGTHS : 0; break;
         case MODE_STAT: tool = SGK_TOOL_STAT; break;
         case MODE_PREFIX: tool = SGK_TOOL_PREFIX; break;
         case MODE_JNN: tool = SGK_TOOL_JNN; break;
@@ -512,13 +512,17 @@ static inline void put_id_len(sbuf_t *o, const batch_t *b, uint32_t r) {
 /* print_events, cfunc.c:16-61 */
 static void row_events(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out, uint32_t r, opt_t opt) {
     const uint64_t a = out->slots[r], n = out->counts[r];
-    const uint32_t *st = out->ev_start + a, *ln = out->ev_length + a;
+    const uint32_t *ln = out->ev_length + a;
     if (opt.compact) {
+        /* (the job hands back the lengths alone, SGK_JOB_EVENTS_LENGTHS: the events of a read are contiguous from
+         * sample 0, events.c:491-501, so event[0].start is 0 and the last event's end the sum of the lengths) */
         put_id_len(o, b, r);
         if (n) {
+            uint64_t end = 0;
+            for (uint64_t j = 0; j < n; j++) end += ln[j];
             char *p = sbuf_room(o, 96 + n * 12);
-            p = fmt_u64(p, st[0]); *p++ = '\t';
-            p = fmt_u64(p, (uint64_t)st[n - 1] + ln[n - 1]); *p++ = '\t';
+            p = fmt_u64(p, 0); *p++ = '\t';
+            p = fmt_u64(p, end); *p++ = '\t';
             p = fmt_u64(p, n); *p++ = '\t';
             for (uint64_t j = 0; j < n; j++) {
                 const int mi = (int)ln[j];
@@ -533,6 +537,7 @@ static void row_events(sbuf_t *o, const batch_t *b, const sgk_job_output_t *out,
         }
         sbuf_str(o, "\n", 1);
     } else {
+        const uint32_t *st = out->ev_start + a;
         const float *mean = out->ev_mean + a, *sd = out->ev_stdv + a;
         const size_t idl = b->recs[r].v.id_len;
         char *p = sbuf_room(o, n * (idl + 160) + 8);

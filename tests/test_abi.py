@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = api.load_library()
-    assert lib.sgk_version().decode() == "0.2.2"   # per-call options (0.2.0), long-read status (0.2.1), decline-and-redo + sgk_event_plan_opt (0.2.2)
+    assert lib.sgk_version().decode() == "0.2.3"   # per-call options (0.2.0), long-read status (0.2.1), decline-and-redo + sgk_event_plan_opt (0.2.2), SGK_JOB_EVENTS_LENGTHS (0.2.3)
     assert lib.sgk_strerror(0).decode() == "ok"
     assert "GPU" in lib.sgk_strerror(-3).decode()
 

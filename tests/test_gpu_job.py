@@ -48,6 +48,16 @@ def test_all_subtools_through_a_recycled_job(gpu, oracle, svb):
                 assert np.array_equal(res["events"][r].length.astype(np.uint64), exp.length.astype(np.uint64))
                 assert res["events"][r].mean.size == 0   # not copied back in compact mode
 
+        # the lengths alone (what `event -c` prints): the starts are their running sums -- events are contiguous from 0
+        job.submit(gpu.TOOL_EVENT, sig, dig, off, rng, rna=kind, flags=gpu.JOB_EVENTS_LENGTHS, counts=counts)
+        res = job.wait()
+        for r, raw in enumerate(reads):
+            if raw.size:
+                exp = oracle.event_raw(raw, dig[r], off[r], rng[r], kind)
+                assert np.array_equal(res["events"][r].length.astype(np.uint64), exp.length.astype(np.uint64))
+                assert np.array_equal(res["events"][r].start.astype(np.uint64), exp.start.astype(np.uint64))
+                assert res["events"][r].mean.size == 0
+
         job.submit(gpu.TOOL_STAT, sig, dig, off, rng, counts=counts)
         st = job.wait()["stat"]
         for r, raw in enumerate(reads):
