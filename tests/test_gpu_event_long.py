@@ -162,18 +162,27 @@ def test_flat_signal_costs_no_more_than_its_length(gpu, oracle, configure):
             assert dt < 2.0, "flat reads took %.1f s (segments %d / %d, rna %d)" % (dt, seg, lmin, rna)
 
 
-def test_tail_split_rule_is_no_cliff(gpu):
+@pytest.mark.parametrize("rna", [0, 1])
+def test_tail_split_rule_is_no_cliff(gpu, rna):
     """VERDICT r04 task 8b: the tail split (api.hip: event_tail_plan -- the reads of a batch's last, partial round of
     wavefronts are cut into segments iff the batch is at most 0.55 of a round, or that round at most a quarter of a round
     behind one full round, a sixth behind more) is a measured choice (tools/tail_sweep.py ->
     profiles/r05_tail_split_sweep.txt).  Either side of every cut the batch is timed with and without the split: what the
     rule picks may be at most 1.10 x the other (+ 30 us).  The events are the same either way (test_gpu_device_api.py,
     the soaks); this guards the rule against a kernel change that moves the cross-over -- its first run found the round's
-    first rule (a third / a sixth) 25 % slower than the other choice on batches of 1 100 - 1 600 reads."""
+    first rule (a third / a sixth) 25 % slower than the other choice on batches of 1 100 - 1 600 reads.
+    RNA preset (two waves per SIMD): a batch of at most 7 / 8 of a round is cut, and no read behind a full round."""
     import torch
     from sigtk_amd import device
     dev = torch.device("cuda", 0)
-    slots = 3072   # wave slots of the DNA preset: 256 CUs x 4 SIMDs x 3 waves (k_event<3, short>: 168 registers)
+    # wave slots: 256 CUs x 4 SIMDs x 3 waves with the DNA preset (k_event<3, short>: 168 registers), x 2 with the RNA preset
+    slots = 2048 if rna else 3072
+    if rna:
+        sizes, want = (slots * 7 // 8 - 40, slots * 7 // 8 + 60, slots + slots // 8, 3 * slots + slots // 8), ["split", "whole", "whole", "whole"]
+    else:
+        sizes = (slots * 11 // 20 - 40, slots * 11 // 20 + 60, slots + slots // 4 - 12, slots + slots // 4 + 40,
+                 3 * slots + slots // 6 - 12, 3 * slots + slots // 6 + 40)
+        want = ["split", "whole"] * 3
 
     def timed(b, tail):
         old = gpu.EVENT_OPTIONS.tail_split
@@ -183,21 +192,20 @@ def test_tail_split_rule_is_no_cliff(gpu):
         finally:
             gpu.EVENT_OPTIONS.tail_split = old
         for _ in range(3):
-            device.event(b, arena, 0)
+            device.event(b, arena, rna)
         torch.cuda.synchronize()
         best = 1e9
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); device.event(b, arena, 0); e1.record()
+            e0.record(); device.event(b, arena, rna); e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         return best
 
     report = []
-    for n in (slots * 11 // 20 - 40, slots * 11 // 20 + 60, slots + slots // 4 - 12, slots + slots // 4 + 40,
-              3 * slots + slots // 6 - 12, 3 * slots + slots // 6 + 40):
-        b = device.synth_reads(n, 100000, seed=9, kind=0, device=dev)
-        plan = gpu.event_plan(n, b.total_samples, 100000, 0)
+    for n in sizes:
+        b = device.synth_reads(n, 100000, seed=9, kind=rna, device=dev)
+        plan = gpu.event_plan(n, b.total_samples, 100000, rna)
         split = plan.tail_segment_len != 0
         rem = n % slots
         t_off, t_on = timed(b, -1), timed(b, rem)
@@ -206,7 +214,7 @@ def test_tail_split_rule_is_no_cliff(gpu):
         assert t_rule <= 1.10 * t_other + 0.03, report
         del b
         torch.cuda.empty_cache()
-    assert [r[1] for r in report] == ["split", "whole"] * 3, report
+    assert [r[1] for r in report] == want, report
     print(report)
 
 
